@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""bench.py -- Gibbs-product throughput of the HIP path on MI355X (BASELINE.json metric).
+
+A "step" is one `prodAppxMSGibbsS`-equivalent pass: every rank draws its Nout chains of the
+headline workload (BASELINE config 3: 6-D, 4 densities x 1000 points, Nout = 2048 per GPU,
+Niter = 10, fp64) from densities already resident in HBM, then (N > 1) the one all-gather of the
+product samples over RCCL.  Weak scaling: per-GPU work is fixed.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  `roofline.achieved` = algorithmic bytes (Nout * E * B,
+E = (Niter+1) * sum_j sum_l n_{j,l} kernel evaluations per sample, B = (2D+1)*8 bytes) divided by
+the kernel's average duration measured with HIP events on the launch stream.  The working set
+(832 KB) is cache resident, so this is a normalised throughput against the 8 TB/s HBM peak, not
+DRAM traffic; `traffic` carries the PMC-measured HBM bytes per launch when a profile is committed.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+CONFIGS = {
+    # name: (D, M, N, Nout per GPU, Niter, precision, config_id)
+    "c2": (2, 3, 200, 256, 5, 64, 2),
+    "c3": (6, 4, 1000, 2048, 10, 64, 3),
+    "c4": (3, 8, 5000, 2048, 10, 64, 4),      # 16384 over 8 GPUs
+    "c5": (6, 4, 10000, 8192, 20, 32, 5),     # 65536 over 8 GPUs, fp32
+}
+
+
+def synth_inputs(kdehip, D, M, N, config_id):
+    """density j = N points from a 3-component Gaussian mixture (centres U(-2,2)^D,
+    std 0.5, equal mixing), uniform weights, Silverman bandwidth; all draws from the library's host
+    Philox with key 0x4B44452D48495000 + config_id, stream = j."""
+    key = 0x4B44452D48495000 + config_id
+    pts_all, bw_all = [], []
+    for j in range(M):
+        u, n = kdehip.philox_streams(key, j, 1, 3 * D + N, N * D)
+        centres = (4.0 * u[: 3 * D] - 2.0).reshape(3, D)
+        comp = np.minimum((u[3 * D:] * 3.0).astype(np.int64), 2)
+        pts = centres[comp] + 0.5 * n.reshape(N, D)
+        pts = np.ascontiguousarray(pts.T)
+        bw = pts.std(axis=1, ddof=1) * (4.0 / ((D + 2.0) * N)) ** (1.0 / (D + 4.0))
+        pts_all.append(pts)
+        bw_all.append(bw)
+    return pts_all, bw_all
+
+
+def load_traffic(workload):
+    """HBM bytes per launch from the committed PMC profile (profiles/traffic_latest.json), or None."""
+    p = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    try:
+        with open(p) as f:
+            t = json.load(f)
+        if t.get("workload") == workload:
+            return t.get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        pass
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--variant", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import kdehip
+    from kdehip.sharded import ShardedProduct
+
+    D, M, N, Nout, Niter, prec, cid = CONFIGS[args.config]
+    workload = f"{args.config}: {D}-D, {M} densities x {N} pts, Nout={Nout}/GPU, Niter={Niter}, fp{prec}"
+    pts_all, bw_all = synth_inputs(kdehip, D, M, N, cid)
+    trees = [kdehip.kde(p, b) for p, b in zip(pts_all, bw_all)]
+    plan = kdehip.ProductPlan(trees, precision=prec, device=local_rank)
+    if args.variant:
+        plan.set_variant(args.variant)
+    sp = ShardedProduct(plan, dev)
+    seed = 20260101
+    Np_total = Nout * world
+
+    def step(i):
+        return sp.sample(Np_total, Niter=Niter, seed=seed, sample_base=i * Np_total)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+
+    # kernel-only duration: HIP events on the launch stream around the kernel of each timed step
+    stream = torch.cuda.current_stream(dev)
+    lo, hi = (Np_total * rank) // world, (Np_total * (rank + 1)) // world
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    bufs = sp._buffers(Np_total)
+
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        base = (args.warmup + i) * Np_total
+        ev[i][0].record(stream)
+        plan.sample_philox_device(hi - lo, Niter, seed, base + lo, True, bufs["pts"], bufs["ind"], None,
+                                  stream.cuda_stream)
+        ev[i][1].record(stream)
+        if world > 1:
+            dist.all_gather_into_tensor(bufs["all_pts"], bufs["pts"])
+            dist.all_gather_into_tensor(bufs["all_ind"], bufs["ind"])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    if world > 1:
+        t = torch.tensor([kern_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        kern_ms = float(t.item())
+
+    if rank == 0:
+        E = plan.evals_per_sample(Niter)
+        B = plan.bytes_per_eval
+        alg_bytes = float(Nout) * E * B
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        out = {
+            "metric": "gibbs_product_samples_per_sec",
+            "value": Np_total * args.steps / elapsed,
+            "unit": "samples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64" if prec == 64 else "f32",
+            "data": "synthetic",
+            "config": {"workload": workload, "ndims": D, "ndens": M, "npts": N, "nout_per_gpu": Nout,
+                       "nout_total": Np_total, "niter": Niter, "rng": "device philox4x32-10",
+                       "evals_per_sample": E, "bytes_per_eval": B,
+                       "parallelism": f"chains sharded over {world} GPU(s), 1 all-gather"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(args.config),
+                         "kernel": "gibbs_product_kernel", "kernel_ms": kern_ms,
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "note": "working set is cache-resident: normalised throughput vs HBM peak, not DRAM traffic"},
+            "kernel_samples_per_sec": Nout / (kern_ms * 1e-3),
+            "fast_math_path": plan.fast_math_path,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out.update(cpu_baseline_and_parity(kdehip, plan, pts_all, bw_all, D, M, N, Nout, Niter, seed, args.warmup))
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline_and_parity(kdehip, plan, pts_all, bw_all, D, M, N, Nout, Niter, seed, warmup):
+    """Times the CPU oracle (a faithful single-thread port of gibbs1; all host cores via OpenMP over
+    samples) on a bounded sample of the same workload and checks the GPU output against it."""
+    from oracle import oracle
+    otrees = [oracle.OracleDensity(p, b) for p, b in zip(pts_all, bw_all)]
+    K, R = plan.randu_per_sample(Niter), plan.randn_per_sample()
+    cores = os.cpu_count() or 1
+    # ~10-30 s of CPU work: config-3 costs ~6.5 ms per sample per core
+    per_sample_evals = plan.evals_per_sample(Niter)
+    n1 = max(16, min(Nout, int(4.0 * 13.0e6 / per_sample_evals)))          # ~4 s on one core
+    nall = max(cores * 8, min(Nout, int(8.0 * 13.0e6 * cores / per_sample_evals)))
+    randU, randN = kdehip.philox_streams(seed, 0, nall, K, R)
+    t = time.perf_counter()
+    oracle.gibbs1(otrees, n1, Niter, randU[: n1 * K], randN[: n1 * R])
+    t_one = time.perf_counter() - t
+    t = time.perf_counter()
+    o_pts, o_ind = oracle.gibbs1(otrees, nall, Niter, randU, randN, nthreads=cores)
+    t_all = time.perf_counter() - t
+    g_pts, g_ind = plan.sample(nall, Niter=Niter, seed=seed, sample_offset=0)
+    mism = int((g_pts.shape != o_pts.shape) or (g_ind != o_ind).sum())
+    return {
+        "cpu_baseline": {"value": nall / t_all, "unit": "samples/s", "cores": cores, "kind": "port",
+                         "sample": f"first {nall} samples of the same workload and Philox streams (oracle, OpenMP over samples)",
+                         "single_core_value": n1 / t_one, "single_core_sample": f"first {n1} samples"},
+        "parity": {"samples_checked": nall, "label_mismatches": mism,
+                   "max_abs_point_diff": float(np.abs(g_pts - o_pts).max()),
+                   "moment_mean_diff": float(np.abs(g_pts.mean(axis=1) - o_pts.mean(axis=1)).max()),
+                   "moment_var_diff": float(np.abs(g_pts.var(axis=1) - o_pts.var(axis=1)).max())},
+    }
+
+
+if __name__ == "__main__":
+    main()

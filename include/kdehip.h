@@ -1,0 +1,145 @@
+/*
+ * kdehip.h -- C ABI of libkdehip.so: the MI355X (gfx950) implementation of the multiscale-Gibbs
+ * KDE product hot path of JuliaRobotics/KernelDensityEstimate.jl.
+ *
+ * The reference is pure Julia and has no FFI layer; the seam this library replaces is the Julia
+ * method `gibbs1` (reference src/MSGibbs01.jl:527-629), called only from `prodAppxMSGibbsS`
+ * (src/MSGibbs01.jl:645-703).  A Julia caller binds these entry points with `ccall`
+ * (see INTEGRATION.md); the Python mirror in kerneldensityestimate.jl_amd/ binds them with ctypes.
+ *
+ * Conventions: plain pointers and sizes only.  All matrices are column-major as in Julia
+ * (points: ndims x Np, indices: Ndens x Np).  Node ids inside a density are the reference's
+ * 1-based ids with NO_CHILD = -1 (src/BallTree01.jl:5).  Every function returning `int` returns
+ * KDEHIP_OK (0) or a negative error code; kdehip_last_error() gives the message (thread-local).
+ * The library never keeps a caller's host pointer after a call returns.
+ * There is no CPU fallback: without a usable HIP device every compute entry point fails with
+ * KDEHIP_ERR_NO_DEVICE.
+ */
+#ifndef KDEHIP_H
+#define KDEHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KDEHIP_VERSION 100 /* 0.1.0 */
+
+enum {
+  KDEHIP_OK = 0,
+  KDEHIP_ERR_ARG = -1,         /* invalid argument (message says which)                            */
+  KDEHIP_ERR_DIM_MISMATCH = -2,/* "kdes must have same dimension"  (src/MSGibbs01.jl:720-722)     */
+  KDEHIP_ERR_RAND_SHORT = -3,  /* randU / randN shorter than the run consumes (Julia BoundsError) */
+  KDEHIP_ERR_NO_DEVICE = -4,   /* no HIP device / HIP runtime failure at init                      */
+  KDEHIP_ERR_HIP = -5,         /* a HIP call failed                                                */
+  KDEHIP_ERR_ALLOC = -6,
+  KDEHIP_ERR_UNSUPPORTED = -7  /* e.g. ndims or Ndens above the compiled limits                    */
+};
+
+#define KDEHIP_MAX_DIMS 8    /* kernels are instantiated for ndims = 1..8                          */
+#define KDEHIP_MAX_DENS 16   /* densities per product                                              */
+
+/* The six flat arrays of a BallTreeDensity that gibbs1 reads through its accessors
+ * (reference src/BallTreeDensity01.jl:11-24,86-93; src/BallTree01.jl:10-28,78-94).
+ * Lengths: means/bandwidth = ndim*2*npts (node i, dim k at (i-1)*ndim + k-1; bandwidth holds
+ * VARIANCES, src/KDE01.jl:45); the others = 2*npts. */
+typedef struct kdehip_density {
+  int64_t npts;               /* bt.num_points */
+  int64_t ndim;               /* bt.dims       */
+  const double *means;
+  const double *bandwidth;
+  const double *weights;      /* bt.weights      */
+  const int64_t *left_child;  /* bt.left_child   */
+  const int64_t *right_child; /* bt.right_child  */
+  const int64_t *permutation; /* bt.permutation  */
+} kdehip_density;
+
+/* ---- library ---------------------------------------------------------------------------------- */
+int kdehip_version(void);
+const char *kdehip_last_error(void);
+int kdehip_device_count(void); /* 0 when no device is usable */
+
+/* ---- (1) drop-in for gibbs1 (reference src/MSGibbs01.jl:527-537) ------------------------------
+ * Host buffers in, host buffers out, blocking.  Arguments in the reference's order:
+ *   Ndens, trees, Np, Niter, pts (out, ndims*Np), ind (out, Ndens*Np, = permutation+1, :615),
+ *   randU (nU values), randN (nN values), then the keywords addEntropy, ndims, partialDimMask
+ *   (Ndens*ndims bytes, density-major, 1 = active; NULL = all active).  `device` = HIP ordinal.
+ * RNG consumption is the reference's: 0-based sample s, select call c reads randU[s*K + c - 1],
+ * normal q*ndims+d of sample s is randN[s*R + q*ndims + d] (K, R from kdehip_product_info).
+ * Only the Euclidean manifold operators (the reference defaults addop=+, diffop=-, getEuclidMu,
+ * getEuclidLambda) exist behind this ABI. */
+int kdehip_gibbs1(int Ndens, const kdehip_density *trees, int64_t Np, int Niter, double *pts,
+                  int64_t *ind, const double *randU, int64_t nU, const double *randN, int64_t nN,
+                  int addEntropy, int ndims, const uint8_t *partialDimMask, int device);
+
+/* ---- (2) resident product plan ----------------------------------------------------------------
+ * The densities are re-laid-out once (per-level SoA, "pack_levels") and kept in HBM so repeated
+ * products -- and bench.py's timed region -- start with inputs resident on the device. */
+typedef struct kdehip_product kdehip_product;
+
+typedef struct kdehip_product_info_t {
+  int32_t ndens, ndims, nlevels;     /* nlevels = floor(log(max Npts)/log 2 + 1), :568            */
+  int32_t precision;                 /* 64 or 32                                                   */
+  int64_t nodes_per_sweep;           /* sum_j sum_{l=1..L} n_{j,l}: kernel evals of one sweep      */
+  int64_t bytes_per_eval;            /* (2*ndims+1)*sizeof(T)                           */
+  int64_t packed_bytes;              /* device bytes held by the plan                              */
+  int32_t fast_math_path;            /* 1: product/rsqrt evaluation; 0: per-dim divide+log (SAFE)  */
+  int32_t device;
+} kdehip_product_info_t;
+
+/* precision: 64 (reference arithmetic) or 32.  mask as in kdehip_gibbs1. */
+int kdehip_product_create(kdehip_product **out, int Ndens, const kdehip_density *trees, int ndims,
+                          const uint8_t *partialDimMask, int precision, int device);
+void kdehip_product_destroy(kdehip_product *plan);
+int kdehip_product_info(const kdehip_product *plan, kdehip_product_info_t *info);
+/* Per-sample RNG consumption for a given Niter: K uniforms (first M slots never read), R normals. */
+int64_t kdehip_product_randu_per_sample(const kdehip_product *plan, int Niter);
+int64_t kdehip_product_randn_per_sample(const kdehip_product *plan);
+
+/* Run Np chains.  All pointers are DEVICE pointers on the plan's device; `stream` is a hipStream_t
+ * (NULL = default stream); the call only enqueues work.  d_points: double[ndims*Np];
+ * d_indices: int64[Ndens*Np]; d_labels: optional int32[Np*Ndens*nlevels] (permutation of the label
+ * kept at the end of every level, the recordChoosen trace of src/MSGibbs01.jl:109-112) or NULL. */
+int kdehip_product_sample_streams(kdehip_product *plan, int64_t Np, int Niter,
+                                  const double *d_randU, int64_t nU, const double *d_randN,
+                                  int64_t nN, int addEntropy, double *d_points, int64_t *d_indices,
+                                  int32_t *d_labels, void *stream);
+/* Same, random numbers from the on-device Philox4x32-10 stream keyed by (seed, global sample
+ * index = sample_offset + s, draw index): results do not depend on how samples are split over
+ * calls or GPUs. */
+int kdehip_product_sample_philox(kdehip_product *plan, int64_t Np, int Niter, uint64_t seed,
+                                 int64_t sample_offset, int addEntropy, double *d_points,
+                                 int64_t *d_indices, int32_t *d_labels, void *stream);
+/* Host-buffer convenience wrapper around the Philox run (allocates, runs, copies back, blocking). */
+int kdehip_product_sample_philox_host(kdehip_product *plan, int64_t Np, int Niter, uint64_t seed,
+                                      int64_t sample_offset, int addEntropy, double *points,
+                                      int64_t *indices, int32_t *labels);
+/* Tuning knob for experiments/benchmarks: kernel variant (0 = library default). */
+int kdehip_product_set_variant(kdehip_product *plan, int variant);
+
+/* ---- (3) host twin of the device RNG ----------------------------------------------------------
+ * Fills the arrays a caller would pass as randU / randN so that a streams-run (or the Julia
+ * reference, via its randU=/randN= keywords, src/MSGibbs01.jl:661-662) consumes exactly the
+ * numbers the Philox run draws.  out_u has nsamples*K, out_n has nsamples*R entries. */
+void kdehip_philox_fill_uniform(uint64_t seed, int64_t sample_begin, int64_t nsamples, int64_t K,
+                                double *out_u);
+void kdehip_philox_fill_normal(uint64_t seed, int64_t sample_begin, int64_t nsamples, int64_t R,
+                               double *out_n);
+
+/* ---- (4) density construction (host; reference kde!(points, ks, weights), src/KDE01.jl:34-57 ->
+ * makeBallTreeDensity, src/BallTreeDensity01.jl:192-231 -> buildTree!, src/BallTree01.jl:415-434).
+ * A Julia caller keeps using its own kde!; this entry serves hosts without the reference.
+ * points: D x N column-major; ks: nks = 1 or D standard deviations (squared inside);
+ * weights_in: N or NULL (= ones).  Outputs are caller-allocated: centers, ranges, means,
+ * bandwidth: D*2N; weights and the five index arrays: 2N; bandwidthMin/Max: D*N. */
+int kdehip_make_density(int64_t D, int64_t N, const double *points, const double *ks, int64_t nks,
+                        const double *weights_in, double *centers, double *ranges, double *weights,
+                        int64_t *left_child, int64_t *right_child, int64_t *lowest_leaf,
+                        int64_t *highest_leaf, int64_t *permutation, double *means,
+                        double *bandwidth, double *bandwidthMin, double *bandwidthMax);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KDEHIP_H */

@@ -1,0 +1,143 @@
+"""Host-side mirror of the reference's density container and constructors.
+
+`BallTreeDensity` carries exactly the flat arrays of the reference struct (src/BallTreeDensity01.jl:11-24
+with the embedded BallTree, src/BallTree01.jl:10-28) under the same field names; `kde` mirrors
+`kde!(points, ks[, weights])` (src/KDE01.jl:34-84).  Construction runs in libkdehip.so
+(csrc/balltree.cpp) -- never in the CPU oracle.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _lib
+from ._lib import f64p, i64p, ptr
+
+
+class BallTree:
+    """Fields of the reference `BallTree` (1-based node ids, NO_CHILD = -1)."""
+    __slots__ = ("dims", "num_points", "centers", "ranges", "weights", "left_child", "right_child",
+                 "lowest_leaf", "highest_leaf", "permutation")
+
+
+class BallTreeDensity:
+    """Fields of the reference `BallTreeDensity`; `bandwidth` holds VARIANCES (src/KDE01.jl:45)."""
+    __slots__ = ("bt", "multibandwidth", "means", "bandwidth", "bandwidthMin", "bandwidthMax")
+
+    def __repr__(self):
+        return f"BallTreeDensity(dims={Ndim(self)}, Npts={Npts(self)}, bws={np.round(getBW(self)[:, 0], 6)})"
+
+    def _cstruct(self):
+        bt = self.bt
+        return _lib.CDensity(bt.num_points, bt.dims, ptr(self.means, f64p), ptr(self.bandwidth, f64p),
+                             ptr(bt.weights, f64p), ptr(bt.left_child, i64p), ptr(bt.right_child, i64p),
+                             ptr(bt.permutation, i64p))
+
+    # `p1 * p2` / `*([p1, p2, ...])`, reference src/MSGibbs01.jl:707-736
+    def __mul__(self, other):
+        from .product import mul
+        return mul([self, other])
+
+
+def kde(points, ks, weights=None) -> BallTreeDensity:
+    """`kde!(points, ks)` / `kde!(points, ks, weights)` (reference src/KDE01.jl:34-84).
+
+    points: (D, N) array, or a length-N vector for 1-D data (:78-84).  ks: bandwidth as STANDARD
+    DEVIATION, one entry (repeated over dimensions, :41-43) or D entries.  weights: N values,
+    normalised to sum 1 (:46); default ones (:67).
+    """
+    pts = np.asarray(points, dtype=np.float64)
+    if pts.ndim == 1:
+        pts = pts.reshape(1, -1)
+    if pts.ndim != 2:
+        raise ValueError("points must be a (D, N) matrix or a vector")
+    D, N = pts.shape
+    ks = np.ascontiguousarray(np.atleast_1d(np.asarray(ks, dtype=np.float64)).ravel())
+    if ks.size not in (1, D):
+        raise ValueError("ks must have 1 or D entries")
+    w = None
+    if weights is not None:
+        w = np.ascontiguousarray(np.asarray(weights, dtype=np.float64).ravel())
+        if w.size != N:
+            raise ValueError("weights must have one entry per point")
+    flat = np.ascontiguousarray(pts.T).ravel()  # column-major D x N
+
+    bt = BallTree()
+    bt.dims, bt.num_points = D, N
+    bt.centers = np.empty(2 * N * D)
+    bt.ranges = np.empty(2 * N * D)
+    bt.weights = np.empty(2 * N)
+    bt.left_child = np.empty(2 * N, dtype=np.int64)
+    bt.right_child = np.empty(2 * N, dtype=np.int64)
+    bt.lowest_leaf = np.empty(2 * N, dtype=np.int64)
+    bt.highest_leaf = np.empty(2 * N, dtype=np.int64)
+    bt.permutation = np.empty(2 * N, dtype=np.int64)
+    bd = BallTreeDensity()
+    bd.bt = bt
+    bd.multibandwidth = 0
+    bd.means = np.empty(2 * N * D)
+    bd.bandwidth = np.empty(2 * N * D)
+    bd.bandwidthMin = np.empty(N * D)
+    bd.bandwidthMax = np.empty(N * D)
+    _lib.check(_lib.lib.kdehip_make_density(
+        D, N, ptr(flat, f64p), ptr(ks, f64p), ks.size, None if w is None else ptr(w, f64p),
+        ptr(bt.centers, f64p), ptr(bt.ranges, f64p), ptr(bt.weights, f64p), ptr(bt.left_child, i64p),
+        ptr(bt.right_child, i64p), ptr(bt.lowest_leaf, i64p), ptr(bt.highest_leaf, i64p),
+        ptr(bt.permutation, i64p), ptr(bd.means, f64p), ptr(bd.bandwidth, f64p),
+        ptr(bd.bandwidthMin, f64p), ptr(bd.bandwidthMax, f64p)))
+    return bd
+
+
+kde_b = kde  # spelling of `kde!` for callers that want the bang visible
+
+
+def density_from_arrays(dims, num_points, means, bandwidth, weights, left_child, right_child,
+                        permutation) -> BallTreeDensity:
+    """Wrap flat arrays produced elsewhere (e.g. exported from a Julia BallTreeDensity)."""
+    bt = BallTree()
+    bt.dims, bt.num_points = int(dims), int(num_points)
+    bt.weights = np.ascontiguousarray(weights, dtype=np.float64)
+    bt.left_child = np.ascontiguousarray(left_child, dtype=np.int64)
+    bt.right_child = np.ascontiguousarray(right_child, dtype=np.int64)
+    bt.permutation = np.ascontiguousarray(permutation, dtype=np.int64)
+    bt.centers = bt.ranges = bt.lowest_leaf = bt.highest_leaf = None
+    bd = BallTreeDensity()
+    bd.bt = bt
+    bd.multibandwidth = 0
+    bd.means = np.ascontiguousarray(means, dtype=np.float64)
+    bd.bandwidth = np.ascontiguousarray(bandwidth, dtype=np.float64)
+    bd.bandwidthMin = bd.bandwidthMax = None
+    return bd
+
+
+def Ndim(bd: BallTreeDensity) -> int:
+    return bd.bt.dims
+
+
+def Npts(bd: BallTreeDensity) -> int:
+    return bd.bt.num_points
+
+
+def getPoints(bd: BallTreeDensity):
+    """Points in the caller's original order (reference src/KDE01.jl:91-101)."""
+    N, D = bd.bt.num_points, bd.bt.dims
+    perm = bd.bt.permutation[N:] - 1
+    out = np.zeros((D, N))
+    out[:, perm] = bd.bt.centers[N * D:].reshape(N, D).T
+    return out
+
+
+def getBW(bd: BallTreeDensity):
+    """Per-point bandwidth as standard deviation, (D, N) (reference src/KDE01.jl:109-120)."""
+    N, D = bd.bt.num_points, bd.bt.dims
+    perm = bd.bt.permutation[N:] - 1
+    out = np.zeros((D, N))
+    out[:, perm] = bd.bandwidth[N * D:].reshape(N, D).T
+    return np.sqrt(out)
+
+
+def getWeights(bd: BallTreeDensity):
+    """Normalised point weights in original order (reference src/KDE01.jl:127-136)."""
+    N = bd.bt.num_points
+    out = np.zeros(N)
+    out[bd.bt.permutation[N:] - 1] = bd.bt.weights[N:]
+    return out

@@ -52,3 +52,21 @@ def synth_mixture(rng, D, N, ncomp=3, spread=2.0, std=0.5):
 def silverman_bw(pts):
     D, N = pts.shape
     return pts.std(axis=1, ddof=1) * (4.0 / ((D + 2.0) * N)) ** (1.0 / (D + 4.0))
+
+
+# ---- closed-form streams of the committed Gibbs known-answer fixtures (tests/golden/gibbs_kat_*.npz)
+def weyl(n, alpha, offset=0.0):
+    i = np.arange(1, n + 1, dtype=np.float64)
+    return np.mod(offset + i * alpha, 1.0)
+
+
+def weyl_normal(n, a1, a2):
+    u1 = np.clip(weyl(n, a1, 0.11), 1e-12, 1.0)
+    u2 = weyl(n, a2, 0.37)
+    return np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)
+
+
+
+def kat_streams(nU, nN):
+    """randU / randN of the KAT fixtures (reference allocation sizes, src/MSGibbs01.jl:661-662)."""
+    return weyl(nU, (np.sqrt(5.0) - 1.0) / 2.0, 0.0123), weyl_normal(nN, np.sqrt(7.0) % 1.0, np.sqrt(11.0) % 1.0)
