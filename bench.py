@@ -193,11 +193,13 @@ def cpu_baseline_and_parity(kdehip, plan, pts_all, bw_all, D, M, N, Nout, Niter,
     from oracle import oracle
     otrees = [oracle.OracleDensity(p, b) for p, b in zip(pts_all, bw_all)]
     K, R = plan.randu_per_sample(Niter), plan.randn_per_sample()
-    cores = os.cpu_count() or 1
-    # ~10-30 s of CPU work: config-3 costs ~6.5 ms per sample per core
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    # bounded sample, ~50 core-seconds in total (config 3 costs ~3-6 ms per sample per core): the
+    # all-cores run takes the first `nall` chains of the workload's Philox stream (more than one
+    # GPU batch when the host has many cores), the single-core run the first `n1`.
     per_sample_evals = plan.evals_per_sample(Niter)
-    n1 = max(16, min(Nout, int(4.0 * 13.0e6 / per_sample_evals)))          # ~4 s on one core
-    nall = max(cores * 8, min(Nout, int(8.0 * 13.0e6 * cores / per_sample_evals)))
+    nall = int(max(cores * 8, min(16384, 1.5e9 / per_sample_evals)))
+    n1 = int(max(16, min(1024, 1.0e8 / per_sample_evals)))
     randU, randN = kdehip.philox_streams(seed, 0, nall, K, R)
     t = time.perf_counter()
     oracle.gibbs1(otrees, n1, Niter, randU[: n1 * K], randN[: n1 * R])
@@ -209,7 +211,7 @@ def cpu_baseline_and_parity(kdehip, plan, pts_all, bw_all, D, M, N, Nout, Niter,
     mism = int((g_pts.shape != o_pts.shape) or (g_ind != o_ind).sum())
     return {
         "cpu_baseline": {"value": nall / t_all, "unit": "samples/s", "cores": cores, "kind": "port",
-                         "sample": f"first {nall} samples of the same workload and Philox streams (oracle, OpenMP over samples)",
+                         "sample": f"first {nall} chains of the same workload and Philox stream (C oracle, OpenMP over samples, {cores} threads)",
                          "single_core_value": n1 / t_one, "single_core_sample": f"first {n1} samples"},
         "parity": {"samples_checked": nall, "label_mismatches": mism,
                    "max_abs_point_diff": float(np.abs(g_pts - o_pts).max()),

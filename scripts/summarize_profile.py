@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""Condenses a gpurun_out/prof_<tag>/ directory (written by scripts/profile_gpu.sh) into the tracked
+files profiles/<tag>_rocprof_summary.md / .json and profiles/traffic_latest.json.
+
+Units (MI355X_MICROARCH.md, HBM section): FETCH_SIZE / WRITE_SIZE are KiB of memory-side L2 traffic;
+on gfx950 FETCH_SIZE under-reports wide (16 B/lane) coalesced reads by exactly 2x; other widths are
+uncalibrated, so `fetch_calibration` (measured for this kernel's 8 B/lane loads by
+scripts/calibrate_fetch.hip when available, else 2.0 as the conservative upper bound) multiplies it.
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def counters(d, sub, match):
+    acc = defaultdict(list)
+    for f in glob.glob(os.path.join(d, sub, "*", "*_counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            if match in r["Kernel_Name"]:
+                acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+                acc["_vgpr"].append(float(r["VGPR_Count"]))
+                acc["_sgpr"].append(float(r["SGPR_Count"]))
+                acc["_lds"].append(float(r["LDS_Block_Size"]))
+                acc["_grid"].append(float(r["Grid_Size"]))
+                acc["_wg"].append(float(r["Workgroup_Size"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
+
+
+def main():
+    tag = sys.argv[1]
+    match = sys.argv[2] if len(sys.argv) > 2 else "gibbs_product_kernel"
+    workload = sys.argv[3] if len(sys.argv) > 3 else "c3"
+    calib = float(sys.argv[4]) if len(sys.argv) > 4 else 2.0
+    d = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+    stats = []
+    for f in glob.glob(os.path.join(d, "stats", "*", "*_kernel_stats.csv")):
+        stats += list(csv.DictReader(open(f)))
+    krow = next(r for r in stats if match in r["Name"])
+    out = {"tag": tag, "workload": workload, "kernel": krow["Name"], "calls": int(krow["Calls"]),
+           "avg_ns": float(krow["AverageNs"]), "min_ns": float(krow["MinNs"]), "max_ns": float(krow["MaxNs"]),
+           "pct_of_gpu_time": float(krow["Percentage"])}
+    pmc = {}
+    for sub in ("fetch", "write", "sq", "sq2", "sq3"):
+        if os.path.isdir(os.path.join(d, sub)):
+            m, _ = counters(d, sub, match)
+            pmc.update(m)
+    out["pmc_avg_per_launch"] = {k: v for k, v in pmc.items() if not k.startswith("_")}
+    out["launch"] = {"vgpr": pmc.get("_vgpr"), "sgpr": pmc.get("_sgpr"), "lds_bytes": pmc.get("_lds"),
+                     "grid_threads": pmc.get("_grid"), "workgroup": pmc.get("_wg")}
+    fetch_kib, write_kib = pmc.get("FETCH_SIZE"), pmc.get("WRITE_SIZE")
+    if fetch_kib is not None and write_kib is not None:
+        out["hbm_bytes_per_launch_raw"] = (fetch_kib + write_kib) * 1024.0
+        out["fetch_calibration"] = calib
+        out["hbm_bytes_per_launch"] = (fetch_kib * calib + write_kib) * 1024.0
+    bench = {}
+    try:
+        bench = json.loads(open(os.path.join(d, "bench_stats.json")).read().strip().splitlines()[-1])
+        out["bench_line_under_profiler"] = {"kernel_ms": bench["roofline"]["kernel_ms"], "value": bench["value"],
+                                            "roofline_frac": bench["roofline"]["frac"]}
+    except Exception as e:  # noqa: BLE001
+        out["bench_line_under_profiler"] = f"unavailable: {e}"
+    os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+    with open(os.path.join(ROOT, "profiles", f"{tag}_rocprof_summary.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    if "hbm_bytes_per_launch" in out:
+        with open(os.path.join(ROOT, "profiles", "traffic_latest.json"), "w") as f:
+            json.dump({"workload": workload, "tag": tag, "hbm_bytes_per_launch": out["hbm_bytes_per_launch"],
+                       "raw_bytes": out["hbm_bytes_per_launch_raw"], "fetch_calibration": calib}, f, indent=1)
+    lines = [f"# rocprofv3 summary `{tag}` ({workload})", "",
+             "Command (on the MI355X box): `scripts/profile_gpu.sh " + tag + "` = `rocprofv3 --kernel-trace --stats -- python3 bench.py "
+             "--steps 20 --warmup 3 --no-cpu-baseline` plus separate `--pmc` passes.", "",
+             "## kernel stats (`--kernel-trace --stats`)", "", "| kernel | calls | avg ns | min ns | max ns | % |", "|---|---|---|---|---|---|"]
+    for r in stats[:6]:
+        lines.append(f"| `{r['Name'][:90]}` | {r['Calls']} | {float(r['AverageNs']):.0f} | {r['MinNs']} | {r['MaxNs']} | {r['Percentage']} |")
+    lines += ["", "## PMC counters, average per launch of the product kernel", "", "| counter | value |", "|---|---|"]
+    for k, v in sorted(out["pmc_avg_per_launch"].items()):
+        lines.append(f"| {k} | {v:.6g} |")
+    lines += ["", f"launch: {out['launch']}", ""]
+    if "hbm_bytes_per_launch" in out:
+        lines += [f"HBM bytes per launch: raw (FETCH_SIZE+WRITE_SIZE)*1024 = {out['hbm_bytes_per_launch_raw']:.4g}; "
+                  f"with FETCH_SIZE x {calib} = {out['hbm_bytes_per_launch']:.4g}", ""]
+    lines += [f"bench line under the profiler: {out['bench_line_under_profiler']}", ""]
+    with open(os.path.join(ROOT, "profiles", f"{tag}_rocprof_summary.md"), "w") as f:
+        f.write("\n".join(lines))
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main()
