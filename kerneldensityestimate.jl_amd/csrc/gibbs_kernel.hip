@@ -7,25 +7,39 @@
 // pack_levels.cpp).
 //
 // Mapping (MI355X-first, not a translation of the Julia loop nest):
-//   * one 64-lane wavefront owns one output sample (one Gibbs chain); chains never communicate;
+//   * one 64-lane wavefront owns one output sample (one Gibbs chain); chains never communicate.
+//     Eight chains share a workgroup (one per CU at the headline size) and walk the data-independent
+//     (level, pass, density) schedule in lock step so that the tile every wavefront is about to read
+//     is staged ONCE per workgroup into LDS with direct-to-LDS loads (global_load_lds_dwordx4):
+//     levels whose tiles all fit stay resident for the whole level, larger ones are streamed one
+//     tile per step through a double buffer (the copy of step t+1 overlaps the evaluation of step
+//     t, one barrier per step), and only tiles beyond half the pool are read from L2 directly;
 //   * inside a (level, density) step the lanes are the frontier nodes: lane `ln` owns the
-//     contiguous entries ln*B .. ln*B+B-1 (B = ceil(n/64)), reads them with coalesced loads from the
-//     lane-blocked tile, keeps a private running sum, and ONE DPP wavefront prefix scan turns the
-//     64 lane sums into the cumulative weights the categorical draw needs; the winning lane's
-//     block is then re-evaluated by the whole wavefront (one more pass over <= 64 nodes) and
-//     scanned again to find the node.  No p[] array is ever materialised;
+//     contiguous entries ln*B .. ln*B+B-1 (B = ceil(n/64)), reads them row by row with coalesced
+//     loads (one address per row, fields at constant offsets), keeps a private running sum, and
+//     ONE DPP wavefront prefix scan turns the 64 lane sums into the cumulative weights the
+//     categorical draw needs; the winning lane's block is then re-evaluated by the whole wavefront
+//     (one more pass over <= 64 nodes) and scanned again to find the node.  No p[] array is ever
+//     materialised;
 //   * between steps the lanes are the DIMENSIONS: lane d keeps 1/variance and mean/variance of the
 //     currently selected kernel of every density for dimension d (LDS, per wavefront), forms the
 //     leave-one-out Gaussian product for its dimension, and the D results are broadcast to scalar
 //     registers with v_readlane;
 //   * random numbers come from the caller's streams (bit-for-bit the reference's consumption
-//     order) or from an on-device Philox4x32-10 keyed by (seed, global sample, draw).
+//     order) or from an on-device Philox4x32-10 keyed by (seed, global sample, draw), which the
+//     compiler runs on the scalar unit because every input is wave-uniform.
 //
-// Two arithmetic forms of the kernel evaluation:
-//   FAST    p = w * rsqrt(prod_d c_d) * exp(-1/2 * sum_d delta_d^2 / c_d), with the D reciprocals
-//           obtained from ONE rsqrt via prefix/suffix products -- no divide, no log;
-//   GENERIC the reference's own per-dimension divide + log with its NaN rules (:287-303), used for
-//           partialDimMask products and for inputs whose variance products could leave the range of T.
+// Three arithmetic forms of the kernel evaluation p_z = w_z * N(center; mean_z, bw_z + cov):
+//   UNIFORM  levels whose nodes share one bandwidth vector (every leaf level): the D reciprocals and
+//            the normalisation are wave-uniform and hoisted; per node D subtracts, D multiplies,
+//            D fused multiply-adds and one exp;
+//   FAST     p = w * rsqrt(prod_d c_d) * exp(-1/2 * sum_d delta_d^2 / c_d), the D reciprocals
+//            obtained from ONE rsqrt via prefix/suffix products -- no divide, no log;
+//   GENERIC  the reference's own per-dimension divide + log with its NaN rules (:287-303), used for
+//            partialDimMask products and for inputs whose variance products could leave the range
+//            of T.
+// fp64 exp on the fast forms is a 32-entry-table (LDS, one bank row, conflict free) + degree-6
+// polynomial, ~1 ulp; the GENERIC form calls the library exp/log.
 //
 // Compiled with -ffp-contract=off; fused multiply-adds are written explicitly where wanted.
 #include <hip/hip_runtime.h>
@@ -37,13 +51,42 @@
 
 namespace kdehip {
 
-constexpr int kWavesPerBlock = 4;
 
 // ---- small device helpers ------------------------------------------------------------------------
+
+// 2^(j/32), j = 0..31, correctly rounded
+__constant__ double kExp2Tab[32] = {
+    0x1.0000000000000p+0, 0x1.059b0d3158574p+0, 0x1.0b5586cf9890fp+0, 0x1.11301d0125b51p+0,
+    0x1.172b83c7d517bp+0, 0x1.1d4873168b9aap+0, 0x1.2387a6e756238p+0, 0x1.29e9df51fdee1p+0,
+    0x1.306fe0a31b715p+0, 0x1.371a7373aa9cbp+0, 0x1.3dea64c123422p+0, 0x1.44e086061892dp+0,
+    0x1.4bfdad5362a27p+0, 0x1.5342b569d4f82p+0, 0x1.5ab07dd485429p+0, 0x1.6247eb03a5585p+0,
+    0x1.6a09e667f3bcdp+0, 0x1.71f75e8ec5f74p+0, 0x1.7a11473eb0187p+0, 0x1.82589994cce13p+0,
+    0x1.8ace5422aa0dbp+0, 0x1.93737b0cdc5e5p+0, 0x1.9c49182a3f090p+0, 0x1.a5503b23e255dp+0,
+    0x1.ae89f995ad3adp+0, 0x1.b7f76f2fb5e47p+0, 0x1.c199bdd85529cp+0, 0x1.cb720dcef9069p+0,
+    0x1.d5818dcfba487p+0, 0x1.dfc97337b9b5fp+0, 0x1.ea4afa2a490dap+0, 0x1.f50765b6e4540p+0};
+
+// exp(x) for x <= 0 (NaN in -> NaN out).  x = (32k + j) * ln2/32 + r, |r| <= ln2/64:
+// exp(x) = 2^k * 2^(j/32) * (1 + r + r^2/2 + ... + r^6/720); the truncation error is < 4e-18.
+__device__ __forceinline__ double exp_nonpos(double x, const double *__restrict__ tab /* LDS */) {
+  x = fmax(x, -800.0);  // exp(-800) already underflows to 0; keeps the reduction finite
+  const double kf = rint(x * 0x1.71547652b82fep+5);            // 32/ln2
+  double r = fma(kf, -0x1.62e42fee00000p-6, x);                // ln2/32, high part (32 bits)
+  r = fma(kf, -0x1.a39ef35793c76p-38, r);                      // low part
+  const int ki = static_cast<int>(kf);
+  const double t = tab[ki & 31];
+  double p = fma(r, 0x1.6c16c16c16c17p-10, 0x1.1111111111111p-7);  // 1/720, 1/120
+  p = fma(p, r, 0x1.5555555555555p-5);                              // 1/24
+  p = fma(p, r, 0x1.5555555555555p-3);                              // 1/6
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = p * r;                                                        // exp(r) - 1
+  return ldexp(fma(t, p, t), ki >> 5);
+}
 
 template <typename T> struct Num;
 template <> struct Num<double> {
   static __device__ __forceinline__ double exp(double x) { return ::exp(x); }
+  static __device__ __forceinline__ double exp_fast(double x, const double *tab) { return exp_nonpos(x, tab); }
   static __device__ __forceinline__ double log(double x) { return ::log(x); }
   static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
   static __device__ __forceinline__ double rsqrt(double x) { return ::rsqrt(x); }
@@ -52,6 +95,7 @@ template <> struct Num<double> {
 };
 template <> struct Num<float> {
   static __device__ __forceinline__ float exp(float x) { return __expf(x); }
+  static __device__ __forceinline__ float exp_fast(float x, const double *) { return __expf(x); }
   static __device__ __forceinline__ float log(float x) { return __logf(x); }
   static __device__ __forceinline__ float sqrt(float x) { return ::sqrtf(x); }
   static __device__ __forceinline__ float rsqrt(float x) { return ::rsqrtf(x); }
@@ -100,80 +144,100 @@ __device__ __forceinline__ float lane_read(float v, int src) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
 }
 
-// ---- kernel evaluation at one frontier position ------------------------------------------------
+// ---- kernel evaluation of one frontier entry -----------------------------------------------------
+// `e` points at (row, field 0, lane) of the entry (LDS or global pointer); field f is at e[f*64].
 
-// FAST form.  center[d] / cov[d] are wave-uniform.  Returns w * N(center; mean, bw + cov).
+// UNIFORM: the level has one bandwidth vector; ninv[d] = -1/(2 c_d), scale = rsqrt(prod_d c_d).
 template <typename T, int D>
-__device__ __forceinline__ T eval_fast(const T *__restrict__ tile, int ld, int pos,
-                                       const T (&center)[D], const T (&cov)[D]) {
-  T c[D], d2[D];
+struct EvalUniform {
+  T center[D], ninv[D], scale;
+  const double *tab;
+  template <typename P>
+  __device__ __forceinline__ T operator()(P e) const {
+    T acc = T(0);
 #pragma unroll
-  for (int d = 0; d < D; ++d) {
-    const T mu = tile[d * ld + pos];
-    const T bw = tile[(D + d) * ld + pos];
-    c[d] = bw + cov[d];
-    const T dl = mu - center[d];
-    d2[d] = dl * dl;
+    for (int d = 0; d < D; ++d) {
+      const T dl = e[d * 64] - center[d];
+      acc = Num<T>::fma(dl * dl, ninv[d], acc);
+    }
+    const T p = (e[D * 64] * scale) * Num<T>::exp_fast(acc, tab);
+    return (p != p) ? T(0) : p;  // suppress NaNs, :302
   }
-  const T w = tile[2 * D * ld + pos];
-  // others[d] = prod_{k != d} c[k] from prefix and suffix products; P = prod_k c[k]
-  T pre[D], suf[D];
-  pre[0] = T(1);
-#pragma unroll
-  for (int d = 1; d < D; ++d) pre[d] = pre[d - 1] * c[d - 1];
-  suf[D - 1] = T(1);
-#pragma unroll
-  for (int d = D - 2; d >= 0; --d) suf[d] = suf[d + 1] * c[d + 1];
-  const T P = pre[D - 1] * c[D - 1];
-  T num = T(0);
-#pragma unroll
-  for (int d = 0; d < D; ++d) num = Num<T>::fma(d2[d], pre[d] * suf[d], num);
-  const T r = Num<T>::rsqrt(P);
-  const T q = num * r * r;  // = sum_d delta_d^2 / c_d
-  const T p = w * r * Num<T>::exp(T(-0.5) * q);
-  return (p != p) ? T(0) : p;  // suppress NaNs, :302
-}
+};
 
-// GENERIC form: literally the reference's accumulation (:280-303) incl. inactive dimensions.
+// FAST: per-node bandwidths; one rsqrt instead of D divides and D logs.
 template <typename T, int D>
-__device__ __forceinline__ T eval_generic(const T *__restrict__ tile, int ld, int pos,
-                                          const T (&center)[D], const T (&cov)[D], uint32_t act) {
-  T acc = T(0);
+struct EvalFast {
+  T center[D], cov[D];
+  const double *tab;
+  template <typename P>
+  __device__ __forceinline__ T operator()(P e) const {
+    T c[D], d2[D];
 #pragma unroll
-  for (int d = 0; d < D; ++d) {
-    if ((act >> d) & 1u) {
-      const T c = tile[(D + d) * ld + pos] + cov[d];
-      const T dl = tile[d * ld + pos] - center[d];
-      const T distr = (dl * dl) / c;
-      if (distr == distr) {
-        acc += distr;
-        acc += Num<T>::log(c);
+    for (int d = 0; d < D; ++d) {
+      c[d] = e[(D + d) * 64] + cov[d];
+      const T dl = e[d * 64] - center[d];
+      d2[d] = dl * dl;
+    }
+    const T w = e[2 * D * 64];
+    // pre[d]*suf[d] = prod_{k != d} c[k]; P = prod_k c[k]
+    T pre[D], suf[D];
+    pre[0] = T(1);
+#pragma unroll
+    for (int d = 1; d < D; ++d) pre[d] = pre[d - 1] * c[d - 1];
+    suf[D - 1] = T(1);
+#pragma unroll
+    for (int d = D - 2; d >= 0; --d) suf[d] = suf[d + 1] * c[d + 1];
+    const T prod = pre[D - 1] * c[D - 1];
+    T num = T(0);
+#pragma unroll
+    for (int d = 0; d < D; ++d) num = Num<T>::fma(d2[d], pre[d] * suf[d], num);
+    const T r = Num<T>::rsqrt(prod);
+    const T q = num * r * r;  // = sum_d delta_d^2 / c_d
+    const T p = (w * r) * Num<T>::exp_fast(T(-0.5) * q, tab);
+    return (p != p) ? T(0) : p;
+  }
+};
+
+// GENERIC: literally the reference's accumulation (:280-303) incl. inactive dimensions.
+template <typename T, int D>
+struct EvalGeneric {
+  T center[D], cov[D];
+  uint32_t act;
+  template <typename P>
+  __device__ __forceinline__ T operator()(P e) const {
+    T acc = T(0);
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      if ((act >> d) & 1u) {
+        const T c = e[(D + d) * 64] + cov[d];
+        const T dl = e[d * 64] - center[d];
+        const T distr = (dl * dl) / c;
+        if (distr == distr) {
+          acc += distr;
+          acc += Num<T>::log(c);
+        }
       }
     }
+    const T p = Num<T>::exp(T(-0.5) * acc) * e[2 * D * 64];
+    return (p != p) ? T(0) : p;
   }
-  const T p = Num<T>::exp(T(-0.5) * acc) * tile[2 * D * ld + pos];
-  return (p != p) ? T(0) : p;
-}
-
-template <typename T, int D, bool FAST>
-__device__ __forceinline__ T eval_node(const T *__restrict__ tile, int ld, int pos,
-                                       const T (&center)[D], const T (&cov)[D], uint32_t act) {
-  if constexpr (FAST) return eval_fast<T, D>(tile, ld, pos, center, cov);
-  else return eval_generic<T, D>(tile, ld, pos, center, cov, act);
-}
+};
 
 // ---- one categorical label draw over a frontier -------------------------------------------------
-// Evaluates every node of the frontier against (center, cov), and returns the 0-based frontier
-// entry selected by the uniform draw `u`: the first z with u <= cdf[z], else the last
+// Evaluates every node of the frontier with `ev`, and returns the tile position (row*64 + lane) of
+// the entry selected by the uniform draw `u`: the first z with u <= cdf[z], else the last
 // (selectLabelOnLevel :330-351 applied to the CDF of makeFasterSampleIndex! :318-325).
-template <typename T, int D, bool FAST>
-__device__ __forceinline__ int draw_label(const T *__restrict__ tile, const LevelDesc &ds, int lane,
-                                          const T (&center)[D], const T (&cov)[D], uint32_t act,
-                                          double u) {
-  const int n = ds.n, B = ds.B, ld = B * 64;
-  // pass 1: private sum over the lane's contiguous entries (rows of the tile are coalesced)
+// `rows` points at row 0, field 0, lane 0 of the tile (LDS or global pointer type P).
+template <typename T, typename P, typename Eval>
+__device__ __forceinline__ int draw_label(P rows, const LevelDesc &ds, int lane, const Eval &ev, double u) {
+  const int n = ds.n, B = ds.B, F = ds.F;
+  const int RS = F * 64 + 1;
+  // pass 1: private sum over the lane's contiguous entries (every field row is one coalesced read)
   T S = T(0);
-  for (int i = 0; i < B; ++i) S += eval_node<T, D, FAST>(tile, ld, i * 64 + lane, center, cov, act);
+  P e = rows + lane;
+#pragma unroll 2
+  for (int i = 0; i < B; ++i, e += RS) S += ev(e);
   const T incl = wave_inclusive_scan(S);
   const T total = lane_read(incl, 63);
 
@@ -181,10 +245,13 @@ __device__ __forceinline__ int draw_label(const T *__restrict__ tile, const Leve
     // "stick with selection of others": uniform over the frontier (:311-315); with a zero/NaN
     // last weight the reference's CDF is all-NaN and the last entry is taken.
     const int zl = n - 1;
-    const T wl = tile[2 * D * ld + (zl % B) * 64 + zl / B];
-    if (!(wl > T(0))) return n - 1;
-    int z = static_cast<int>(ceil(u * static_cast<double>(n))) - 1;
-    return z < 0 ? 0 : (z > n - 1 ? n - 1 : z);
+    const T wl = rows[(zl % B) * RS + (F - 1) * 64 + zl / B];
+    int z = n - 1;
+    if (wl > T(0)) {
+      z = static_cast<int>(ceil(u * static_cast<double>(n))) - 1;
+      z = z < 0 ? 0 : (z > n - 1 ? n - 1 : z);
+    }
+    return (z % B) * 64 + z / B;
   }
 
   const T target = static_cast<T>(u) * total;
@@ -199,12 +266,13 @@ __device__ __forceinline__ int draw_label(const T *__restrict__ tile, const Leve
   int r0 = 0;
   int len = n - lstar * B;
   if (len > B) len = B;
+  P col = rows + lstar;
   while (len > 64) {  // only for frontiers beyond 4096 nodes
     const int b2 = (len + 63) / 64;
     T S2 = T(0);
     for (int i = 0; i < b2; ++i) {
       const int r = lane * b2 + i;
-      if (r < len) S2 += eval_node<T, D, FAST>(tile, ld, (r0 + r) * 64 + lstar, center, cov, act);
+      if (r < len) S2 += ev(col + (r0 + r) * RS);
     }
     const T inc2 = wave_inclusive_scan(S2);
     const unsigned long long h2 = __ballot(target <= base + inc2);
@@ -216,54 +284,86 @@ __device__ __forceinline__ int draw_label(const T *__restrict__ tile, const Leve
     len = (len - l2 * b2 < b2) ? (len - l2 * b2) : b2;
   }
   T p2 = T(0);
-  if (lane < len) p2 = eval_node<T, D, FAST>(tile, ld, (r0 + lane) * 64 + lstar, center, cov, act);
+  if (lane < len) p2 = ev(col + (r0 + lane) * RS);
   const T inc3 = wave_inclusive_scan(p2);
   const unsigned long long h3 = __ballot((target <= base + inc3) && (lane < len));
   const int istar = h3 ? (__ffsll(h3) - 1) : (len - 1);
-  return lstar * B + r0 + istar;
+  return (r0 + istar) * 64 + lstar;
 }
 
 // ---- the sampler ----------------------------------------------------------------------------------
 
+// LDS of one workgroup (ONE object, so the compiler keeps direct-to-LDS loads asynchronous):
+//   [exp table 256 B][per-wave chain state][tile pool kLdsPoolBytes]
+template <typename T, int D>
+struct LdsLayout {
+  static constexpr int kStatePerWave = (2 * KDEHIP_MAX_DENS * D) * int(sizeof(T)) + KDEHIP_MAX_DENS * int(sizeof(int));
+  static constexpr int kStateOff = 256;
+  static constexpr int kPoolOff = (kStateOff + kWgWaves * kStatePerWave + 1023) / 1024 * 1024;
+  static constexpr int kBytes = kPoolOff + kLdsPoolBytes;
+  static_assert(kBytes <= 160 * 1024, "LDS budget of one CU exceeded");
+};
+
+template <typename T> using LdsPtr = const __attribute__((address_space(3))) T *;
+using LdsVoidPtr = __attribute__((address_space(3))) void *;
+using GlobalVoidPtr = const __attribute__((address_space(1))) void *;
+
+// Cooperative, asynchronous copy of one tile image (bytes is a multiple of 1 KiB) into the pool:
+// every wavefront issues global_load_lds_dwordx4 for its share of 1-KiB pieces.
+__device__ __forceinline__ void stage_tile(const unsigned char *__restrict__ src, unsigned char *dst,
+                                           int bytes, int wave, int lane) {
+  const int pieces = bytes >> 10;
+  for (int c = wave; c < pieces; c += kWgWaves)
+    __builtin_amdgcn_global_load_lds((GlobalVoidPtr)(src + (c << 10) + (lane << 4)),
+                                     (LdsVoidPtr)(dst + (c << 10)), 16, 0, 0);
+}
+
 template <typename T, int D, bool FAST>
-__global__ __launch_bounds__(kWavesPerBlock * 64) void gibbs_product_kernel(PlanDev plan, RunArgs a) {
-  __shared__ T sLam[kWavesPerBlock][KDEHIP_MAX_DENS * D];  // 1/variance of the selected kernels
-  __shared__ T sLmu[kWavesPerBlock][KDEHIP_MAX_DENS * D];  // mean/variance
-  __shared__ int sZ[kWavesPerBlock][KDEHIP_MAX_DENS];      // selected frontier entry per density
+__global__ __launch_bounds__(kWgWaves * 64) void gibbs_product_kernel(PlanDev plan, RunArgs a) {
+  using Lay = LdsLayout<T, D>;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[Lay::kBytes];
+
+  double *sExpTab = reinterpret_cast<double *>(smem);
+  if (threadIdx.x < 32) sExpTab[threadIdx.x] = kExp2Tab[threadIdx.x];
+  __syncthreads();
 
   const int lane = threadIdx.x & 63;
   // readfirstlane makes the wave id (and everything derived from it: sample index, RNG counters,
   // descriptor addresses) provably wave-uniform, so it lives in SGPRs / runs on the scalar unit
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
-  const int64_t s = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave;
-  if (s >= a.Np) return;  // wave-uniform; no block-wide barriers are used below
+  int64_t s = static_cast<int64_t>(blockIdx.x) * kWgWaves + wave;
+  // surplus wavefronts of the last workgroup keep taking part in staging and barriers: they replay
+  // the last chain and store nothing
+  const bool live = s < a.Np;
+  if (!live) s = a.Np - 1;
   const uint64_t gs = static_cast<uint64_t>(a.sample_offset + s);
 
   const int M = plan.M, L = plan.L;
   const T *__restrict__ data = static_cast<const T *>(plan.data);
-  T *lam = sLam[wave];
-  T *lmu = sLmu[wave];
-  int *zsel = sZ[wave];
+  const LevelDesc *__restrict__ levels = plan.levels;
+  unsigned char *state = smem + Lay::kStateOff + wave * Lay::kStatePerWave;
+  T *lam = reinterpret_cast<T *>(state);                 // 1/variance of the selected kernels
+  T *lmu = lam + KDEHIP_MAX_DENS * D;                    // mean/variance
+  int *psel = reinterpret_cast<int *>(lmu + KDEHIP_MAX_DENS * D);  // selected tile position per density
+  unsigned char *pool = smem + Lay::kPoolOff;
   const int dl = lane < D ? lane : D - 1;  // this lane's dimension in the "lanes = dimensions" phases
 
   uint32_t any_bits = 0;  // dimensions informed by at least one density
-  for (int j = 0; j < M; ++j) any_bits |= plan.mask_bits[j];
+  for (int j = 0; j < M; ++j) any_bits |= levels[j * (L + 1)].mask_bits;
 
-  // selected kernel of density j <- frontier entry z of level descriptor ds
+  // selected kernel of density j <- entry `pos` of the tile whose header is at `hdr` (LDS or global)
   // (updateGlbParticlesVariance!, :89-115; masked dimensions carry no information)
-  auto set_particle = [&](int j, const LevelDesc &ds, int z) {
-    const int B = ds.B, ld = B * 64;
-    const int pos = (z % B) * 64 + z / B;
-    const T *tile = data + ds.data_off;
-    const T mu = tile[dl * ld + pos];
-    const T var = tile[(D + dl) * ld + pos];
-    const bool on = (plan.mask_bits[j] >> dl) & 1u;
+  auto set_particle = [&](int j, const LevelDesc &ds, auto hdr, int pos) {
+    auto e = hdr + kTileHeader + (pos >> 6) * (ds.F * 64 + 1) + (pos & 63);
+    const T mu = e[dl * 64];
+    const T var = ds.uniform_bw ? hdr[dl] : e[(D + dl) * 64];
+    const bool on = (ds.mask_bits >> dl) & 1u;
     const T l = on ? T(1) / var : T(0);
     if (lane < D) {
       lam[j * D + dl] = l;
       lmu[j * D + dl] = on ? mu * l : T(0);
     }
-    if (lane == 0) zsel[j] = z;
+    if (lane == 0) psel[j] = pos;
   };
 
   // Gaussian product of the selected kernels without density `skip` for this lane's dimension
@@ -281,8 +381,62 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gibbs_product_kernel(Plan
     mean = on ? cov * ms : T(0);
   };
 
+  // one label draw of density j on level descriptor ds against the per-dimension (mean, cov)
+  // held by the dimension lanes; `hdr` = tile header (LDS or global pointer)
+  auto draw = [&](const LevelDesc &ds, auto hdr, T mean, T cov, double u) -> int {
+    auto rows = hdr + kTileHeader;
+    using P = decltype(rows);
+    if constexpr (FAST) {
+      if (ds.uniform_bw) {
+        EvalUniform<T, D> ev;
+        ev.tab = sExpTab;
+        const T c = hdr[dl] + cov;
+        const T ni = T(-0.5) / c;
+        T Pr = T(1);
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+          ev.center[d] = lane_read(mean, d);
+          ev.ninv[d] = lane_read(ni, d);
+          Pr *= lane_read(c, d);
+        }
+        ev.scale = Num<T>::rsqrt(Pr);
+        return draw_label<T, P>(rows, ds, lane, ev, u);
+      }
+      EvalFast<T, D> ev;
+      ev.tab = sExpTab;
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        ev.center[d] = lane_read(mean, d);
+        ev.cov[d] = lane_read(cov, d);
+      }
+      return draw_label<T, P>(rows, ds, lane, ev, u);
+    } else {
+      EvalGeneric<T, D> ev;
+      ev.act = ds.mask_bits & ds.others_bits;
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        ev.center[d] = lane_read(mean, d);
+        ev.cov[d] = lane_read(cov, d);
+      }
+      return draw_label<T, P>(rows, ds, lane, ev, u);
+    }
+  };
+
+  // one (pass, density) step: draw the label and adopt it.  Updating the selected kernel right
+  // after the draw is equivalent to the reference's deferred calcIndices! (:383): within the
+  // sampleIndices! pass nothing reads the selected kernels.
+  auto step = [&](int j, const LevelDesc &ds, auto hdr, T mean, T cov, double u) {
+    const int pos = draw(ds, hdr, mean, cov, u);
+    wave_sync();
+    set_particle(j, ds, hdr, pos);
+    wave_sync();
+  };
+
   // init: frontier = {root}, label = root (levelInit!/initIndices!/calcIndices!, :587-589)
-  for (int j = 0; j < M; ++j) set_particle(j, plan.levels[j * (L + 1)], 0);
+  for (int j = 0; j < M; ++j) {
+    const LevelDesc ds = levels[j * (L + 1)];
+    set_particle(j, ds, data + ds.hdr_off, 0);
+  }
   wave_sync();
 
   uint32_t c = static_cast<uint32_t>(M);  // select-call counter; the M init calls read nothing
@@ -299,75 +453,76 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gibbs_product_kernel(Plan
     return a.randN[s * a.R + r];
   };
 
-  T xs[D], zero[D];
-#pragma unroll
-  for (int d = 0; d < D; ++d) zero[d] = T(0);
-
+  const int nsteps = M * (a.Niter + 1);  // per level: M sampleIndices! draws, then Niter sweeps of M
   for (int l = 1; l <= L; ++l) {
     // samplePoint! (:440-463): x = mean + sqrt(cov) * randn, all densities included
+    T x;
     {
       T mean, cov;
       product_dim(-1, any_bits, mean, cov);
-      const T x = mean + Num<T>::sqrt(cov) * static_cast<T>(normal_for_lane(l - 1));
-#pragma unroll
-      for (int d = 0; d < D; ++d) xs[d] = lane_read(x, d);
+      x = mean + Num<T>::sqrt(cov) * static_cast<T>(normal_for_lane(l - 1));
     }
-    // sampleIndices! (:364-385): every density draws a label on the new frontier against x
-    for (int j = 0; j < M; ++j) {
-      const LevelDesc ds = plan.levels[j * (L + 1) + l];
-      const uint32_t act = plan.mask_bits[j] & plan.others_bits[j];
-      const double u = next_uniform();
-      const int z = draw_label<T, D, FAST>(data + ds.data_off, ds, lane, xs, zero, act, u);
-      if (lane == 0) zsel[j] = z;
-    }
-    wave_sync();
-    for (int j = 0; j < M; ++j) set_particle(j, plan.levels[j * (L + 1) + l], zsel[j]);
-    wave_sync();
+    const int mode = a.variant == 1 ? int(kStageGlobal) : levels[l].stage_mode;
 
-    // sequential Gibbs sweeps (:604-609): leave density j out, redraw its label
-    for (int it = 0; it < a.Niter; ++it) {
+    if (mode == kStageResident) {
+      __syncthreads();  // every wavefront is done reading the previous level's images
       for (int j = 0; j < M; ++j) {
-        const LevelDesc ds = plan.levels[j * (L + 1) + l];
-        T mean, cov;
-        product_dim(j, plan.others_bits[j], mean, cov);
-        T mc[D], cc[D];
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-          mc[d] = lane_read(mean, d);
-          cc[d] = lane_read(cov, d);
-        }
-        const uint32_t act = plan.mask_bits[j] & plan.others_bits[j];
-        const double u = next_uniform();
-        const int z = draw_label<T, D, FAST>(data + ds.data_off, ds, lane, mc, cc, act, u);
-        wave_sync();
-        set_particle(j, ds, z);
-        wave_sync();
+        const LevelDesc ds = levels[j * (L + 1) + l];
+        stage_tile(reinterpret_cast<const unsigned char *>(data + ds.hdr_off), pool + ds.lds_off,
+                   ds.stage_bytes, wave, lane);
       }
+      __syncthreads();  // (waits for this wavefront's copies, then for everyone's)
+    } else if (mode == kStageStream) {
+      __syncthreads();
+      const LevelDesc ds0 = levels[l];
+      stage_tile(reinterpret_cast<const unsigned char *>(data + ds0.hdr_off), pool, ds0.stage_bytes, wave, lane);
     }
-    if (a.labels && lane == 0) {
-      for (int j = 0; j < M; ++j) {
-        const LevelDesc ds = plan.levels[j * (L + 1) + l];
-        const int z = zsel[j];
-        a.labels[(s * M + j) * L + (l - 1)] = plan.perm[ds.perm_off + (z % ds.B) * 64 + z / ds.B];
+
+    int j = 0;
+    for (int t = 0; t < nsteps; ++t) {
+      const LevelDesc ds = levels[j * (L + 1) + l];
+      T mean = x, cov = T(0);      // sampleIndices! (:364-385): against the point just drawn
+      if (t >= M) product_dim(j, ds.others_bits, mean, cov);  // sampleIndex (:404-429): leave j out
+      const double u = next_uniform();
+      if (mode == kStageGlobal) {
+        step(j, ds, data + ds.hdr_off, mean, cov, u);
+      } else if (mode == kStageResident) {
+        step(j, ds, (LdsPtr<T>)(pool + ds.lds_off), mean, cov, u);
+      } else {
+        // tile t has been copied by all wavefronts once everyone passes this barrier; buffer
+        // (t+1)&1 was last read in step t-1, which everyone has left -> start the next copy
+        __syncthreads();
+        if (t + 1 < nsteps) {
+          const int jn = (j + 1 == M) ? 0 : j + 1;
+          const LevelDesc dn = levels[jn * (L + 1) + l];
+          stage_tile(reinterpret_cast<const unsigned char *>(data + dn.hdr_off),
+                     pool + ((t + 1) & 1) * (kLdsPoolBytes / 2), dn.stage_bytes, wave, lane);
+        }
+        step(j, ds, (LdsPtr<T>)(pool + (t & 1) * (kLdsPoolBytes / 2)), mean, cov, u);
+      }
+      j = (j + 1 == M) ? 0 : j + 1;
+    }
+    if (a.labels && live && lane == 0) {
+      for (int k = 0; k < M; ++k) {
+        const LevelDesc ds = levels[k * (L + 1) + l];
+        a.labels[(s * M + k) * L + (l - 1)] = plan.perm[ds.perm_off + psel[k]];
       }
     }
   }
 
   // final labels (:612-616) and final point (:625)
-  if (lane == 0) {
-    for (int j = 0; j < M; ++j) {
-      const LevelDesc ds = plan.levels[j * (L + 1) + L];
-      const int z = zsel[j];
-      a.indices[s * M + j] =
-          static_cast<int64_t>(plan.perm[ds.perm_off + (z % ds.B) * 64 + z / ds.B]) + 1;
+  if (live && lane == 0) {
+    for (int k = 0; k < M; ++k) {
+      const LevelDesc ds = levels[k * (L + 1) + L];
+      a.indices[s * M + k] = static_cast<int64_t>(plan.perm[ds.perm_off + psel[k]]) + 1;
     }
   }
   {
     T mean, cov;
     product_dim(-1, any_bits, mean, cov);
-    T x = mean;
-    if (a.addEntropy) x = mean + Num<T>::sqrt(cov) * static_cast<T>(normal_for_lane(L));
-    if (lane < D) a.points[s * D + lane] = static_cast<double>(x);
+    T xf = mean;
+    if (a.addEntropy) xf = mean + Num<T>::sqrt(cov) * static_cast<T>(normal_for_lane(L));
+    if (live && lane < D) a.points[s * D + lane] = static_cast<double>(xf);
   }
 }
 
@@ -375,10 +530,10 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gibbs_product_kernel(Plan
 
 template <typename T, int D, bool FAST>
 static int launch_one(const PlanDev &plan, const RunArgs &args, hipStream_t stream) {
-  const int64_t blocks = (args.Np + kWavesPerBlock - 1) / kWavesPerBlock;
+  const int64_t blocks = (args.Np + kWgWaves - 1) / kWgWaves;
   if (blocks <= 0) return KDEHIP_OK;
   hipLaunchKernelGGL((gibbs_product_kernel<T, D, FAST>), dim3(static_cast<unsigned>(blocks)),
-                     dim3(kWavesPerBlock * 64), 0, stream, plan, args);
+                     dim3(kWgWaves * 64), 0, stream, plan, args);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess)
     return set_error(KDEHIP_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString(e));

@@ -16,28 +16,49 @@ const char *last_error_cstr();
 // ---- packed per-level layout ("pack_levels") ---------------------------------------------------
 // The frontier of density j after l levelDown! calls (reference src/MSGibbs01.jl:500-523) is
 // data-independent, so it is materialised once on the host.  A frontier of n nodes is stored as a
-// tile of B*64 positions, B = ceil(n/64): frontier entry z (0-based, reference order) lives at
-// position (z % B)*64 + z / B, i.e. lane `ln` of a wavefront owns the CONTIGUOUS entries
-// z = ln*B .. ln*B+B-1 and reads them with fully coalesced loads (row i of the tile holds entry
-// ln*B+i of every lane).  Fields are struct-of-arrays with leading dimension ld = B*64:
-//   [0, D)      mean of dim d          [D, 2D)  bandwidth (variance) of dim d      [2D]  weight
-// Padding positions (z >= n) carry weight 0, variance 1, mean 0 and never win a draw.
-struct LevelDesc {
-  int32_t n;          // frontier size n_{j,l}
-  int32_t B;          // entries per lane
-  int64_t data_off;   // element offset (units of T) of the tile in the plan's data buffer
-  int64_t perm_off;   // offset of the tile's int32 permutation row (position-indexed, 0 = internal)
-  int32_t uniform_bw; // 1: every node of the frontier has the same bandwidth vector
-  int32_t pad_;
+// tile of B rows x 64 lanes, B = ceil(n/64): frontier entry z (0-based, reference order) sits in
+// lane z / B, row z % B, i.e. lane `ln` of a wavefront owns the CONTIGUOUS entries
+// ln*B .. ln*B+B-1.  A tile is one contiguous block of T elements:
+//   header  kTileHeader (8) elements: the bandwidth vector of entry 0 (= of every entry if uniform_bw)
+//   row i   F fields of 64 lanes each + 1 pad element (row stride RS = F*64 + 1); the pad makes the
+//           column walk of the second selection pass bank-conflict free once the tile sits in LDS
+//   element (row i, field f, lane ln) at hdr_off + kTileHeader + i*RS + f*64 + ln
+//   fields: [0, D) mean per dimension; then, unless the level has ONE bandwidth vector shared by
+//   all its nodes (uniform_bw: always true for the leaf level of a reference-built density),
+//   [D, 2D) bandwidth (variance) per dimension; last field (F-1): weight.
+// `pos` = i*64 + ln identifies an entry inside its tile (also the index into the permutation row).
+// Padding entries (z >= n) carry weight 0, variance 1, mean 0 and never win a draw.
+// The LDS image of a tile is a byte copy of [hdr_off, hdr_off + stage_bytes).
+constexpr int kTileHeader = 8;
+enum StageMode : int32_t {
+  kStageGlobal = 0,    // tile too large for LDS: wavefronts read it from global memory (L1/L2)
+  kStageResident = 1,  // all densities' tiles of the level fit the LDS pool at once
+  kStageStream = 2     // one tile per step, double-buffered in the LDS pool
 };
+constexpr int kWgWaves = 8;                 // wavefronts (= chains) per workgroup
+constexpr int kLdsPoolBytes = 140 * 1024;   // LDS bytes for staged tiles (of 160 KiB per CU)
+
+struct LevelDesc {
+  int32_t n;            // frontier size n_{j,l}
+  int32_t B;            // rows = entries per lane
+  int32_t F;            // fields per row: 2D+1, or D+1 when uniform_bw
+  int32_t uniform_bw;   // 1: every node of the frontier has the header's bandwidth vector
+  int64_t hdr_off;      // element offset (units of T) of the tile header; rows start kTileHeader later
+  int64_t perm_off;     // offset of the tile's int32 permutation row (indexed by pos, 0 = internal)
+  uint32_t mask_bits;   // bit d: this density informs dimension d (partialDimMask)
+  uint32_t others_bits; // bit d: some other density informs dimension d
+  int32_t stage_mode;   // StageMode of this LEVEL (same for every density)
+  int32_t lds_off;      // byte offset of the tile image in the LDS pool (resident mode)
+  int32_t stage_bytes;  // bytes to copy (header + rows, rounded up to 1 KiB)
+  int32_t pad_[3];
+};
+static_assert(sizeof(LevelDesc) == 64, "LevelDesc is read with scalar loads; keep it 64 bytes");
 
 struct PlanDev {
   const void *data;          // T[...]
   const int32_t *perm;       // int32[...]
   const LevelDesc *levels;   // [M][L+1], level 0 = root
   int32_t M, L, D, pad_;
-  uint32_t mask_bits[KDEHIP_MAX_DENS];    // bit d: density j informs dimension d (partialDimMask)
-  uint32_t others_bits[KDEHIP_MAX_DENS];  // bit d: some density k != j informs dimension d
 };
 
 struct RunArgs {
@@ -64,14 +85,14 @@ struct PackedProduct {
   std::vector<double> data;        // fp64 payload
   std::vector<int32_t> perm;
   int64_t nodes_per_sweep = 0;     // sum_j sum_{l>=1} n_{j,l}
-  bool fast_ok_f64 = true, fast_ok_f32 = true;
-  uint32_t mask_bits[KDEHIP_MAX_DENS] = {0};
-  uint32_t others_bits[KDEHIP_MAX_DENS] = {0};
+  bool fast = true;                // product/rsqrt arithmetic + compact uniform tiles in use
   bool masked = false;
 };
 
 // Validates the densities and builds the packed layout.  Returns KDEHIP_OK or an error code.
-int pack_levels(int Ndens, const kdehip_density *trees, int ndims, const uint8_t *mask,
+// `precision` (64/32) decides whether the fast arithmetic path -- and with it the compact
+// uniform-bandwidth tiles -- may be used (out.fast).
+int pack_levels(int Ndens, const kdehip_density *trees, int ndims, const uint8_t *mask, int precision,
                 PackedProduct &out);
 
 // floor(log(maxNp)/log(2) + 1), reference src/MSGibbs01.jl:568

@@ -2,11 +2,10 @@
 //
 // The reference builds the frontier lists on the fly for every output sample (levelInit!,
 // levelDown!, src/MSGibbs01.jl:467-475,500-523).  They depend only on the trees, so here they are
-// expanded once per product and stored level by level in the lane-blocked SoA layout described in
-// kdehip_internal.hpp; the kernels never touch the tree topology.
+// expanded once per product and stored level by level in the lane-blocked row/field layout
+// described in kdehip_internal.hpp; the kernels never touch the tree topology.
 #include <cmath>
 #include <cstring>
-#include <mutex>
 
 #include "kdehip_internal.hpp"
 
@@ -27,7 +26,7 @@ int nlevels_for(int64_t maxNp) {
   return static_cast<int>(std::floor(std::log(static_cast<double>(maxNp)) / std::log(2.0) + 1.0));
 }
 
-int pack_levels(int Ndens, const kdehip_density *trees, int ndims, const uint8_t *mask,
+int pack_levels(int Ndens, const kdehip_density *trees, int ndims, const uint8_t *mask, int precision,
                 PackedProduct &out) {
   if (Ndens < 1 || !trees) return set_error(KDEHIP_ERR_ARG, "need at least one density");
   if (Ndens > KDEHIP_MAX_DENS)
@@ -51,36 +50,32 @@ int pack_levels(int Ndens, const kdehip_density *trees, int ndims, const uint8_t
   out.M = M; out.D = D; out.L = L;
   out.levels.resize(static_cast<size_t>(M) * (L + 1));
 
-  const uint32_t all = (D >= 32) ? 0xFFFFFFFFu : ((1u << D) - 1u);
+  const uint32_t all = (1u << D) - 1u;
+  std::vector<uint32_t> mask_bits(M, all), others_bits(M, 0);
   for (int j = 0; j < M; ++j) {
-    uint32_t b = all;
     if (mask) {
-      b = 0;
+      uint32_t b = 0;
       for (int d = 0; d < D; ++d) if (mask[j * D + d]) b |= (1u << d);
+      mask_bits[j] = b;
       if (b != all) out.masked = true;
     }
-    out.mask_bits[j] = b;
   }
-  for (int j = 0; j < M; ++j) {
-    uint32_t o = 0;
-    for (int k = 0; k < M; ++k) if (k != j) o |= out.mask_bits[k];
-    out.others_bits[j] = o;
-  }
+  for (int j = 0; j < M; ++j)
+    for (int k = 0; k < M; ++k) if (k != j) others_bits[j] |= mask_bits[k];
 
-  // range bookkeeping for the product/rsqrt evaluation (see eval_fast in gibbs_kernel.hip)
+  // ---- phase 1: expand every frontier (levelDown!, src/MSGibbs01.jl:503-511) and collect ranges
+  std::vector<std::vector<int64_t>> frontier(static_cast<size_t>(M) * (L + 1));
   std::vector<double> bw_lo(D, INFINITY), bw_hi(D, 0.0);
   bool finite_ok = true;
-
-  const int F = 2 * D + 1;
-  std::vector<int64_t> cur, nxt;
   for (int j = 0; j < M; ++j) {
     const kdehip_density &t = trees[j];
     const int64_t N = t.npts;
     auto valid = [N](int64_t id) { return id > 0 && id <= 2 * N; };  // BallTree01.jl:83
-    cur.assign(1, 1);  // levelInit!: frontier = {root()}
+    std::vector<int64_t> cur(1, 1);  // levelInit!: frontier = {root()}
     for (int l = 0; l <= L; ++l) {
-      if (l > 0) {  // levelDown!, src/MSGibbs01.jl:503-511
-        nxt.clear();
+      if (l > 0) {
+        std::vector<int64_t> nxt;
+        nxt.reserve(cur.size() * 2);
         for (int64_t node : cur) {
           const int64_t a = t.left_child[node - 1], b = t.right_child[node - 1];
           if (valid(a)) nxt.push_back(a);
@@ -91,44 +86,18 @@ int pack_levels(int Ndens, const kdehip_density *trees, int ndims, const uint8_t
         cur.swap(nxt);
         out.nodes_per_sweep += static_cast<int64_t>(cur.size());
       }
-      const int64_t n = static_cast<int64_t>(cur.size());
-      const int64_t B = (n + 63) / 64;
-      const int64_t ld = B * 64;
-      LevelDesc &ds = out.levels[static_cast<size_t>(j) * (L + 1) + l];
-      ds.n = static_cast<int32_t>(n);
-      ds.B = static_cast<int32_t>(B);
-      ds.data_off = static_cast<int64_t>(out.data.size());
-      ds.perm_off = static_cast<int64_t>(out.perm.size());
-      ds.pad_ = 0;
-      out.data.resize(out.data.size() + static_cast<size_t>(F * ld));
-      out.perm.resize(out.perm.size() + static_cast<size_t>(ld), 0);
-      double *tile = out.data.data() + ds.data_off;
-      int32_t *prow = out.perm.data() + ds.perm_off;
-      for (int64_t p = 0; p < ld; ++p) {  // padding: mean 0, variance 1, weight 0
-        for (int d = 0; d < D; ++d) { tile[d * ld + p] = 0.0; tile[(D + d) * ld + p] = 1.0; }
-        tile[2 * D * ld + p] = 0.0;
-      }
-      bool uni = true;
-      for (int64_t z = 0; z < n; ++z) {
-        const int64_t node = cur[static_cast<size_t>(z)];
+      for (int64_t node : cur) {
         if (!valid(node)) return set_error(KDEHIP_ERR_ARG, "malformed tree: child id out of range");
-        const int64_t p = (z % B) * 64 + z / B;
         for (int d = 0; d < D; ++d) {
-          const double mu = t.means[(node - 1) * D + d];
-          const double v = t.bandwidth[(node - 1) * D + d];
-          tile[d * ld + p] = mu;
-          tile[(D + d) * ld + p] = v;
-          if (v != t.bandwidth[(cur[0] - 1) * D + d]) uni = false;
+          const double mu = t.means[(node - 1) * D + d], v = t.bandwidth[(node - 1) * D + d];
           if (!(std::isfinite(mu) && std::isfinite(v) && v > 0.0)) finite_ok = false;
           if (v < bw_lo[d]) bw_lo[d] = v;
           if (v > bw_hi[d]) bw_hi[d] = v;
         }
         const double w = t.weights[node - 1];
         if (!(std::isfinite(w) && w >= 0.0)) finite_ok = false;
-        tile[2 * D * ld + p] = w;
-        prow[p] = static_cast<int32_t>(t.permutation[node - 1]);
       }
-      ds.uniform_bw = uni ? 1 : 0;
+      frontier[static_cast<size_t>(j) * (L + 1) + l] = cur;
     }
   }
 
@@ -142,10 +111,85 @@ int pack_levels(int Ndens, const kdehip_density *trees, int ndims, const uint8_t
     if (hi > 1.0) up *= hi;
     if (lo < 1.0) dn *= lo;
   }
-  const bool range64 = finite_ok && up < 1e120 && dn > 1e-120;
-  const bool range32 = finite_ok && up < 1e15 && dn > 1e-15;
-  out.fast_ok_f64 = range64 && !out.masked;
-  out.fast_ok_f32 = range32 && !out.masked;
+  const bool in_range = (precision == 64) ? (up < 1e120 && dn > 1e-120) : (up < 1e15 && dn > 1e-15);
+  out.fast = finite_ok && in_range && !out.masked;
+
+  // ---- phase 2: write the tiles
+  const int64_t esz = (precision == 64) ? 8 : 4;
+  for (int j = 0; j < M; ++j) {
+    const kdehip_density &t = trees[j];
+    for (int l = 0; l <= L; ++l) {
+      const std::vector<int64_t> &cur = frontier[static_cast<size_t>(j) * (L + 1) + l];
+      const int64_t n = static_cast<int64_t>(cur.size());
+      const int64_t B = (n + 63) / 64;
+      bool uni = out.fast;  // compact tiles only on the fast path
+      for (int64_t z = 1; z < n && uni; ++z)
+        for (int d = 0; d < D; ++d)
+          if (t.bandwidth[(cur[z] - 1) * D + d] != t.bandwidth[(cur[0] - 1) * D + d]) { uni = false; break; }
+      const int F = uni ? D + 1 : 2 * D + 1;
+      const int64_t RS = static_cast<int64_t>(F) * 64 + 1;
+      LevelDesc &ds = out.levels[static_cast<size_t>(j) * (L + 1) + l];
+      std::memset(&ds, 0, sizeof(ds));
+      ds.n = static_cast<int32_t>(n);
+      ds.B = static_cast<int32_t>(B);
+      ds.F = F;
+      ds.uniform_bw = uni ? 1 : 0;
+      ds.mask_bits = mask_bits[j];
+      ds.others_bits = others_bits[j];
+      while (out.data.size() % 8) out.data.push_back(0.0);  // tiles start 64-byte (fp32: 32-byte) aligned
+      ds.hdr_off = static_cast<int64_t>(out.data.size());
+      for (int d = 0; d < kTileHeader; ++d)
+        out.data.push_back(d < D ? t.bandwidth[(cur[0] - 1) * D + d] : 0.0);
+      const int64_t rows_off = static_cast<int64_t>(out.data.size());
+      ds.perm_off = static_cast<int64_t>(out.perm.size());
+      out.data.resize(out.data.size() + static_cast<size_t>(B * RS), 0.0);
+      out.perm.resize(out.perm.size() + static_cast<size_t>(B * 64), 0);
+      const int64_t bytes = (kTileHeader + B * RS) * esz;
+      if (bytes > (int64_t(1) << 30)) return set_error(KDEHIP_ERR_UNSUPPORTED, "level tile too large");
+      ds.stage_bytes = static_cast<int32_t>((bytes + 1023) / 1024 * 1024);
+      double *tile = out.data.data() + rows_off;
+      int32_t *prow = out.perm.data() + ds.perm_off;
+      for (int64_t i = 0; i < B; ++i)
+        for (int ln = 0; ln < 64; ++ln) {
+          double *e = tile + i * RS + ln;
+          const int64_t z = static_cast<int64_t>(ln) * B + i;
+          if (z < n) {
+            const int64_t node = cur[static_cast<size_t>(z)];
+            for (int d = 0; d < D; ++d) e[d * 64] = t.means[(node - 1) * D + d];
+            if (!uni) for (int d = 0; d < D; ++d) e[(D + d) * 64] = t.bandwidth[(node - 1) * D + d];
+            e[(F - 1) * 64] = t.weights[node - 1];
+            prow[i * 64 + ln] = static_cast<int32_t>(t.permutation[node - 1]);
+          } else {  // padding: mean 0, variance 1, weight 0
+            for (int d = 0; d < D; ++d) e[d * 64] = 0.0;
+            if (!uni) for (int d = 0; d < D; ++d) e[(D + d) * 64] = 1.0;
+            e[(F - 1) * 64] = 0.0;
+          }
+        }
+    }
+  }
+  // staged copies are rounded up to whole KiB: keep the tail readable
+  out.data.resize(out.data.size() + 1024 / 4, 0.0);
+
+  // ---- phase 3: where each level's tiles live while the kernel works on that level
+  for (int l = 0; l <= L; ++l) {
+    int64_t sum = 0, mx = 0;
+    for (int j = 0; j < M; ++j) {
+      const int64_t b = out.levels[static_cast<size_t>(j) * (L + 1) + l].stage_bytes;
+      sum += b;
+      if (b > mx) mx = b;
+    }
+    int32_t mode = kStageGlobal;
+    if (l == 0) mode = kStageGlobal;  // the roots are read once, straight from memory
+    else if (sum <= kLdsPoolBytes) mode = kStageResident;
+    else if (mx <= kLdsPoolBytes / 2) mode = kStageStream;
+    int64_t off = 0;
+    for (int j = 0; j < M; ++j) {
+      LevelDesc &ds = out.levels[static_cast<size_t>(j) * (L + 1) + l];
+      ds.stage_mode = mode;
+      ds.lds_off = (mode == kStageResident) ? static_cast<int32_t>(off) : 0;
+      off += ds.stage_bytes;
+    }
+  }
   return KDEHIP_OK;
 }
 

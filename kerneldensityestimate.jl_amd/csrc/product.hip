@@ -85,12 +85,12 @@ int kdehip_product_create(kdehip_product **out, int Ndens, const kdehip_density 
   if (precision != 64 && precision != 32) return set_error(KDEHIP_ERR_ARG, "precision must be 64 or 32");
   kdehip_product *p = new (std::nothrow) kdehip_product();
   if (!p) return set_error(KDEHIP_ERR_ALLOC, "out of host memory");
-  int rc = pack_levels(Ndens, trees, ndims, partialDimMask, p->host);
+  int rc = pack_levels(Ndens, trees, ndims, partialDimMask, precision, p->host);
   if (rc == KDEHIP_OK) rc = use_device(device);
   if (rc != KDEHIP_OK) { delete p; return rc; }
   p->device = device;
   p->precision = precision;
-  p->fast = (precision == 64) ? p->host.fast_ok_f64 : p->host.fast_ok_f32;
+  p->fast = p->host.fast;
 
   const size_t nelem = p->host.data.size();
   const size_t esz = (precision == 64) ? sizeof(double) : sizeof(float);
@@ -130,8 +130,6 @@ int kdehip_product_create(kdehip_product **out, int Ndens, const kdehip_density 
   p->dev.L = p->host.L;
   p->dev.D = p->host.D;
   p->dev.pad_ = 0;
-  std::memcpy(p->dev.mask_bits, p->host.mask_bits, sizeof(p->dev.mask_bits));
-  std::memcpy(p->dev.others_bits, p->host.others_bits, sizeof(p->dev.others_bits));
   *out = p;
   return KDEHIP_OK;
 }
