@@ -56,6 +56,18 @@ def synth_inputs(kdehip, D, M, N, config_id):
     return pts_all, bw_all
 
 
+def usable_cores():
+    """Host cores this process may actually use: the affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def load_traffic(workload):
     """HBM bytes per launch from the committed PMC profile (profiles/traffic_latest.json), or None."""
     p = os.path.join(ROOT, "profiles", "traffic_latest.json")
@@ -91,8 +103,12 @@ def main():
         raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("KDEHIP_FORCE_DIST") == "1"  # (the latter: 1-rank test of the RCCL path)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     import kdehip
@@ -122,7 +138,7 @@ def main():
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     bufs = sp._buffers(Np_total)
 
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -132,20 +148,20 @@ def main():
         plan.sample_philox_device(hi - lo, Niter, seed, base + lo, True, bufs["pts"], bufs["ind"], None,
                                   stream.cuda_stream)
         ev[i][1].record(stream)
-        if world > 1:
+        if use_dist:
             dist.all_gather_into_tensor(bufs["all_pts"], bufs["pts"])
             dist.all_gather_into_tensor(bufs["all_ind"], bufs["ind"])
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    if world > 1:
+    if use_dist:
         t = torch.tensor([kern_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         kern_ms = float(t.item())
@@ -183,7 +199,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out.update(cpu_baseline_and_parity(kdehip, plan, pts_all, bw_all, D, M, N, Nout, Niter, seed, args.warmup))
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
@@ -193,7 +209,7 @@ def cpu_baseline_and_parity(kdehip, plan, pts_all, bw_all, D, M, N, Nout, Niter,
     from oracle import oracle
     otrees = [oracle.OracleDensity(p, b) for p, b in zip(pts_all, bw_all)]
     K, R = plan.randu_per_sample(Niter), plan.randn_per_sample()
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = usable_cores()
     # bounded sample, ~50 core-seconds in total (config 3 costs ~3-6 ms per sample per core): the
     # all-cores run takes the first `nall` chains of the workload's Philox stream (more than one
     # GPU batch when the host has many cores), the single-core run the first `n1`.

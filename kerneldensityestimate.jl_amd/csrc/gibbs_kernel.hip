@@ -305,6 +305,18 @@ struct LdsLayout {
 };
 
 template <typename T> using LdsPtr = const __attribute__((address_space(3))) T *;
+// read-only, wave-uniform tables are read through the constant address space so that the compiler
+// uses scalar loads (s_load_*, lgkmcnt) and never drains the direct-to-LDS copies in flight (vmcnt)
+typedef int kdehip_v16i __attribute__((ext_vector_type(16)));
+struct LevelTable {
+  const __attribute__((address_space(4))) kdehip_v16i *p;
+  __device__ __forceinline__ LevelDesc operator[](int idx) const {
+    const kdehip_v16i raw = p[idx];  // one s_load_dwordx16
+    LevelDesc d;
+    __builtin_memcpy(&d, &raw, sizeof(LevelDesc));
+    return d;
+  }
+};
 using LdsVoidPtr = __attribute__((address_space(3))) void *;
 using GlobalVoidPtr = const __attribute__((address_space(1))) void *;
 
@@ -340,7 +352,7 @@ __global__ __launch_bounds__(kWgWaves * 64) void gibbs_product_kernel(PlanDev pl
 
   const int M = plan.M, L = plan.L;
   const T *__restrict__ data = static_cast<const T *>(plan.data);
-  const LevelDesc *__restrict__ levels = plan.levels;
+  const LevelTable levels{(const __attribute__((address_space(4))) kdehip_v16i *)(plan.levels)};
   unsigned char *state = smem + Lay::kStateOff + wave * Lay::kStatePerWave;
   T *lam = reinterpret_cast<T *>(state);                 // 1/variance of the selected kernels
   T *lmu = lam + KDEHIP_MAX_DENS * D;                    // mean/variance
@@ -348,6 +360,7 @@ __global__ __launch_bounds__(kWgWaves * 64) void gibbs_product_kernel(PlanDev pl
   unsigned char *pool = smem + Lay::kPoolOff;
   const int dl = lane < D ? lane : D - 1;  // this lane's dimension in the "lanes = dimensions" phases
 
+  const int vlev = a.variant % 1000, vflags = a.variant / 1000;  // timing/ablation experiments only
   uint32_t any_bits = 0;  // dimensions informed by at least one density
   for (int j = 0; j < M; ++j) any_bits |= levels[j * (L + 1)].mask_bits;
 
@@ -369,12 +382,24 @@ __global__ __launch_bounds__(kWgWaves * 64) void gibbs_product_kernel(PlanDev pl
   // Gaussian product of the selected kernels without density `skip` for this lane's dimension
   // (gaussianProductMeanCov!, :176-216): cov = 1/sum(lambda), mean = cov * sum(mu*lambda).
   auto product_dim = [&](int skip, uint32_t info_bits, T &mean, T &cov) {
+    // all LDS reads are issued before the first add (one LDS round trip instead of M); a skipped
+    // density contributes an exact +0, so the sums are the reference's sequential sums (:199-213)
     T ls = T(0), ms = T(0);
-    for (int k = 0; k < M; ++k) {
-      if (k != skip) {
-        ls += lam[k * D + dl];
-        ms += lmu[k * D + dl];
+    int k = 0;
+    for (; k + 4 <= M; k += 4) {
+      T l4[4], m4[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { l4[i] = lam[(k + i) * D + dl]; m4[i] = lmu[(k + i) * D + dl]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ls += (k + i != skip) ? l4[i] : T(0);
+        ms += (k + i != skip) ? m4[i] : T(0);
       }
+    }
+    for (; k < M; ++k) {
+      const T l1 = lam[k * D + dl], m1 = lmu[k * D + dl];
+      ls += (k != skip) ? l1 : T(0);
+      ms += (k != skip) ? m1 : T(0);
     }
     const bool on = (info_bits >> dl) & 1u;
     cov = on ? T(1) / ls : T(0);
@@ -426,9 +451,9 @@ __global__ __launch_bounds__(kWgWaves * 64) void gibbs_product_kernel(PlanDev pl
   // after the draw is equivalent to the reference's deferred calcIndices! (:383): within the
   // sampleIndices! pass nothing reads the selected kernels.
   auto step = [&](int j, const LevelDesc &ds, auto hdr, T mean, T cov, double u) {
-    const int pos = draw(ds, hdr, mean, cov, u);
+    const int pos = (vflags & 8) ? 0 : draw(ds, hdr, mean, cov, u);
     wave_sync();
-    set_particle(j, ds, hdr, pos);
+    if (!(vflags & 2)) set_particle(j, ds, hdr, pos);
     wave_sync();
   };
 
@@ -439,11 +464,30 @@ __global__ __launch_bounds__(kWgWaves * 64) void gibbs_product_kernel(PlanDev pl
   }
   wave_sync();
 
-  uint32_t c = static_cast<uint32_t>(M);  // select-call counter; the M init calls read nothing
+  // Uniform draws: select call c of this chain uses uniform c of its stream (the M init calls read
+  // nothing).  They are produced 128 at a time across the lanes -- lane ln holds uniforms
+  // 128*batch + 2*ln and + 2*ln+1 (one Philox block, or two stream elements) -- and handed out with
+  // v_readlane, so the 10-round Philox is off the per-step critical path.
+  uint32_t c = static_cast<uint32_t>(M);
+  uint32_t ubatch = 0xFFFFFFFFu;
+  double u_even = 0.0, u_odd = 0.0;
   auto next_uniform = [&]() -> double {
-    double u;
-    if (a.rng_philox) u = philox_uniform(a.seed, gs, c);
-    else u = a.randU[s * a.K + static_cast<int64_t>(c) - 1];
+    if (vflags & 1) { ++c; return 0.37; }
+    const uint32_t b = c >> 7;
+    if (b != ubatch) {
+      ubatch = b;
+      if (a.rng_philox) {
+        const Philox4 r = philox_block(a.seed, gs, b * 64u + static_cast<uint32_t>(lane), 0u);
+        u_even = bits_to_unit(r.v[0], r.v[1]);
+        u_odd = bits_to_unit(r.v[2], r.v[3]);
+      } else {  // element i of the sample's slice feeds call i+1 (philox.hpp / product.hip)
+        const int64_t i0 = s * a.K + static_cast<int64_t>(b) * 128 + 2 * lane - 1;
+        u_even = (i0 >= 0 && i0 < a.nU) ? a.randU[i0] : 0.5;
+        u_odd = (i0 + 1 < a.nU) ? a.randU[i0 + 1] : 0.5;
+      }
+    }
+    const double pick = (c & 1u) ? u_odd : u_even;
+    const double u = lane_read(pick, static_cast<int>((c & 127u) >> 1));
     ++c;
     return u;
   };
@@ -454,7 +498,9 @@ __global__ __launch_bounds__(kWgWaves * 64) void gibbs_product_kernel(PlanDev pl
   };
 
   const int nsteps = M * (a.Niter + 1);  // per level: M sampleIndices! draws, then Niter sweeps of M
-  for (int l = 1; l <= L; ++l) {
+  // (timing experiments only: variant 100+k stops the anneal after level k)
+  const int Lrun = (vlev >= 100 && vlev - 100 < L) ? vlev - 100 : L;
+  for (int l = 1; l <= Lrun; ++l) {
     // samplePoint! (:440-463): x = mean + sqrt(cov) * randn, all densities included
     T x;
     {
@@ -462,7 +508,7 @@ __global__ __launch_bounds__(kWgWaves * 64) void gibbs_product_kernel(PlanDev pl
       product_dim(-1, any_bits, mean, cov);
       x = mean + Num<T>::sqrt(cov) * static_cast<T>(normal_for_lane(l - 1));
     }
-    const int mode = a.variant == 1 ? int(kStageGlobal) : levels[l].stage_mode;
+    const int mode = vlev == 1 ? int(kStageGlobal) : levels[l].stage_mode;
 
     if (mode == kStageResident) {
       __syncthreads();  // every wavefront is done reading the previous level's images
@@ -479,10 +525,13 @@ __global__ __launch_bounds__(kWgWaves * 64) void gibbs_product_kernel(PlanDev pl
     }
 
     int j = 0;
+    LevelDesc ds_next = levels[l];  // descriptor of step 0; each step fetches its successor's early
     for (int t = 0; t < nsteps; ++t) {
-      const LevelDesc ds = levels[j * (L + 1) + l];
+      const LevelDesc ds = ds_next;
+      const int jn = (j + 1 == M) ? 0 : j + 1;
+      ds_next = levels[jn * (L + 1) + l];
       T mean = x, cov = T(0);      // sampleIndices! (:364-385): against the point just drawn
-      if (t >= M) product_dim(j, ds.others_bits, mean, cov);  // sampleIndex (:404-429): leave j out
+      if (t >= M && !(vflags & 4)) product_dim(j, ds.others_bits, mean, cov);  // sampleIndex (:404-429): leave j out
       const double u = next_uniform();
       if (mode == kStageGlobal) {
         step(j, ds, data + ds.hdr_off, mean, cov, u);
@@ -492,15 +541,12 @@ __global__ __launch_bounds__(kWgWaves * 64) void gibbs_product_kernel(PlanDev pl
         // tile t has been copied by all wavefronts once everyone passes this barrier; buffer
         // (t+1)&1 was last read in step t-1, which everyone has left -> start the next copy
         __syncthreads();
-        if (t + 1 < nsteps) {
-          const int jn = (j + 1 == M) ? 0 : j + 1;
-          const LevelDesc dn = levels[jn * (L + 1) + l];
-          stage_tile(reinterpret_cast<const unsigned char *>(data + dn.hdr_off),
-                     pool + ((t + 1) & 1) * (kLdsPoolBytes / 2), dn.stage_bytes, wave, lane);
-        }
+        if (t + 1 < nsteps)
+          stage_tile(reinterpret_cast<const unsigned char *>(data + ds_next.hdr_off),
+                     pool + ((t + 1) & 1) * (kLdsPoolBytes / 2), ds_next.stage_bytes, wave, lane);
         step(j, ds, (LdsPtr<T>)(pool + (t & 1) * (kLdsPoolBytes / 2)), mean, cov, u);
       }
-      j = (j + 1 == M) ? 0 : j + 1;
+      j = jn;
     }
     if (a.labels && live && lane == 0) {
       for (int k = 0; k < M; ++k) {

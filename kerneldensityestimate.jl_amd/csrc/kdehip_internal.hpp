@@ -70,6 +70,7 @@ struct RunArgs {
   const double *randU;
   const double *randN;
   int64_t K, R;         // per-sample consumption
+  int64_t nU, nN;       // stream lengths (streams mode)
   uint64_t seed;
   int64_t sample_offset;
   double *points;

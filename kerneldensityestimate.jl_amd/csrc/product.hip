@@ -192,7 +192,7 @@ int kdehip_product_sample_streams(kdehip_product *plan, int64_t Np, int Niter, c
   RunArgs a{};
   a.Np = Np; a.Niter = Niter; a.addEntropy = addEntropy ? 1 : 0; a.rng_philox = 0;
   a.variant = plan->variant;
-  a.randU = d_randU; a.randN = d_randN; a.K = K; a.R = R;
+  a.randU = d_randU; a.randN = d_randN; a.K = K; a.R = R; a.nU = nU; a.nN = nN;
   a.seed = 0; a.sample_offset = 0;
   a.points = d_points; a.indices = d_indices; a.labels = d_labels;
   return launch_gibbs(plan->precision, plan->fast, plan->dev, a, stream);

@@ -1,0 +1,45 @@
+"""bench.py contract checks on a GPU box: one JSON line with the required keys, and the N>1 code path
+(process group "nccl" = RCCL, all-gather of the samples) exercised with a 1-rank group."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline"}
+
+
+def _run(cmd, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    out = subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_single_gpu_json_contract():
+    d = _run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1"])
+    assert REQUIRED <= set(d) and "cpu_baseline" in d
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["dtype"] == "f64" and d["scaling"] == "weak"
+    assert d["config"]["workload"].startswith("c3")
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert d["parity"]["label_mismatches"] == 0 and d["parity"]["moment_mean_diff"] < 1e-6
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
+
+
+def test_bench_distributed_path_one_rank():
+    d = _run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+             env={"KDEHIP_FORCE_DIST": "1", "MASTER_PORT": "29533"})
+    assert d["n_gpus"] == 1 and d["value"] > 0
+    d = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+              "--master-addr", "127.0.0.1", "--master-port", "29534", "bench.py", "--gpus", "1", "--steps", "2",
+              "--warmup", "1", "--no-cpu-baseline"])
+    assert d["n_gpus"] == 1 and d["value"] > 0
