@@ -1,0 +1,162 @@
+# KernelDensityEstimateHIP.jl -- thin `ccall` shim over libkdehip.so (include/kdehip.h).
+#
+# Host code stays in Julia: densities are built by the reference's own `kde!` / `BallTreeDensity`
+# (KernelDensityEstimate.jl), and only the Gibbs engine `gibbs1` (reference src/MSGibbs01.jl:527-629)
+# is replaced by the MI355X HIP kernels.  Two ways to use it:
+#
+#   using KernelDensityEstimate, KernelDensityEstimateHIP
+#   pGM, idx = KernelDensityEstimateHIP.prodAppxMSGibbsS(dummy, [p1; p2; p3], nothing, nothing; Niter=5)
+#
+# or, to route every existing caller (`*`, IncrementalInference, ...) through the GPU:
+#
+#   KernelDensityEstimateHIP.enable!()      # overrides KernelDensityEstimate.gibbs1
+#
+# NOTE: Julia is not installed in the build container, so this file has been written against the
+# C ABI but never executed; tests/ exercise the same entry points through the Python mirror.
+module KernelDensityEstimateHIP
+
+using KernelDensityEstimate
+const KDE = KernelDensityEstimate
+
+const libkdehip = get(ENV, "KDEHIP_LIB", joinpath(@__DIR__, "..", "libkdehip.so"))
+
+# struct kdehip_density (include/kdehip.h)
+struct CDensity
+  npts::Int64
+  ndim::Int64
+  means::Ptr{Float64}
+  bandwidth::Ptr{Float64}
+  weights::Ptr{Float64}
+  left_child::Ptr{Int64}
+  right_child::Ptr{Int64}
+  permutation::Ptr{Int64}
+end
+
+CDensity(bd::BallTreeDensity) = CDensity(bd.bt.num_points, bd.bt.dims, pointer(bd.means), pointer(bd.bandwidth),
+                                         pointer(bd.bt.weights), pointer(bd.bt.left_child),
+                                         pointer(bd.bt.right_child), pointer(bd.bt.permutation))
+
+lasterror() = unsafe_string(ccall((:kdehip_last_error, libkdehip), Cstring, ()))
+devicecount() = Int(ccall((:kdehip_device_count, libkdehip), Cint, ()))
+
+function check(rc::Integer)
+  rc == 0 && return nothing
+  msg = lasterror()
+  rc == -3 && throw(BoundsError(msg))   # randU / randN too short
+  error("libkdehip ($rc): $msg")         # incl. "kdes must have same dimension"
+end
+
+isEuclid(addop, diffop, getMu, getLambda) =
+  all(f -> f === +, addop) && all(f -> f === -, diffop) &&
+  all(f -> f === KDE.getEuclidMu, getMu) && all(f -> f === KDE.getEuclidLambda, getLambda)
+
+maskbytes(partialDimMask, Ndens, ndims) =
+  UInt8[partialDimMask[j][d] ? 0x01 : 0x00 for d in 1:ndims, j in 1:Ndens]   # density-major in memory
+
+"""
+    gibbs1(Ndens, trees, Np, Niter, pts, ind, randU, randN; kw...)
+
+Drop-in for `KernelDensityEstimate.gibbs1` (same arguments, fills `pts` and `ind` in place).
+Non-Euclidean manifold operators cannot cross the C ABI: they fall back to the reference.
+"""
+function gibbs1(Ndens::Int, trees::Array{BallTreeDensity,1}, Np::Int, Niter::Int,
+                pts::Array{Float64,1}, ind::Array{Int}, randU::Array{Float64,1}, randN::Array{Float64,1};
+                addop=(+,), diffop=(-,), getMu=(KDE.getEuclidMu,), getLambda=(KDE.getEuclidLambda,),
+                glbs=KDE.makeEmptyGbGlb(), addEntropy::Bool=true,
+                ndims::Int=maximum(Ndim.(trees)),
+                partialDimMask::AbstractVector{<:BitVector}=[ones(Int, ndims) .== 1 for i in 1:Ndens],
+                device::Int=0)
+  if !isEuclid(addop, diffop, getMu, getLambda) || glbs.recordChoosen
+    return KDE.gibbs1(Ndens, trees, Np, Niter, pts, ind, randU, randN; addop=addop, diffop=diffop, getMu=getMu,
+                      getLambda=getLambda, glbs=glbs, addEntropy=addEntropy, ndims=ndims,
+                      partialDimMask=partialDimMask)
+  end
+  cds = CDensity[CDensity(t) for t in trees]
+  mask = maskbytes(partialDimMask, Ndens, ndims)
+  GC.@preserve trees cds mask begin
+    rc = ccall((:kdehip_gibbs1, libkdehip), Cint,
+               (Cint, Ptr{CDensity}, Int64, Cint, Ptr{Float64}, Ptr{Int64}, Ptr{Float64}, Int64, Ptr{Float64},
+                Int64, Cint, Cint, Ptr{UInt8}, Cint),
+               Ndens, cds, Np, Niter, pts, ind, randU, length(randU), randN, length(randN),
+               addEntropy ? 1 : 0, ndims, mask, device)
+  end
+  check(rc)
+  nothing
+end
+
+"""
+    prodAppxMSGibbsS(npd0, trees, anFcns, anParams; Niter=3, ..., seed=nothing, device=0)
+
+Same keywords and return value as the reference (src/MSGibbs01.jl:645-703).  With `randU`/`randN`
+given they are consumed exactly like the reference consumes them; otherwise the on-device Philox
+stream keyed by `seed` replaces `rand`/`randn`.
+"""
+function prodAppxMSGibbsS(npd0::BallTreeDensity, trees::Array{BallTreeDensity,1}, anFcns, anParams;
+                          Niter::Int=3, addop=(+,), diffop=(-,), getMu=(KDE.getEuclidMu,),
+                          getLambda=(KDE.getEuclidLambda,), glbs=KDE.makeEmptyGbGlb(), addEntropy::Bool=true,
+                          ndims::Integer=maximum(Ndim.(trees)), Ndens=length(trees), Np=Npts(npd0),
+                          randU=nothing, randN=nothing,
+                          partialDimMask::AbstractVector{<:BitVector}=[ones(Int, ndims) .== 1 for i in 1:length(trees)],
+                          seed::Union{Nothing,UInt64}=nothing, device::Int=0)
+  if !isEuclid(addop, diffop, getMu, getLambda) || glbs.recordChoosen
+    kw = (randU === nothing) ? NamedTuple() : (randU=randU, randN=randN)
+    return KDE.prodAppxMSGibbsS(npd0, trees, anFcns, anParams; Niter=Niter, addop=addop, diffop=diffop,
+                                getMu=getMu, getLambda=getLambda, glbs=glbs, addEntropy=addEntropy,
+                                ndims=ndims, Ndens=Ndens, Np=Np, partialDimMask=partialDimMask, kw...)
+  end
+  points = zeros(ndims * Np)
+  indices = ones(Int, Ndens, Np)
+  if randU !== nothing
+    gibbs1(Ndens, trees, Np, Niter, points, indices, randU, randN; addEntropy=addEntropy, ndims=Int(ndims),
+           partialDimMask=partialDimMask, device=device)
+    return reshape(points, ndims, Np), indices
+  end
+  cds = CDensity[CDensity(t) for t in trees]
+  mask = maskbytes(partialDimMask, Ndens, ndims)
+  plan = Ref{Ptr{Cvoid}}(C_NULL)
+  GC.@preserve trees cds mask begin
+    check(ccall((:kdehip_product_create, libkdehip), Cint,
+                (Ref{Ptr{Cvoid}}, Cint, Ptr{CDensity}, Cint, Ptr{UInt8}, Cint, Cint),
+                plan, Ndens, cds, ndims, mask, 64, device))
+  end
+  try
+    s = seed === nothing ? rand(UInt64) : seed
+    check(ccall((:kdehip_product_sample_philox_host, libkdehip), Cint,
+                (Ptr{Cvoid}, Int64, Cint, UInt64, Int64, Cint, Ptr{Float64}, Ptr{Int64}, Ptr{Int32}),
+                plan[], Np, Niter, s, 0, addEntropy ? 1 : 0, points, indices, C_NULL))
+  finally
+    ccall((:kdehip_product_destroy, libkdehip), Cvoid, (Ptr{Cvoid},), plan[])
+  end
+  return reshape(points, ndims, Np), indices
+end
+
+"""
+    enable!()
+
+Route `KernelDensityEstimate.gibbs1` -- and with it `prodAppxMSGibbsS`, `*` and every downstream
+caller -- through libkdehip.so.  (Method overwrite; the Julia fallback stays reachable for
+non-Euclidean manifolds because this module calls the original through `invoke_original`.)
+"""
+function enable!()
+  devicecount() > 0 || error("libkdehip: no MI355X visible; refusing to enable (no CPU fallback in the library)")
+  orig = KDE.gibbs1
+  m = first(methods(orig))
+  invoke_original(args...; kw...) = Base.invoke_in_world(m.primary_world, orig, args...; kw...)
+  @eval KDE function gibbs1(Ndens::Int, trees::Array{BallTreeDensity,1}, Np::Int, Niter::Int,
+                            pts::Array{Float64,1}, ind::Array{Int}, randU::Array{Float64,1},
+                            randN::Array{Float64,1}; addop=(+,), diffop=(-,), getMu=(getEuclidMu,),
+                            getLambda=(getEuclidLambda,), glbs=makeEmptyGbGlb(), addEntropy::Bool=true,
+                            ndims::Int=maximum(Ndim.(trees)),
+                            partialDimMask::AbstractVector{<:BitVector}=[ones(Int, ndims) .== 1 for i in 1:Ndens])
+    if $(isEuclid)(addop, diffop, getMu, getLambda) && !glbs.recordChoosen
+      return $(gibbs1)(Ndens, trees, Np, Niter, pts, ind, randU, randN; addEntropy=addEntropy, ndims=ndims,
+                       partialDimMask=partialDimMask)
+    end
+    return $(invoke_original)(Ndens, trees, Np, Niter, pts, ind, randU, randN; addop=addop, diffop=diffop,
+                              getMu=getMu, getLambda=getLambda, glbs=glbs, addEntropy=addEntropy, ndims=ndims,
+                              partialDimMask=partialDimMask)
+  end
+  nothing
+end
+
+end # module
