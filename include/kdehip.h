@@ -139,6 +139,22 @@ int kdehip_make_density(int64_t D, int64_t N, const double *points, const double
                         int64_t *highest_leaf, int64_t *permutation, double *means,
                         double *bandwidth, double *bandwidthMin, double *bandwidthMax);
 
+/* ---- (5) direct evaluation and automatic bandwidth (the callers either side of the product) ----
+ * kdehip_evaluate: `evaluateDualTree(bd, pos)` / `bd(pos)` with the reference's default
+ * FORCE_EVAL_DIRECT = true (src/DualTree01.jl:130-162, 303-346, 370-446): p_out[q] = density of `bd` at
+ * column q of pos (D x Nq, column-major).  leave_one_out != 0 is the `bd == locations` case
+ * (`makeDualTree(bd, errTol)`, :361-368): pos is ignored, the density is evaluated at its own points
+ * without the self term and divided by (1 - w_q) (:335); p_out has npts entries in the ORIGINAL point
+ * order.  Host buffers, blocking. */
+int kdehip_evaluate(const kdehip_density *bd, const double *pos, int64_t Nq, int leave_one_out,
+                    double *p_out, int device);
+/* kdehip_auto_bandwidth: the bandwidth `kde!(points)` selects (src/KDE01.jl:3-27): per dimension,
+ * `ksize` of the 1-D marginal = golden-section search (tol 1e-2) over the leave-one-out
+ * log-likelihood (src/CrossValidation.jl:15-120).  points: D x N column-major; bw_out: D standard
+ * deviations; nevals (optional): number of likelihood evaluations. */
+int kdehip_auto_bandwidth(int64_t D, int64_t N, const double *points, double *bw_out, int32_t *nevals,
+                          int device);
+
 #ifdef __cplusplus
 }
 #endif

@@ -8,6 +8,7 @@ through the top-level `kdehip` module of this repository.
 from ._lib import KdeHipError, LIB_PATH, lib as _clib  # noqa: F401  (import fails loudly if the .so is missing)
 from .density import (BallTree, BallTreeDensity, Ndim, Npts, density_from_arrays, getBW, getPoints,  # noqa: F401
                       getWeights, kde, kde_b)
+from .bandwidth import auto_bandwidth, evaluateDualTree, kde_auto  # noqa: F401
 from .product import ProductPlan, gibbs1, mul, nlevels, philox_streams, prodAppxMSGibbsS  # noqa: F401
 
 

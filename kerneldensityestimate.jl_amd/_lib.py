@@ -62,6 +62,8 @@ SIGNATURES = {
     "kdehip_product_set_variant": (C.c_int, [C.c_void_p, C.c_int]),
     "kdehip_philox_fill_uniform": (None, [C.c_uint64, C.c_int64, C.c_int64, C.c_int64, f64p]),
     "kdehip_philox_fill_normal": (None, [C.c_uint64, C.c_int64, C.c_int64, C.c_int64, f64p]),
+    "kdehip_evaluate": (C.c_int, [C.POINTER(CDensity), f64p, C.c_int64, C.c_int, f64p, C.c_int]),
+    "kdehip_auto_bandwidth": (C.c_int, [C.c_int64, C.c_int64, f64p, f64p, i32p, C.c_int]),
     "kdehip_make_density": (C.c_int, [C.c_int64, C.c_int64, f64p, f64p, C.c_int64, f64p, f64p, f64p, f64p,
                                       i64p, i64p, i64p, i64p, i64p, f64p, f64p, f64p, f64p]),
 }

@@ -1,0 +1,390 @@
+// evaluate.hip -- direct KDE evaluation and LOOCV bandwidth selection on gfx950.
+//
+// Replaces, for the default configuration of the reference (FORCE_EVAL_DIRECT = true,
+// src/KernelDensityEstimate.jl:54, so `evaluate` always ends in `evalDirect`):
+//   evaluateDualTree(bd, pos) / bd(pos)         src/DualTree01.jl:370-446 -> evaluate :303-346 -> evalDirect :130-162
+//   kde!(points)  (automatic bandwidth)         src/KDE01.jl:3-27 -> ksize, golden, nLOO_LL, src/CrossValidation.jl:15-120
+// The all-pairs Gaussian sum is the GPU part: one lane per query point, source points staged through
+// LDS in chunks and read as broadcasts, partial sums per (source chunk, query) reduced in a fixed order
+// by a second kernel (deterministic, no atomics).  The golden-section search runs on the host and
+// advances the D independent 1-D searches of kde!(points) in lock step, one launch per round.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kdehip_internal.hpp"
+
+namespace kdehip {
+namespace {
+
+constexpr int kEvalThreads = 256;  // queries per block
+constexpr int kEvalChunk = 128;    // source points per block
+
+#define KDEHIP_CHECK(expr)                                                                  \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess)                                                                   \
+      return set_error(KDEHIP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+struct DevBuf {
+  void *p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+  template <typename T> T *as() { return static_cast<T *>(p); }
+};
+
+// One problem of a batch: N source points (tree/leaf order), Nq queries.
+struct EvalProblem {
+  const double *src;   // [N][D]
+  const double *w;     // [N]
+  const double *qry;   // [Nq][D]
+  double *partial;     // [nchunks][Nq]
+  double nhib[KDEHIP_MAX_DIMS];  // -1/(2 bw_k)
+  int64_t N, Nq;
+};
+
+// partial[c][q] = sum_{i in chunk c, (i != q if loo)} w_i exp(-1/2 sum_k (x_qk - c_ik)^2 / bw_k)
+// (the kernel value of distGauss!, src/DualTree01.jl:14-47, with leaf ranges 0 and uniform bandwidth)
+template <int D>
+__global__ __launch_bounds__(kEvalThreads) void eval_partial_kernel(const EvalProblem *__restrict__ problems,
+                                                                    int loo) {
+  __shared__ double sSrc[kEvalChunk * (D + 1)];
+  const EvalProblem pb = problems[blockIdx.z];
+  const int64_t q = static_cast<int64_t>(blockIdx.x) * kEvalThreads + threadIdx.x;
+  const int64_t i0 = static_cast<int64_t>(blockIdx.y) * kEvalChunk;
+  if (i0 >= pb.N || static_cast<int64_t>(blockIdx.x) * kEvalThreads >= pb.Nq) return;  // block-uniform
+  const int cnt = static_cast<int>((pb.N - i0 < kEvalChunk) ? (pb.N - i0) : kEvalChunk);
+  for (int t = threadIdx.x; t < cnt * (D + 1); t += kEvalThreads) {
+    const int i = t / (D + 1), f = t % (D + 1);
+    sSrc[t] = (f < D) ? pb.src[(i0 + i) * D + f] : pb.w[i0 + i];
+  }
+  __syncthreads();
+  if (q >= pb.Nq) return;
+  double x[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) x[k] = pb.qry[q * D + k];
+  double sum = 0.0;
+  for (int i = 0; i < cnt; ++i) {
+    const double *s = sSrc + i * (D + 1);
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      const double d = x[k] - s[k];
+      acc = fma(d * d, pb.nhib[k], acc);
+    }
+    double v = s[D] * exp(acc);
+    if (loo && i0 + i == q) v = 0.0;  // leave-one-out: skip the self term (:141)
+    sum += v;
+  }
+  pb.partial[static_cast<int64_t>(blockIdx.y) * pb.Nq + q] = sum;
+}
+
+struct FinishProblem {
+  const double *partial;   // [nchunks][Nq]
+  const double *w;         // [N] (loo: 1 - w_q)
+  const int64_t *out_idx;  // optional: output position of query q (loo: permutation - 1), or null
+  double *out;
+  double inv_norm;
+  int64_t Nq;
+  int nchunks;
+};
+
+// p[q] = (sum over chunks, in chunk order) / norm [/ (1 - w_q)]   (src/DualTree01.jl:325-340)
+__global__ void eval_finish_kernel(const FinishProblem *__restrict__ problems, int loo) {
+  const FinishProblem pb = problems[blockIdx.y];
+  const int64_t q = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (q >= pb.Nq) return;
+  double s = 0.0;
+  for (int c = 0; c < pb.nchunks; ++c) s += pb.partial[static_cast<int64_t>(c) * pb.Nq + q];
+  double p = s * pb.inv_norm;
+  if (loo) p = p / (1.0 - pb.w[q]);
+  pb.out[pb.out_idx ? pb.out_idx[q] : q] = p;
+}
+
+template <int D>
+void launch_partial(const EvalProblem *d_problems, int nprob, int64_t maxNq, int64_t maxN, int loo,
+                    hipStream_t st) {
+  dim3 grid(static_cast<unsigned>((maxNq + kEvalThreads - 1) / kEvalThreads),
+            static_cast<unsigned>((maxN + kEvalChunk - 1) / kEvalChunk), static_cast<unsigned>(nprob));
+  hipLaunchKernelGGL((eval_partial_kernel<D>), grid, dim3(kEvalThreads), 0, st, d_problems, loo);
+}
+
+int launch_partial_dims(int D, const EvalProblem *d_problems, int nprob, int64_t maxNq, int64_t maxN, int loo,
+                        hipStream_t st) {
+  switch (D) {
+    case 1: launch_partial<1>(d_problems, nprob, maxNq, maxN, loo, st); break;
+    case 2: launch_partial<2>(d_problems, nprob, maxNq, maxN, loo, st); break;
+    case 3: launch_partial<3>(d_problems, nprob, maxNq, maxN, loo, st); break;
+    case 4: launch_partial<4>(d_problems, nprob, maxNq, maxN, loo, st); break;
+    case 5: launch_partial<5>(d_problems, nprob, maxNq, maxN, loo, st); break;
+    case 6: launch_partial<6>(d_problems, nprob, maxNq, maxN, loo, st); break;
+    case 7: launch_partial<7>(d_problems, nprob, maxNq, maxN, loo, st); break;
+    case 8: launch_partial<8>(d_problems, nprob, maxNq, maxN, loo, st); break;
+    default: return set_error(KDEHIP_ERR_UNSUPPORTED, "ndims outside 1..KDEHIP_MAX_DIMS");
+  }
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_error(KDEHIP_ERR_HIP, std::string("eval launch failed: ") + hipGetErrorString(e));
+  return KDEHIP_OK;
+}
+
+int use_device(int device) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+    return set_error(KDEHIP_ERR_NO_DEVICE, "no HIP device available (libkdehip has no CPU fallback by design)");
+  if (device < 0 || device >= n) return set_error(KDEHIP_ERR_ARG, "device ordinal out of range");
+  if (hipSetDevice(device) != hipSuccess) return set_error(KDEHIP_ERR_NO_DEVICE, "hipSetDevice failed");
+  return KDEHIP_OK;
+}
+
+// (2 pi)^(D/2) * prod_k sqrt(bw_k)   (src/DualTree01.jl:325-330)
+double gauss_norm(const double *bw, int D) {
+  double norm = std::pow(2.0 * M_PI, D / 2.0);
+  for (int k = 0; k < D; ++k) norm *= std::sqrt(bw[k]);
+  return norm;
+}
+
+}  // namespace
+}  // namespace kdehip
+
+using namespace kdehip;
+
+extern "C" int kdehip_evaluate(const kdehip_density *bd, const double *pos, int64_t Nq, int leave_one_out,
+                               double *p_out, int device) {
+  if (!bd || !p_out) return set_error(KDEHIP_ERR_ARG, "null argument");
+  const int D = static_cast<int>(bd->ndim);
+  const int64_t N = bd->npts;
+  if (D < 1 || D > KDEHIP_MAX_DIMS) return set_error(KDEHIP_ERR_UNSUPPORTED, "ndims outside 1..KDEHIP_MAX_DIMS");
+  if (N < 1 || !bd->means || !bd->bandwidth || !bd->weights || !bd->permutation)
+    return set_error(KDEHIP_ERR_ARG, "malformed density");
+  if (leave_one_out) Nq = N;
+  else if (!pos || Nq < 0) return set_error(KDEHIP_ERR_ARG, "pos must hold Nq >= 0 points");
+  if (Nq == 0) return KDEHIP_OK;
+  // the reference's evalDirect reads ONE bandwidth vector (bandwidthMin[1..D], BallTreeDensity01.jl:98)
+  const double *leaf_pts = bd->means + N * D;  // leaf centres == leaf means == the points, tree order
+  const double *bw = bd->bandwidth + N * D;
+  for (int64_t i = 0; i < N; ++i)
+    for (int k = 0; k < D; ++k)
+      if (bd->bandwidth[(N + i) * D + k] != bw[k])
+        return set_error(KDEHIP_ERR_UNSUPPORTED, "per-point bandwidths are not supported (the reference's kde! never builds them)");
+  int rc = use_device(device);
+  if (rc != KDEHIP_OK) return rc;
+
+  const int nchunks = static_cast<int>((N + kEvalChunk - 1) / kEvalChunk);
+  DevBuf d_src, d_w, d_q, d_part, d_out, d_idx, d_prob, d_fin;
+  KDEHIP_CHECK(d_src.alloc(sizeof(double) * N * D));
+  KDEHIP_CHECK(d_w.alloc(sizeof(double) * N));
+  KDEHIP_CHECK(d_part.alloc(sizeof(double) * nchunks * Nq));
+  KDEHIP_CHECK(d_out.alloc(sizeof(double) * Nq));
+  KDEHIP_CHECK(d_prob.alloc(sizeof(EvalProblem)));
+  KDEHIP_CHECK(d_fin.alloc(sizeof(FinishProblem)));
+  KDEHIP_CHECK(hipMemcpy(d_src.p, leaf_pts, sizeof(double) * N * D, hipMemcpyHostToDevice));
+  KDEHIP_CHECK(hipMemcpy(d_w.p, bd->weights + N, sizeof(double) * N, hipMemcpyHostToDevice));
+  std::vector<int64_t> idx;
+  if (leave_one_out) {  // p[getIndexOf(locations, j)] (:335): results in the caller's original order
+    idx.resize(N);
+    for (int64_t i = 0; i < N; ++i) idx[i] = bd->permutation[N + i] - 1;
+    KDEHIP_CHECK(d_idx.alloc(sizeof(int64_t) * N));
+    KDEHIP_CHECK(hipMemcpy(d_idx.p, idx.data(), sizeof(int64_t) * N, hipMemcpyHostToDevice));
+  } else {
+    KDEHIP_CHECK(d_q.alloc(sizeof(double) * Nq * D));
+    KDEHIP_CHECK(hipMemcpy(d_q.p, pos, sizeof(double) * Nq * D, hipMemcpyHostToDevice));
+  }
+  EvalProblem pb{};
+  pb.src = d_src.as<double>(); pb.w = d_w.as<double>();
+  pb.qry = leave_one_out ? d_src.as<double>() : d_q.as<double>();
+  pb.partial = d_part.as<double>(); pb.N = N; pb.Nq = Nq;
+  for (int k = 0; k < D; ++k) pb.nhib[k] = -0.5 / bw[k];
+  FinishProblem fp{};
+  fp.partial = d_part.as<double>(); fp.w = d_w.as<double>();
+  fp.out_idx = leave_one_out ? d_idx.as<int64_t>() : nullptr;
+  fp.out = d_out.as<double>(); fp.inv_norm = 1.0 / gauss_norm(bw, D); fp.Nq = Nq; fp.nchunks = nchunks;
+  KDEHIP_CHECK(hipMemcpy(d_prob.p, &pb, sizeof(pb), hipMemcpyHostToDevice));
+  KDEHIP_CHECK(hipMemcpy(d_fin.p, &fp, sizeof(fp), hipMemcpyHostToDevice));
+  rc = launch_partial_dims(D, d_prob.as<EvalProblem>(), 1, Nq, N, leave_one_out ? 1 : 0, nullptr);
+  if (rc != KDEHIP_OK) return rc;
+  hipLaunchKernelGGL(eval_finish_kernel, dim3(static_cast<unsigned>((Nq + 255) / 256), 1), dim3(256), 0, nullptr,
+                     d_fin.as<FinishProblem>(), leave_one_out ? 1 : 0);
+  KDEHIP_CHECK(hipGetLastError());
+  KDEHIP_CHECK(hipDeviceSynchronize());
+  KDEHIP_CHECK(hipMemcpy(p_out, d_out.p, sizeof(double) * Nq, hipMemcpyDeviceToHost));
+  return KDEHIP_OK;
+}
+
+// ---- kde!(points): per-dimension LOOCV bandwidth ------------------------------------------------------
+
+namespace {
+
+// Host state of one 1-D golden-section search (golden, src/CrossValidation.jl:44-98).
+struct Golden {
+  double x0, x1, x2, x3, f1, f2;
+  double minm, maxm;
+  double bcur;        // current leaf variance of the search density (drifts like the reference's (b*a)/a)
+  int phase;          // 0: needs f1, 1: needs f2, 2: iterating, 3: done
+  int pending;        // which of f1/f2 the evaluation in flight fills (1 or 2)
+  double alpha;       // argument of the evaluation in flight
+  int nevals;
+  double result;
+};
+
+}  // namespace
+
+extern "C" int kdehip_auto_bandwidth(int64_t D64, int64_t N, const double *points, double *bw_out,
+                                     int32_t *nevals_out, int device) {
+  if (!points || !bw_out) return set_error(KDEHIP_ERR_ARG, "null argument");
+  if (D64 < 1 || D64 > KDEHIP_MAX_DIMS) return set_error(KDEHIP_ERR_UNSUPPORTED, "ndims outside 1..KDEHIP_MAX_DIMS");
+  if (N < 2) return set_error(KDEHIP_ERR_ARG, "kde!(points) needs at least two points");
+  const int D = static_cast<int>(D64);
+  int rc = use_device(device);
+  if (rc != KDEHIP_OK) return rc;
+
+  // Per dimension d: marginal(p,[d]) with unit bandwidth (src/KDE01.jl:13,19,143-153) -> its tree gives
+  // neighborMinMax (src/CrossValidation.jl:100-108); the search density is kde!(x_d, (minm+maxm)/2).
+  std::vector<Golden> g(D);
+  std::vector<double> leaf_x(static_cast<size_t>(D) * N), leaf_w(static_cast<size_t>(D) * N);
+  std::vector<int64_t> leaf_idx(static_cast<size_t>(D) * N);
+  std::vector<double> W(static_cast<size_t>(D) * N);  // weights in original order (getWeights)
+  {
+    std::vector<double> x(N), centers(2 * N), ranges(2 * N), weights(2 * N), means(2 * N), bw(2 * N), bmin(N), bmax(N);
+    std::vector<int64_t> lc(2 * N), rcv(2 * N), lo(2 * N), hi(2 * N), perm(2 * N);
+    for (int d = 0; d < D; ++d) {
+      for (int64_t i = 0; i < N; ++i) x[i] = points[i * D + d];
+      const double one = 1.0;
+      rc = kdehip_make_density(1, N, x.data(), &one, 1, nullptr, centers.data(), ranges.data(), weights.data(),
+                               lc.data(), rcv.data(), lo.data(), hi.data(), perm.data(), means.data(), bw.data(),
+                               bmin.data(), bmax.data());
+      if (rc != KDEHIP_OK) return rc;
+      double maxm = std::sqrt((2.0 * ranges[0]) * (2.0 * ranges[0]));
+      double minm = INFINITY;
+      for (int64_t i = 0; i < N - 1; ++i) {
+        const double v = std::sqrt((2.0 * ranges[i]) * (2.0 * ranges[i]));
+        if (v < minm) minm = v;
+      }
+      if (minm < 1e-6) minm = 1e-6;
+      // getPoints / getWeights of the marginal (original order), then the search density
+      std::vector<double> xo(N), wo(N);
+      for (int64_t j = N; j < 2 * N; ++j) { xo[perm[j] - 1] = centers[j]; wo[perm[j] - 1] = weights[j]; }
+      const double mid = (minm + maxm) / 2.0;
+      rc = kdehip_make_density(1, N, xo.data(), &mid, 1, wo.data(), centers.data(), ranges.data(), weights.data(),
+                               lc.data(), rcv.data(), lo.data(), hi.data(), perm.data(), means.data(), bw.data(),
+                               bmin.data(), bmax.data());
+      if (rc != KDEHIP_OK) return rc;
+      for (int64_t i = 0; i < N; ++i) {
+        leaf_x[static_cast<size_t>(d) * N + i] = centers[N + i];
+        leaf_w[static_cast<size_t>(d) * N + i] = weights[N + i];
+        leaf_idx[static_cast<size_t>(d) * N + i] = perm[N + i] - 1;
+        W[static_cast<size_t>(d) * N + (perm[N + i] - 1)] = weights[N + i];
+      }
+      Golden &s = g[d];
+      s.minm = minm; s.maxm = maxm; s.bcur = bw[N];
+      const double ax = 2.0 * minm / (minm + maxm), bx = 1.0, cx = 2.0 * maxm / (minm + maxm);
+      const double C = (3.0 - std::sqrt(5.0)) / 2.0;
+      s.x0 = ax; s.x3 = cx;
+      if (std::fabs(cx - bx) > std::fabs(bx - ax)) { s.x1 = bx; s.x2 = bx + C * (cx - bx); }
+      else { s.x1 = bx - C * (bx - ax); s.x2 = bx; }
+      s.phase = 0; s.nevals = 0; s.pending = 0; s.alpha = 0; s.f1 = s.f2 = 0; s.result = 0;
+    }
+  }
+
+  const int nchunks = static_cast<int>((N + kEvalChunk - 1) / kEvalChunk);
+  DevBuf d_x, d_w, d_idx, d_part, d_out, d_prob, d_fin;
+  KDEHIP_CHECK(d_x.alloc(sizeof(double) * D * N));
+  KDEHIP_CHECK(d_w.alloc(sizeof(double) * D * N));
+  KDEHIP_CHECK(d_idx.alloc(sizeof(int64_t) * D * N));
+  KDEHIP_CHECK(d_part.alloc(sizeof(double) * D * nchunks * N));
+  KDEHIP_CHECK(d_out.alloc(sizeof(double) * D * N));
+  KDEHIP_CHECK(d_prob.alloc(sizeof(EvalProblem) * D));
+  KDEHIP_CHECK(d_fin.alloc(sizeof(FinishProblem) * D));
+  KDEHIP_CHECK(hipMemcpy(d_x.p, leaf_x.data(), sizeof(double) * D * N, hipMemcpyHostToDevice));
+  KDEHIP_CHECK(hipMemcpy(d_w.p, leaf_w.data(), sizeof(double) * D * N, hipMemcpyHostToDevice));
+  KDEHIP_CHECK(hipMemcpy(d_idx.p, leaf_idx.data(), sizeof(int64_t) * D * N, hipMemcpyHostToDevice));
+
+  std::vector<EvalProblem> probs(D);
+  std::vector<FinishProblem> fins(D);
+  std::vector<double> p_host(static_cast<size_t>(D) * N);
+  const double C = (3.0 - std::sqrt(5.0)) / 2.0, R = 1.0 - C;
+  const double tol = 1e-2;  // ksize, src/CrossValidation.jl:116
+
+  for (;;) {
+    // decide what every unfinished search evaluates in this round
+    std::vector<int> active;
+    for (int d = 0; d < D; ++d) {
+      Golden &s = g[d];
+      if (s.phase == 3) continue;
+      if (s.phase == 0) { s.alpha = s.x1; s.pending = 1; }
+      else if (s.phase == 1) { s.alpha = s.x2; s.pending = 2; }
+      else {
+        if (!(std::fabs(s.x3 - s.x0) > tol * (std::fabs(s.x1) + std::fabs(s.x2)))) {
+          s.result = (s.f1 < s.f2) ? s.x1 : s.x2;
+          s.phase = 3;
+          continue;
+        }
+        if (s.f2 < s.f1) { s.x0 = s.x1; s.x1 = s.x2; s.x2 = R * s.x1 + C * s.x3; s.f1 = s.f2; s.alpha = s.x2; s.pending = 2; }
+        else { s.x3 = s.x2; s.x2 = s.x1; s.x1 = R * s.x2 + C * s.x0; s.f2 = s.f1; s.alpha = s.x1; s.pending = 1; }
+      }
+      active.push_back(d);
+    }
+    if (active.empty()) break;
+    // nLOO_LL (src/CrossValidation.jl:15-24): bandwidth *= alpha^2 for the evaluation, /= alpha^2 after
+    const int na = static_cast<int>(active.size());
+    std::vector<double> a2(na), bw_eval(na);
+    for (int a = 0; a < na; ++a) {
+      const int d = active[a];
+      a2[a] = g[d].alpha * g[d].alpha;
+      bw_eval[a] = g[d].bcur * a2[a];
+      EvalProblem &pb = probs[a];
+      std::memset(&pb, 0, sizeof(pb));
+      pb.src = d_x.as<double>() + static_cast<size_t>(d) * N;
+      pb.qry = pb.src;
+      pb.w = d_w.as<double>() + static_cast<size_t>(d) * N;
+      pb.partial = d_part.as<double>() + static_cast<size_t>(d) * nchunks * N;
+      pb.nhib[0] = -0.5 / bw_eval[a];
+      pb.N = N; pb.Nq = N;
+      FinishProblem &fp = fins[a];
+      fp.partial = pb.partial; fp.w = pb.w;
+      fp.out_idx = d_idx.as<int64_t>() + static_cast<size_t>(d) * N;
+      fp.out = d_out.as<double>() + static_cast<size_t>(d) * N;
+      fp.inv_norm = 1.0 / gauss_norm(&bw_eval[a], 1);
+      fp.Nq = N; fp.nchunks = nchunks;
+    }
+    KDEHIP_CHECK(hipMemcpyAsync(d_prob.p, probs.data(), sizeof(EvalProblem) * na, hipMemcpyHostToDevice, nullptr));
+    KDEHIP_CHECK(hipMemcpyAsync(d_fin.p, fins.data(), sizeof(FinishProblem) * na, hipMemcpyHostToDevice, nullptr));
+    rc = launch_partial_dims(1, d_prob.as<EvalProblem>(), na, N, N, 1, nullptr);
+    if (rc != KDEHIP_OK) return rc;
+    hipLaunchKernelGGL(eval_finish_kernel, dim3(static_cast<unsigned>((N + 255) / 256), static_cast<unsigned>(na)),
+                       dim3(256), 0, nullptr, d_fin.as<FinishProblem>(), 1);
+    KDEHIP_CHECK(hipGetLastError());
+    KDEHIP_CHECK(hipMemcpy(p_host.data(), d_out.p, sizeof(double) * D * N, hipMemcpyDeviceToHost));
+    for (int a = 0; a < na; ++a) {
+      const int d = active[a];
+      Golden &s = g[d];
+      // entropy = -evalAvgLogL (src/DualTree01.jl:450-474,505-508): -(log.(L)' * W), original order
+      const double *L = p_host.data() + static_cast<size_t>(d) * N;
+      const double *Wd = W.data() + static_cast<size_t>(d) * N;
+      bool bad = false;
+      for (int64_t q = 0; q < N; ++q) if (L[q] == 0.0 && Wd[q] != 0.0) bad = true;
+      double H;
+      if (bad) H = INFINITY;
+      else {
+        double ll = 0.0;
+        for (int64_t q = 0; q < N; ++q) ll += std::log(L[q] == 0.0 ? 1.0 : L[q]) * Wd[q];
+        H = -ll;
+      }
+      s.bcur = (s.bcur * a2[a]) / a2[a];
+      s.nevals += 1;
+      if (s.pending == 1) s.f1 = H; else s.f2 = H;
+      if (s.phase < 2) s.phase += 1;
+    }
+  }
+  int total = 0;
+  for (int d = 0; d < D; ++d) {
+    double ks = g[d].result * (g[d].minm + g[d].maxm) / 2.0;  // ksize, src/CrossValidation.jl:117
+    bw_out[d] = std::sqrt(ks * ks);                            // getBW of kde!(.., [ks]) (src/KDE01.jl:45,118)
+    total += g[d].nevals;
+  }
+  if (nevals_out) *nevals_out = total;
+  return KDEHIP_OK;
+}

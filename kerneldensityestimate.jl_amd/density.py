@@ -32,19 +32,30 @@ class BallTreeDensity:
                              ptr(bt.weights, f64p), ptr(bt.left_child, i64p), ptr(bt.right_child, i64p),
                              ptr(bt.permutation, i64p))
 
+    # `bd(pos)`: evaluate the density at points (reference functor, src/DualTree01.jl:431-446)
+    def __call__(self, pos, lvFlag=False, errTol=1e-3):
+        from .bandwidth import evaluateDualTree
+        return evaluateDualTree(self, pos, lvFlag, errTol)
+
     # `p1 * p2` / `*([p1, p2, ...])`, reference src/MSGibbs01.jl:707-736
     def __mul__(self, other):
         from .product import mul
         return mul([self, other])
 
 
-def kde(points, ks, weights=None) -> BallTreeDensity:
-    """`kde!(points, ks)` / `kde!(points, ks, weights)` (reference src/KDE01.jl:34-84).
+def kde(points, ks=None, weights=None) -> BallTreeDensity:
+    """`kde!(points, ks)` / `kde!(points, ks, weights)` (reference src/KDE01.jl:34-84); with ks=None the
+    automatic LOOCV bandwidth `kde!(points)` (src/KDE01.jl:3-27, GPU).
 
     points: (D, N) array, or a length-N vector for 1-D data (:78-84).  ks: bandwidth as STANDARD
     DEVIATION, one entry (repeated over dimensions, :41-43) or D entries.  weights: N values,
     normalised to sum 1 (:46); default ones (:67).
     """
+    if ks is None:
+        if weights is not None:
+            raise ValueError("kde!(points) with automatic bandwidth takes no weights")
+        from .bandwidth import kde_auto
+        return kde_auto(points)
     pts = np.asarray(points, dtype=np.float64)
     if pts.ndim == 1:
         pts = pts.reshape(1, -1)

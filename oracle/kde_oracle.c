@@ -18,6 +18,8 @@
  * Node ids are the reference's 1-based ids; array element [id-1] stores node `id`.
  * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off, so a*b+c is never fused, as in Julia).
  */
+#define _USE_MATH_DEFINES
+#define _GNU_SOURCE
 #include "kde_oracle.h"
 
 #include <math.h>
@@ -525,4 +527,202 @@ int okde_gibbs1_omp(int Ndens, const okde_tree *trees, int64_t Np, int Niter, do
     }
   }
   return rc_all;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Direct KDE evaluation and LOOCV bandwidth selection
+ * ---------------------------------------------------------------------------------------------- */
+
+/* One kernel value as evalDirect computes it (src/DualTree01.jl:130-162 -> maxDistKer! ->
+ * distGauss! :14-47 with minmaxFnc = bwMin, leaf ranges = 0, uniform bandwidth):
+ * exp(-0.5 * sum_k |x_k - c_k|^2 / bw_k), bw = bandwidthMin[1..D] = the first leaf's variances. */
+static double direct_kernel(const double *x, const double *c, const double *bw, int D) {
+  double acc = 0.0;
+  for (int k = 0; k < D; ++k) {
+    double t = fabs(x[k] - c[k]);
+    acc += (t * t) / bw[k];
+  }
+  return exp(-0.5 * acc);
+}
+
+/* evaluate(bd, locations, p, maxErr) with FORCE_EVAL_DIRECT = true (src/DualTree01.jl:303-346):
+ * p[q] = sum_i w_i K(x_q, c_i) / norm, norm = (2 pi)^(D/2) * prod_k sqrt(bw_k) (:325-330).
+ * loo != 0: the query points ARE the density's own points in ORIGINAL order (pos may be NULL);
+ * the self term is skipped (:141) and the result divided by (1 - w_q) (:335). */
+int okde_eval_direct(const okde_tree *bd, const double *pos, int64_t Nq, int loo, double *p) {
+  const int D = (int)bd->ndim;
+  const int64_t N = bd->npts;
+  if (D < 1 || D > 64 || N < 1) return OKDE_ERR_ARG;
+  const double *bw = bd->bandwidth + (size_t)N * D; /* bandwidthMin[1..D], src/BallTreeDensity01.jl:98,214 */
+  double norm = pow(2.0 * M_PI, D / 2.0);
+  for (int k = 0; k < D; ++k) norm *= sqrt(bw[k]);
+  if (loo) {
+    for (int64_t j = N + 1; j <= 2 * N; ++j) { /* locations in tree (leaf) order */
+      const double *x = bd->means + (size_t)(j - 1) * D;
+      double s = 0.0;
+      for (int64_t i = N + 1; i <= 2 * N; ++i) {
+        if (i == j) continue;
+        s += direct_kernel(x, bd->means + (size_t)(i - 1) * D, bw, D) * bd->weights[i - 1];
+      }
+      p[bd->permutation[j - 1] - 1] = 0.5 * (s + s) / norm / (1.0 - bd->weights[j - 1]);
+    }
+    return 0;
+  }
+  for (int64_t q = 0; q < Nq; ++q) {
+    const double *x = pos + (size_t)q * D;
+    double s = 0.0;
+    for (int64_t i = N + 1; i <= 2 * N; ++i)
+      s += direct_kernel(x, bd->means + (size_t)(i - 1) * D, bw, D) * bd->weights[i - 1];
+    p[q] = 0.5 * (s + s) / norm;
+  }
+  return 0;
+}
+
+/* A private, mutable copy of a 1-D (or D-dim) density used by the bandwidth search. */
+typedef struct {
+  int64_t D, N;
+  double *centers, *ranges, *weights, *means, *bw, *bwMin, *bwMax;
+  int64_t *left, *right, *lo, *hi, *perm;
+} okde_owned;
+
+static void owned_free(okde_owned *o) {
+  free(o->centers); free(o->ranges); free(o->weights); free(o->means); free(o->bw); free(o->bwMin);
+  free(o->bwMax); free(o->left); free(o->right); free(o->lo); free(o->hi); free(o->perm);
+}
+static int owned_make(okde_owned *o, int64_t D, int64_t N, const double *pts, const double *ks, int64_t nks,
+                      const double *w) {
+  memset(o, 0, sizeof(*o));
+  o->D = D; o->N = N;
+  size_t nd = (size_t)(2 * N * D), n2 = (size_t)(2 * N);
+  o->centers = (double *)malloc(nd * sizeof(double)); o->ranges = (double *)malloc(nd * sizeof(double));
+  o->means = (double *)malloc(nd * sizeof(double)); o->bw = (double *)malloc(nd * sizeof(double));
+  o->weights = (double *)malloc(n2 * sizeof(double));
+  o->bwMin = (double *)malloc((size_t)(N * D) * sizeof(double)); o->bwMax = (double *)malloc((size_t)(N * D) * sizeof(double));
+  o->left = (int64_t *)malloc(n2 * sizeof(int64_t)); o->right = (int64_t *)malloc(n2 * sizeof(int64_t));
+  o->lo = (int64_t *)malloc(n2 * sizeof(int64_t)); o->hi = (int64_t *)malloc(n2 * sizeof(int64_t));
+  o->perm = (int64_t *)malloc(n2 * sizeof(int64_t));
+  if (!o->centers || !o->ranges || !o->means || !o->bw || !o->weights || !o->bwMin || !o->bwMax || !o->left ||
+      !o->right || !o->lo || !o->hi || !o->perm)
+    return OKDE_ERR_ALLOC;
+  return okde_make_density(D, N, pts, ks, nks, w, o->centers, o->ranges, o->weights, o->left, o->right, o->lo,
+                           o->hi, o->perm, o->means, o->bw, o->bwMin, o->bwMax);
+}
+static okde_tree owned_view(const okde_owned *o) {
+  okde_tree t;
+  t.npts = o->N; t.ndim = o->D; t.means = o->means; t.bandwidth = o->bw; t.weights = o->weights;
+  t.left_child = o->left; t.right_child = o->right; t.permutation = o->perm;
+  return t;
+}
+
+/* entropy(bd) = -evalAvgLogL(bd, bd) (src/DualTree01.jl:450-474,505-508) with the leave-one-out
+ * evaluation above; weights in original order (getWeights, src/KDE01.jl:127-136). */
+static double loo_entropy(const okde_owned *o, double *scratch_p) {
+  okde_tree t = owned_view(o);
+  okde_eval_direct(&t, NULL, 0, 1, scratch_p);
+  const int64_t N = o->N;
+  /* W[perm] = weights[leaf]; any zero likelihood carrying weight -> -Inf */
+  double ll = 0.0;
+  int bad = 0;
+  for (int64_t j = N + 1; j <= 2 * N; ++j) {
+    int64_t q = o->perm[j - 1] - 1;
+    if (scratch_p[q] == 0.0 && o->weights[j - 1] != 0.0) bad = 1;
+  }
+  if (bad) return INFINITY; /* H = -(-Inf) */
+  /* (log.(L)')*W in original order */
+  double *W = (double *)malloc((size_t)N * sizeof(double));
+  for (int64_t j = N + 1; j <= 2 * N; ++j) W[o->perm[j - 1] - 1] = o->weights[j - 1];
+  for (int64_t q = 0; q < N; ++q) {
+    double L = scratch_p[q];
+    if (L == 0.0) L = 1.0;
+    ll += log(L) * W[q];
+  }
+  free(W);
+  return -ll;
+}
+
+/* nLOO_LL (src/CrossValidation.jl:15-24): bandwidth *= alpha^2 (whole array, updateBandwidth! :5-12),
+ * H = entropy, bandwidth /= alpha^2 -- the rounding drift of (b*a)/a is the reference's. */
+static double nloo_ll(double alpha, okde_owned *o, double *scratch_p) {
+  alpha = alpha * alpha;
+  size_t nd = (size_t)(2 * o->N * o->D);
+  for (size_t i = 0; i < nd; ++i) o->bw[i] = o->bw[i] * alpha;
+  double H = loo_entropy(o, scratch_p);
+  for (size_t i = 0; i < nd; ++i) o->bw[i] = o->bw[i] / alpha;
+  return H;
+}
+
+/* golden (src/CrossValidation.jl:44-98) */
+static double golden_search(okde_owned *o, double ax, double bx, double cx, double tol, double *scratch_p,
+                            int *nevals) {
+  const double C = (3.0 - sqrt(5.0)) / 2.0, R = 1.0 - C;
+  double x0 = ax, x3 = cx, x1, x2;
+  if (fabs(cx - bx) > fabs(bx - ax)) { x1 = bx; x2 = bx + C * (cx - bx); }
+  else { x1 = bx - C * (bx - ax); x2 = bx; }
+  double f1 = nloo_ll(x1, o, scratch_p), f2 = nloo_ll(x2, o, scratch_p);
+  int k = 2;
+  while (fabs(x3 - x0) > tol * (fabs(x1) + fabs(x2))) {
+    if (f2 < f1) {
+      x0 = x1; x1 = x2; x2 = R * x1 + C * x3; f1 = f2; f2 = nloo_ll(x2, o, scratch_p);
+    } else {
+      x3 = x2; x2 = x1; x1 = R * x2 + C * x0; f2 = f1; f1 = nloo_ll(x1, o, scratch_p);
+    }
+    ++k;
+  }
+  if (nevals) *nevals = k;
+  return (f1 < f2) ? x1 : x2;
+}
+
+/* ksize (src/CrossValidation.jl:110-120) of a 1-D marginal with unit bandwidth, incl. neighborMinMax
+ * (:100-108).  Returns the selected standard deviation. */
+static int ksize_1d(int64_t N, const double *x, const double *w, double *ks_out, int *nevals) {
+  okde_owned m;
+  const double one = 1.0;
+  int rc = owned_make(&m, 1, N, x, &one, 1, w); /* marginal(p,[i]) of p = kde!(points,[1.0]) */
+  if (rc) { owned_free(&m); return rc; }
+  /* neighborMinMax: ranges of nodes 1..N (first half), D = 1 */
+  double maxm = sqrt((2.0 * m.ranges[0]) * (2.0 * m.ranges[0]));
+  double minm = INFINITY;
+  for (int64_t i = 0; i < N - 1; ++i) {
+    double v = sqrt((2.0 * m.ranges[i]) * (2.0 * m.ranges[i]));
+    if (v < minm) minm = v;
+  }
+  if (N - 1 < 1) minm = maxm; /* degenerate: a single point has no internal node below the root */
+  if (minm < 1e-6) minm = 1e-6;
+  /* getPoints / getWeights in original order */
+  double *xo = (double *)malloc((size_t)N * sizeof(double)), *wo = (double *)malloc((size_t)N * sizeof(double));
+  for (int64_t j = N + 1; j <= 2 * N; ++j) {
+    xo[m.perm[j - 1] - 1] = m.centers[j - 1];
+    wo[m.perm[j - 1] - 1] = m.weights[j - 1];
+  }
+  owned_free(&m);
+  okde_owned p;
+  const double mid = (minm + maxm) / 2.0;
+  rc = owned_make(&p, 1, N, xo, &mid, 1, wo);
+  if (rc) { owned_free(&p); free(xo); free(wo); return rc; }
+  double *scratch = (double *)malloc((size_t)N * sizeof(double));
+  double ks = golden_search(&p, 2.0 * minm / (minm + maxm), 1.0, 2.0 * maxm / (minm + maxm), 1e-2, scratch, nevals);
+  ks = ks * (minm + maxm) / 2.0;
+  /* npd = kde!(..., [ks], ...); getBW(npd)[1] = sqrt(ks^2) (src/KDE01.jl:45,118) */
+  *ks_out = sqrt(ks * ks);
+  free(scratch); free(xo); free(wo);
+  owned_free(&p);
+  return 0;
+}
+
+/* kde!(points) automatic bandwidth (src/KDE01.jl:3-27): per dimension, ksize of the 1-D marginal. */
+int okde_auto_bandwidth(int64_t D, int64_t N, const double *points, double *bw_out, int *nevals_total) {
+  if (D < 1 || N < 2) return OKDE_ERR_ARG;
+  double *x = (double *)malloc((size_t)N * sizeof(double));
+  if (!x) return OKDE_ERR_ALLOC;
+  int total = 0;
+  for (int64_t d = 0; d < D; ++d) {
+    for (int64_t i = 0; i < N; ++i) x[i] = points[i * D + d];
+    int ne = 0;
+    int rc = ksize_1d(N, x, NULL, &bw_out[d], &ne);
+    if (rc) { free(x); return rc; }
+    total += ne;
+  }
+  if (nevals_total) *nevals_total = total;
+  free(x);
+  return 0;
 }

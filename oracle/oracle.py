@@ -62,6 +62,10 @@ def lib():
         L.okde_gibbs1_omp.restype = C.c_int
         L.okde_gibbs1_omp.argtypes = [C.c_int, C.POINTER(_Tree), C.c_int64, C.c_int, _f64p, _i64p, _f64p,
                                       C.c_int64, _f64p, C.c_int64, C.c_int, C.c_int, _u8p, C.c_int]
+        L.okde_eval_direct.restype = C.c_int
+        L.okde_eval_direct.argtypes = [C.POINTER(_Tree), _f64p, C.c_int64, C.c_int, _f64p]
+        L.okde_auto_bandwidth.restype = C.c_int
+        L.okde_auto_bandwidth.argtypes = [C.c_int64, C.c_int64, _f64p, _f64p, C.POINTER(C.c_int)]
         _LIB = L
     return _LIB
 
@@ -174,3 +178,43 @@ def gibbs1(trees, Np, Niter, randU, randN, addEntropy=True, partialDimMask=None,
         raise IndexError(f"okde_gibbs1 failed rc={rc} (randU/randN too short = Julia BoundsError)")
     out = (pts.reshape(Np, D).T.copy(), ind.reshape(Np, M).T.copy())
     return out + (labels,) if want_labels else out
+
+
+def eval_direct(tree, pos=None, loo=False):
+    """evaluateDualTree with FORCE_EVAL_DIRECT (reference src/DualTree01.jl:130-162,303-346): density of
+    `tree` at pos (D x Nq); loo=True: at its own points (original order), leave-one-out."""
+    t = tree._ctree()
+    if loo:
+        p = np.zeros(tree.num_points)
+        rc = lib().okde_eval_direct(C.byref(t), None, 0, 1, _p(p, _f64p))
+    else:
+        pos = np.asarray(pos, dtype=np.float64)
+        if pos.ndim == 1:
+            pos = pos.reshape(1, -1)
+        flat = np.ascontiguousarray(pos.T).ravel()
+        p = np.zeros(pos.shape[1])
+        rc = lib().okde_eval_direct(C.byref(t), _p(flat, _f64p), pos.shape[1], 0, _p(p, _f64p))
+    if rc != 0:
+        raise ValueError(f"okde_eval_direct rc={rc}")
+    return p
+
+
+def auto_bandwidth(points):
+    """The per-dimension LOOCV bandwidth of kde!(points) (reference src/KDE01.jl:3-27); returns (bw[D], n_evals)."""
+    pts = np.asarray(points, dtype=np.float64)
+    if pts.ndim == 1:
+        pts = pts.reshape(1, -1)
+    D, N = pts.shape
+    flat = np.ascontiguousarray(pts.T).ravel()
+    bw = np.zeros(D)
+    ne = C.c_int(0)
+    rc = lib().okde_auto_bandwidth(D, N, _p(flat, _f64p), _p(bw, _f64p), C.byref(ne))
+    if rc != 0:
+        raise ValueError(f"okde_auto_bandwidth rc={rc}")
+    return bw, ne.value
+
+
+def kde_auto(points):
+    """kde!(points): LOOCV bandwidth, then the explicit-bandwidth constructor (src/KDE01.jl:24)."""
+    bw, _ = auto_bandwidth(points)
+    return OracleDensity(points, bw)

@@ -1,0 +1,104 @@
+"""GPU parity of the callers either side of the product: direct evaluation (`evaluateDualTree`, `bd(pos)`),
+the LOOCV bandwidth of `kde!(points)`, and `*` -- against the oracle, the reference's LOOCV golden and
+the reference's own statistical tests (which build their inputs with `kde!(randn(...))`)."""
+import os
+
+import numpy as np
+import pytest
+
+import kdehip
+from oracle import oracle
+from tests.helpers import parse_mat_print_kde
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("D,N,Nq,weighted", [(1, 100, 33, False), (2, 257, 300, True), (3, 1000, 129, False),
+                                             (6, 2048, 2048, False), (8, 50, 7, True), (1, 2, 1, False)])
+def test_evaluate_direct_parity(D, N, Nq, weighted):
+    rng = np.random.default_rng(10 * D + N)
+    pts = rng.standard_normal((D, N))
+    w = rng.uniform(0.2, 1.0, N) if weighted else None
+    bw = rng.uniform(0.2, 0.6, D)
+    g, o = kdehip.kde(pts, bw, w), oracle.OracleDensity(pts, bw, w)
+    pos = rng.standard_normal((D, Nq)) * 1.5
+    assert np.allclose(kdehip.evaluateDualTree(g, pos), oracle.eval_direct(o, pos), rtol=1e-12, atol=1e-300)
+    assert np.allclose(g(pos), oracle.eval_direct(o, pos), rtol=1e-12, atol=1e-300)          # functor form
+    assert np.allclose(kdehip.evaluateDualTree(g, lvFlag=True), oracle.eval_direct(o, loo=True), rtol=1e-12)
+    assert np.allclose(kdehip.evaluateDualTree(g, g), oracle.eval_direct(o, loo=True), rtol=1e-12)  # bd == pos
+    with pytest.raises(ValueError):
+        kdehip.evaluateDualTree(g, np.zeros((D + 1, 3)))
+
+
+def test_loocv_bandwidth_reproduces_reference_golden(golden_dir):
+    """UnitTest1Dlcv01 (reference test/runtests.jl:104-116) through the GPU path."""
+    from tests.test_host_cpu import _Flat
+    from tests.helpers import check_density_against_golden
+    gold = parse_mat_print_kde(os.path.join(golden_dir, "test1Dlcv100Result.txt"))
+    x = np.loadtxt(os.path.join(golden_dir, "test1Dlcv100.txt")).ravel()
+    d = kdehip.kde(x)  # kde!(x): automatic bandwidth
+    check_density_against_golden(_Flat(d), gold, 1e-4)
+
+
+@pytest.mark.parametrize("D,N", [(1, 100), (2, 300), (3, 64), (6, 2048), (4, 1000)])
+def test_loocv_bandwidth_parity_with_oracle(D, N):
+    rng = np.random.default_rng(100 + D)
+    pts = rng.standard_normal((D, N)) * rng.uniform(0.3, 3.0, size=(D, 1)) + rng.uniform(-2, 2, size=(D, 1))
+    g, nev = kdehip.auto_bandwidth(pts, return_evals=True)
+    o, onev = oracle.auto_bandwidth(pts)
+    assert np.allclose(g, o, rtol=1e-9, atol=0), (g, o)
+    assert nev == onev
+
+
+def _test_prods(rng, D=3, M=6, N=100, n=100, dev=1.0, MCMC=5):
+    """testProds exactly as the reference builds it (test/runtests.jl:167-182): inputs via kde!(randn)."""
+    P = [kdehip.kde(dev * rng.standard_normal((D, N))) for _ in range(M)]
+    dummy = kdehip.kde(rng.standard_normal((D, n)), [1.0])
+    pGM, _ = kdehip.prodAppxMSGibbsS(dummy, P, None, None, Niter=MCMC, seed=int(rng.integers(1 << 60)))
+    assert np.abs(pGM).sum() > 1e-14
+    prodDev = np.sqrt(dev ** (2 * M) / (M * dev ** 2))
+    t1 = np.linalg.norm(pGM.mean(axis=1)) < prodDev
+    return t1 and all(0.66 * prodDev < pGM[i].std(ddof=1) < 1.33 * prodDev for i in range(D))
+
+
+@pytest.mark.parametrize("kw", [dict(D=2, M=2), dict(D=2, M=4), dict(D=2, M=6), dict(D=3, M=6, MCMC=10),
+                                dict(D=4, M=6, n=200, MCMC=10), dict(D=3, M=5, N=300), dict(D=2, M=7, n=300),
+                                dict(D=3, M=2, MCMC=100)])
+def test_reference_range_unit_tests_with_loocv_inputs(kw):
+    """rangeUnitTests (reference test/runtests.jl:184-201): >= 5 of 10 repetitions pass."""
+    rng = np.random.default_rng(77)
+    assert sum(bool(_test_prods(rng, **kw)) for _ in range(10)) >= 5
+
+
+def test_partial_product_reference_test_with_loocv_inputs():
+    """reference test/testPartialProd.jl:8-58, inputs built exactly as there (kde!(pts) bandwidths)."""
+    rng = np.random.default_rng(5)
+    pts1, pts2, pts3 = rng.random((2, 100)) + 10.0, rng.random((2, 100)), rng.random((2, 100)) - 10.0
+    P1, P2, P3 = kdehip.kde(pts1), kdehip.kde(pts2), kdehip.kde(pts3)
+    bw1, bw3 = kdehip.getBW(P1)[:, 0], kdehip.getBW(P3)[:, 0]
+    pts1[1, :] = 9999999.0
+    pts3[0, :] = 9999999.0
+    P1, P3 = kdehip.kde(pts1, bw1), kdehip.kde(pts3, bw3)
+    dummy = kdehip.kde(rng.random((2, 100)))
+    pGM, _ = kdehip.prodAppxMSGibbsS(dummy, [P1, P2, P3], None, None, seed=3,
+                                     partialDimMask=[[True, False], [True, True], [False, True]])
+    assert 80 < int(((0 < pGM[0]) & (pGM[0] < 10)).sum())
+    assert 80 < int(((-10 < pGM[1]) & (pGM[1] < 0)).sum())
+
+
+def test_star_product():
+    """`p * q` and `*([..])` (reference src/MSGibbs01.jl:707-736): Np = round(mean Npts), Niter = 5, kde!(pGM)."""
+    rng = np.random.default_rng(8)
+    p = kdehip.kde(rng.standard_normal((2, 120)) + 1.0)
+    q = kdehip.kde(rng.standard_normal((2, 80)) - 1.0)
+    pq = p * q
+    assert (kdehip.Ndim(pq), kdehip.Npts(pq)) == (2, 100)
+    m = kdehip.getPoints(pq).mean(axis=1)
+    assert np.all(np.abs(m) < 0.6)  # product of N(+1, ~1) and N(-1, ~1) sits near 0
+    r = kdehip.mul([p, q, p], seed=4)
+    assert kdehip.Npts(r) == round((120 + 80 + 120) / 3)
+    with pytest.raises(ValueError, match="same dimension"):
+        kdehip.mul([p, kdehip.kde(rng.standard_normal(50), [0.3])])
+    # hack fix for #70 (:713-716): one density, no entropy -> kde!(its own points)
+    one = kdehip.mul([p], addEntropy=False)
+    assert np.allclose(kdehip.getPoints(one), kdehip.getPoints(p))
