@@ -12,6 +12,7 @@
 #include <cfloat>
 #include <cstdint>
 #include <cstring>
+#include <utility>
 #include <vector>
 
 #include "../../include/kdehip.h"
@@ -20,73 +21,114 @@
 namespace kdehip {
 namespace {
 
+// The reference moves every leaf's payload (centre, mean, bandwidth, weight, permutation) on each
+// quick-select swap.  All of it is a function of "which input point sits in which leaf slot", so
+// this builder permutes only an index array `slot_` (leaf slot -> input point) with the reference's
+// exact swap sequence, materialises the leaves once, and then computes the node statistics in the
+// reference's post-order.  Same arrays, bit for bit, at a fraction of the memory traffic.
 class DensityBuilder {
  public:
-  DensityBuilder(int64_t D, int64_t N, double *centers, double *ranges, double *weights,
-                 int64_t *left, int64_t *right, int64_t *lo, int64_t *hi, int64_t *perm,
+  DensityBuilder(int64_t D, int64_t N, const double *points, double *centers, double *ranges,
+                 double *weights, int64_t *left, int64_t *right, int64_t *lo, int64_t *hi, int64_t *perm,
                  double *means, double *bw)
-      : D_(D), N_(N), centers_(centers), ranges_(ranges), weights_(weights), left_(left),
-        right_(right), lo_(lo), hi_(hi), perm_(perm), means_(means), bw_(bw), next_id_(2) {}
+      : D_(D), N_(N), pts_(points), centers_(centers), ranges_(ranges), weights_(weights), left_(left),
+        right_(right), lo_(lo), hi_(hi), perm_(perm), means_(means), bw_(bw), next_id_(2) {
+    slot_.resize(static_cast<size_t>(N));
+    for (int64_t i = 0; i < N; ++i) slot_[static_cast<size_t>(i)] = i;  // buildTree!, :419-429
+    post_order_.reserve(static_cast<size_t>(N));
+    acc_.resize(static_cast<size_t>(2 * D));
+  }
 
-  void build() { build_node(N_ + 1, 2 * N_, 1); }
+  // wnorm: normalised weight of every input point; var: the D leaf variances
+  void build(const double *wnorm, const double *var) {
+    build_node(N_ + 1, 2 * N_, 1);
+    for (int64_t s = 0; s < N_; ++s) {  // materialise the leaves in their final order
+      const int64_t id = N_ + 1 + s, src = slot_[static_cast<size_t>(s)];
+      weights_[id - 1] = wnorm[src];
+      perm_[id - 1] = src + 1;
+      for (int64_t k = 0; k < D_; ++k) {
+        const double x = pts_[src * D_ + k];
+        centers_[(id - 1) * D_ + k] = x;
+        means_[(id - 1) * D_ + k] = x;
+        bw_[(id - 1) * D_ + k] = var[k];
+      }
+    }
+    for (int64_t id : post_order_) summarize(id);
+    if (N_ == 1) right_[0] = -1;  // single-point density, :358-360
+  }
 
  private:
-  // row pointers of node `id` (1-based)
+  // coordinate k of the point currently in leaf `id` (N+1 .. 2N)
+  double key(int64_t id, int64_t k) const { return pts_[slot_[static_cast<size_t>(id - N_ - 1)] * D_ + k]; }
+  void exchange(int64_t a, int64_t b) {  // swapBall!/swapDensity!, BallTree01.jl:109-138
+    std::swap(slot_[static_cast<size_t>(a - N_ - 1)], slot_[static_cast<size_t>(b - N_ - 1)]);
+  }
   double *ctr(int64_t id) { return centers_ + (id - 1) * D_; }
   double *rng(int64_t id) { return ranges_ + (id - 1) * D_; }
   double *mu(int64_t id) { return means_ + (id - 1) * D_; }
   double *var(int64_t id) { return bw_ + (id - 1) * D_; }
   bool valid(int64_t id) const { return id > 0 && id <= 2 * N_; }  // BallTree01.jl:83
 
-  // Exchange two leaves: weight, permutation, centre (swapBall!, BallTree01.jl:109-138) and
-  // mean, bandwidth (swapDensity!, BallTreeDensity01.jl:112-139; uniform-bandwidth case).
-  void exchange(int64_t a, int64_t b) {
-    if (a == b) return;
-    std::swap(weights_[a - 1], weights_[b - 1]);
-    std::swap(perm_[a - 1], perm_[b - 1]);
-    double *ca = ctr(a), *cb = ctr(b), *ma = mu(a), *mb = mu(b), *va = var(a), *vb = var(b);
-    for (int64_t k = 0; k < D_; ++k) {
-      std::swap(ca[k], cb[k]);
-      std::swap(ma[k], mb[k]);
-      std::swap(va[k], vb[k]);
-    }
-  }
-
   // Dimension of largest spread over leaves first..last (most_spread_coord, BallTree01.jl:142-173).
   // The reference leaves the last leaf out of both sums while scaling by 1/(last-first); ties and
   // the all-equal case resolve to the lowest dimension (strict '>').
   int64_t widest_dim(int64_t first, int64_t last) {
+    // every dimension keeps the reference's own sequential sums; the dimensions are interleaved in
+    // the inner loop only to give the CPU D independent dependency chains over contiguous memory
     const double scale = 1.0 / static_cast<double>(last - first);
+    double *m = acc_.data(), *v = acc_.data() + D_;
+    for (int64_t k = 0; k < D_; ++k) m[k] = v[k] = 0.0;
+    for (int64_t id = first; id < last; ++id) {
+      const double *x = pts_ + slot_[static_cast<size_t>(id - N_ - 1)] * D_;
+      for (int64_t k = 0; k < D_; ++k) m[k] = m[k] + scale * x[k];
+    }
+    for (int64_t id = first; id < last; ++id) {
+      const double *x = pts_ + slot_[static_cast<size_t>(id - N_ - 1)] * D_;
+      for (int64_t k = 0; k < D_; ++k) {
+        const double dlt = x[k] - m[k];
+        v[k] += dlt * dlt;
+      }
+    }
     int64_t best = 0;
     double best_var = 0.0;
-    for (int64_t k = 0; k < D_; ++k) {
-      double m = 0.0;
-      for (int64_t id = first; id < last; ++id) m = m + scale * ctr(id)[k];
-      double v = 0.0;
-      for (int64_t id = first; id < last; ++id) {
-        const double dlt = ctr(id)[k] - m;
-        v += dlt * dlt;
-      }
-      if (v > best_var) { best_var = v; best = k; }
-    }
+    for (int64_t k = 0; k < D_; ++k)
+      if (v[k] > best_var) { best_var = v[k]; best = k; }
     return best;
   }
 
   // Quick-select (select!, BallTree01.jl:223-242): afterwards leaves first..pos are <= those after.
+  // The scan is the reference's single forward pass ("if less than the pivot: ++store, swap(store, i)"),
+  // written branch-free on a contiguous copy of the keys: a not-less element swaps with itself.
   void quick_select(int64_t k, int64_t pos, int64_t first, int64_t last) {
-    while (first < last) {
-      exchange((first + last) / 2, first);  // pivot to the front
-      int64_t store = first;
-      for (int64_t id = first; id <= last; ++id) {
-        // the pivot value is re-read each time: it stays at `first` for the whole scan
-        if (ctr(id)[k] - ctr(first)[k] < 0.0) {
-          ++store;
-          exchange(store, id);
-        }
+    if (first >= last) return;
+    const int64_t base = first;
+    const int64_t n0 = last - first + 1;
+    if (static_cast<int64_t>(keys_.size()) < n0) keys_.resize(static_cast<size_t>(n0));
+    double *kk = keys_.data();                                   // kk[i]  = key of leaf base+i
+    int64_t *sl = slot_.data() + (base - N_ - 1);                // sl[i]  = input point in leaf base+i
+    for (int64_t i = 0; i < n0; ++i) kk[i] = pts_[sl[i] * D_ + k];
+    int64_t lo = 0, hi = n0 - 1;
+    const int64_t p = pos - base;
+    while (lo < hi) {
+      const int64_t r = (lo + base + hi + base) / 2 - base;      // floor((low+high)/2) on 1-based ids
+      std::swap(kk[r], kk[lo]);
+      std::swap(sl[r], sl[lo]);
+      const double pivot = kk[lo];
+      int64_t store = lo;
+      for (int64_t i = lo; i <= hi; ++i) {
+        const bool lt = (kk[i] - pivot < 0.0);
+        store += lt ? 1 : 0;
+        const double ka = kk[store], kb = kk[i];
+        const int64_t sa = sl[store], sb = sl[i];
+        kk[store] = lt ? kb : ka;
+        kk[i] = lt ? ka : kb;
+        sl[store] = lt ? sb : sa;
+        sl[i] = lt ? sa : sb;
       }
-      exchange(first, store);
-      if (store <= pos) first = store + 1;
-      if (store >= pos) last = store - 1;
+      std::swap(kk[lo], kk[store]);
+      std::swap(sl[lo], sl[store]);
+      if (store <= p) lo = store + 1;
+      if (store >= p) hi = store - 1;
     }
   }
 
@@ -119,15 +161,15 @@ class DensityBuilder {
   }
 
   // buildBall!, BallTree01.jl:342-411.  Child ids are handed out (left, then right) before either
-  // subtree is built; a one-leaf side points straight at the leaf.
+  // subtree is built; a one-leaf side points straight at the leaf.  Statistics are deferred: nodes
+  // are recorded in the order the reference computes them (children before parents).
   void build_node(int64_t first, int64_t last, int64_t id) {
     lo_[id - 1] = first;
     hi_[id - 1] = last;
-    if (first == last) {  // single-point density, :351-362
+    if (first == last) {  // single-point density, :351-362 (right child fixed up after the stats)
       left_[id - 1] = first;
       right_[id - 1] = last;
-      summarize(id);
-      right_[id - 1] = -1;
+      post_order_.push_back(id);
       return;
     }
     const int64_t k = widest_dim(first, last);
@@ -139,14 +181,17 @@ class DensityBuilder {
     right_[id - 1] = b;
     if (a != first) build_node(first, mid, a);
     if (b != last) build_node(mid + 1, last, b);
-    summarize(id);
+    post_order_.push_back(id);
   }
 
   const int64_t D_, N_;
+  const double *pts_;
   double *centers_, *ranges_, *weights_;
   int64_t *left_, *right_, *lo_, *hi_, *perm_;
   double *means_, *bw_;
   int64_t next_id_;
+  std::vector<int64_t> slot_, post_order_;
+  std::vector<double> acc_, keys_;
 };
 
 }  // namespace
@@ -180,25 +225,23 @@ extern "C" int kdehip_make_density(int64_t D, int64_t N, const double *points, c
   }
   double total = 0.0;
   for (int64_t i = 0; i < N; ++i) total += weights_in ? weights_in[i] : 1.0;
+  std::vector<double> wnorm(static_cast<size_t>(N)), var(static_cast<size_t>(D));
+  for (int64_t i = 0; i < N; ++i) wnorm[static_cast<size_t>(i)] = (weights_in ? weights_in[i] : 1.0) / total;  // KDE01.jl:46
+  for (int64_t k = 0; k < D; ++k) {
+    const double sd = (nks == 1) ? ks[0] : ks[k];
+    var[static_cast<size_t>(k)] = sd * sd;  // ks.^2, KDE01.jl:45
+  }
   for (int64_t i = 0; i < N; ++i) {
-    const int64_t id = N + 1 + i;  // leaf of input point i (buildTree!, :419-429)
-    weights[id - 1] = (weights_in ? weights_in[i] : 1.0) / total;
+    const int64_t id = N + 1 + i;  // leaf slots (buildTree!, :419-429)
     left_child[id - 1] = lowest_leaf[id - 1] = highest_leaf[id - 1] = id;
     right_child[id - 1] = -1;
-    permutation[id - 1] = i + 1;
     for (int64_t k = 0; k < D; ++k) {
-      const double x = points[i * D + k];
-      const double sd = (nks == 1) ? ks[0] : ks[k];
-      const double v = sd * sd;  // ks.^2, KDE01.jl:45
-      centers[(id - 1) * D + k] = x;
-      means[(id - 1) * D + k] = x;
-      bandwidth[(id - 1) * D + k] = v;
-      bandwidthMin[i * D + k] = v;
-      bandwidthMax[i * D + k] = v;
+      bandwidthMin[i * D + k] = var[static_cast<size_t>(k)];
+      bandwidthMax[i * D + k] = var[static_cast<size_t>(k)];
     }
   }
-  DensityBuilder(D, N, centers, ranges, weights, left_child, right_child, lowest_leaf, highest_leaf,
+  DensityBuilder(D, N, points, centers, ranges, weights, left_child, right_child, lowest_leaf, highest_leaf,
                  permutation, means, bandwidth)
-      .build();
+      .build(wnorm.data(), var.data());
   return KDEHIP_OK;
 }

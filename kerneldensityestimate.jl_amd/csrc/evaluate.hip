@@ -10,6 +10,7 @@
 // advances the D independent 1-D searches of kde!(points) in lock step, one launch per round.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <string>
@@ -103,6 +104,33 @@ __global__ void eval_finish_kernel(const FinishProblem *__restrict__ problems, i
   double p = s * pb.inv_norm;
   if (loo) p = p / (1.0 - pb.w[q]);
   pb.out[pb.out_idx ? pb.out_idx[q] : q] = p;
+}
+
+// Leave-one-out finish fused with the entropy reduction of nLOO_LL: block b of problem y writes
+// hpart[y][b] = sum over its queries of W_q * log(p_q)  (evalAvgLogL, src/DualTree01.jl:450-474;
+// a zero likelihood that carries weight makes the log-likelihood -Inf, :460-463).
+constexpr int kFinishThreads = 256;
+__global__ __launch_bounds__(kFinishThreads) void loo_entropy_kernel(const FinishProblem *__restrict__ problems,
+                                                                   double *__restrict__ hpart, int nblocks) {
+  __shared__ double red[kFinishThreads];
+  const FinishProblem pb = problems[blockIdx.y];
+  const int64_t q = static_cast<int64_t>(blockIdx.x) * kFinishThreads + threadIdx.x;
+  double term = 0.0;
+  if (q < pb.Nq) {
+    double s = 0.0;
+    for (int c = 0; c < pb.nchunks; ++c) s += pb.partial[static_cast<int64_t>(c) * pb.Nq + q];
+    const double w = pb.w[q];
+    const double p = s * pb.inv_norm / (1.0 - w);
+    if (p == 0.0) term = (w != 0.0) ? -INFINITY : 0.0;
+    else term = log(p) * w;
+  }
+  red[threadIdx.x] = term;
+  __syncthreads();
+  for (int off = kFinishThreads / 2; off > 0; off >>= 1) {
+    if (static_cast<int>(threadIdx.x) < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) hpart[blockIdx.y * nblocks + blockIdx.x] = red[0];
 }
 
 template <int D>
@@ -230,6 +258,27 @@ struct Golden {
   double result;
 };
 
+// Bounding interval (centre, half-range) of the 1-D ball-tree node that covers the sorted ranks
+// [a, b], computed bottom-up exactly as calcStatsBall! does (src/BallTree01.jl:282-336): in one
+// dimension the median splits of buildBall! (:371-394) make every node a rank interval, so the
+// tree's `ranges` -- all neighborMinMax needs (src/CrossValidation.jl:100-108) -- follow from a sort.
+// `low`/`high` are the reference's 1-based leaf ids of the interval ends; min2r collects the minimum
+// of sqrt((2*range)^2) over internal nodes.
+void interval_stats(const double *xs, int64_t low, int64_t high, int64_t leaf0, double &centre, double &half,
+                    double &min2r) {
+  if (low == high) { centre = xs[low - leaf0]; half = 0.0; return; }
+  const int64_t split = (low + high) / 2;
+  double cL, rL, cR, rR;
+  interval_stats(xs, low, split, leaf0, cL, rL, min2r);
+  interval_stats(xs, split + 1, high, leaf0, cR, rR, min2r);
+  const double upA = cL + rL, upB = cR + rR, dnA = cL - rL, dnB = cR - rR;
+  const double top = (upA > upB) ? upA : upB, bottom = (dnA < dnB) ? dnA : dnB;
+  half = (top - bottom) / 2.0;
+  centre = bottom + half;
+  const double v = std::sqrt((2.0 * half) * (2.0 * half));
+  if (v < min2r) min2r = v;
+}
+
 }  // namespace
 
 extern "C" int kdehip_auto_bandwidth(int64_t D64, int64_t N, const double *points, double *bw_out,
@@ -241,45 +290,33 @@ extern "C" int kdehip_auto_bandwidth(int64_t D64, int64_t N, const double *point
   int rc = use_device(device);
   if (rc != KDEHIP_OK) return rc;
 
-  // Per dimension d: marginal(p,[d]) with unit bandwidth (src/KDE01.jl:13,19,143-153) -> its tree gives
-  // neighborMinMax (src/CrossValidation.jl:100-108); the search density is kde!(x_d, (minm+maxm)/2).
+  // Per dimension d: the marginal's tree ranges give neighborMinMax; the search density is
+  // kde!(x_d, (minm+maxm)/2) (ksize, src/CrossValidation.jl:110-120).  The GPU evaluates the
+  // leave-one-out likelihood over the points in their ORIGINAL order (the tree order only fixes the
+  // reference's summation order), so no tree is built here.
   std::vector<Golden> g(D);
-  std::vector<double> leaf_x(static_cast<size_t>(D) * N), leaf_w(static_cast<size_t>(D) * N);
-  std::vector<int64_t> leaf_idx(static_cast<size_t>(D) * N);
-  std::vector<double> W(static_cast<size_t>(D) * N);  // weights in original order (getWeights)
+  std::vector<double> xo(static_cast<size_t>(D) * N), wts(static_cast<size_t>(D) * N), xs(N);
   {
-    std::vector<double> x(N), centers(2 * N), ranges(2 * N), weights(2 * N), means(2 * N), bw(2 * N), bmin(N), bmax(N);
-    std::vector<int64_t> lc(2 * N), rcv(2 * N), lo(2 * N), hi(2 * N), perm(2 * N);
+    // weights: ones -> /N (kde!(points,[1.0])) -> renormalised by the marginal's kde! (src/KDE01.jl:46,152)
+    std::vector<double> w0(N), w1(N);
+    for (int64_t i = 0; i < N; ++i) w0[i] = 1.0 / static_cast<double>(N);
+    double t = 0.0;
+    for (int64_t i = 0; i < N; ++i) t += w0[i];
+    for (int64_t i = 0; i < N; ++i) w1[i] = w0[i] / t;
     for (int d = 0; d < D; ++d) {
-      for (int64_t i = 0; i < N; ++i) x[i] = points[i * D + d];
-      const double one = 1.0;
-      rc = kdehip_make_density(1, N, x.data(), &one, 1, nullptr, centers.data(), ranges.data(), weights.data(),
-                               lc.data(), rcv.data(), lo.data(), hi.data(), perm.data(), means.data(), bw.data(),
-                               bmin.data(), bmax.data());
-      if (rc != KDEHIP_OK) return rc;
-      double maxm = std::sqrt((2.0 * ranges[0]) * (2.0 * ranges[0]));
-      double minm = INFINITY;
-      for (int64_t i = 0; i < N - 1; ++i) {
-        const double v = std::sqrt((2.0 * ranges[i]) * (2.0 * ranges[i]));
-        if (v < minm) minm = v;
-      }
-      if (minm < 1e-6) minm = 1e-6;
-      // getPoints / getWeights of the marginal (original order), then the search density
-      std::vector<double> xo(N), wo(N);
-      for (int64_t j = N; j < 2 * N; ++j) { xo[perm[j] - 1] = centers[j]; wo[perm[j] - 1] = weights[j]; }
-      const double mid = (minm + maxm) / 2.0;
-      rc = kdehip_make_density(1, N, xo.data(), &mid, 1, wo.data(), centers.data(), ranges.data(), weights.data(),
-                               lc.data(), rcv.data(), lo.data(), hi.data(), perm.data(), means.data(), bw.data(),
-                               bmin.data(), bmax.data());
-      if (rc != KDEHIP_OK) return rc;
       for (int64_t i = 0; i < N; ++i) {
-        leaf_x[static_cast<size_t>(d) * N + i] = centers[N + i];
-        leaf_w[static_cast<size_t>(d) * N + i] = weights[N + i];
-        leaf_idx[static_cast<size_t>(d) * N + i] = perm[N + i] - 1;
-        W[static_cast<size_t>(d) * N + (perm[N + i] - 1)] = weights[N + i];
+        xo[static_cast<size_t>(d) * N + i] = points[i * D + d];
+        wts[static_cast<size_t>(d) * N + i] = w1[i];
+        xs[i] = points[i * D + d];
       }
+      std::sort(xs.begin(), xs.end());
+      double centre, half, minm = INFINITY;
+      interval_stats(xs.data(), N + 1, 2 * N, N + 1, centre, half, minm);
+      const double maxm = std::sqrt((2.0 * half) * (2.0 * half));  // root
+      if (minm < 1e-6) minm = 1e-6;
       Golden &s = g[d];
-      s.minm = minm; s.maxm = maxm; s.bcur = bw[N];
+      const double mid = (minm + maxm) / 2.0;
+      s.minm = minm; s.maxm = maxm; s.bcur = mid * mid;
       const double ax = 2.0 * minm / (minm + maxm), bx = 1.0, cx = 2.0 * maxm / (minm + maxm);
       const double C = (3.0 - std::sqrt(5.0)) / 2.0;
       s.x0 = ax; s.x3 = cx;
@@ -290,21 +327,20 @@ extern "C" int kdehip_auto_bandwidth(int64_t D64, int64_t N, const double *point
   }
 
   const int nchunks = static_cast<int>((N + kEvalChunk - 1) / kEvalChunk);
-  DevBuf d_x, d_w, d_idx, d_part, d_out, d_prob, d_fin;
+  const int nfb = static_cast<int>((N + kFinishThreads - 1) / kFinishThreads);
+  DevBuf d_x, d_w, d_part, d_prob, d_fin, d_h;
   KDEHIP_CHECK(d_x.alloc(sizeof(double) * D * N));
   KDEHIP_CHECK(d_w.alloc(sizeof(double) * D * N));
-  KDEHIP_CHECK(d_idx.alloc(sizeof(int64_t) * D * N));
   KDEHIP_CHECK(d_part.alloc(sizeof(double) * D * nchunks * N));
-  KDEHIP_CHECK(d_out.alloc(sizeof(double) * D * N));
   KDEHIP_CHECK(d_prob.alloc(sizeof(EvalProblem) * D));
   KDEHIP_CHECK(d_fin.alloc(sizeof(FinishProblem) * D));
-  KDEHIP_CHECK(hipMemcpy(d_x.p, leaf_x.data(), sizeof(double) * D * N, hipMemcpyHostToDevice));
-  KDEHIP_CHECK(hipMemcpy(d_w.p, leaf_w.data(), sizeof(double) * D * N, hipMemcpyHostToDevice));
-  KDEHIP_CHECK(hipMemcpy(d_idx.p, leaf_idx.data(), sizeof(int64_t) * D * N, hipMemcpyHostToDevice));
+  KDEHIP_CHECK(d_h.alloc(sizeof(double) * D * nfb));
+  KDEHIP_CHECK(hipMemcpy(d_x.p, xo.data(), sizeof(double) * D * N, hipMemcpyHostToDevice));
+  KDEHIP_CHECK(hipMemcpy(d_w.p, wts.data(), sizeof(double) * D * N, hipMemcpyHostToDevice));
 
   std::vector<EvalProblem> probs(D);
   std::vector<FinishProblem> fins(D);
-  std::vector<double> p_host(static_cast<size_t>(D) * N);
+  std::vector<double> h_host(static_cast<size_t>(D) * nfb);
   const double C = (3.0 - std::sqrt(5.0)) / 2.0, R = 1.0 - C;
   const double tol = 1e-2;  // ksize, src/CrossValidation.jl:116
 
@@ -344,9 +380,8 @@ extern "C" int kdehip_auto_bandwidth(int64_t D64, int64_t N, const double *point
       pb.nhib[0] = -0.5 / bw_eval[a];
       pb.N = N; pb.Nq = N;
       FinishProblem &fp = fins[a];
+      std::memset(&fp, 0, sizeof(fp));
       fp.partial = pb.partial; fp.w = pb.w;
-      fp.out_idx = d_idx.as<int64_t>() + static_cast<size_t>(d) * N;
-      fp.out = d_out.as<double>() + static_cast<size_t>(d) * N;
       fp.inv_norm = 1.0 / gauss_norm(&bw_eval[a], 1);
       fp.Nq = N; fp.nchunks = nchunks;
     }
@@ -354,25 +389,16 @@ extern "C" int kdehip_auto_bandwidth(int64_t D64, int64_t N, const double *point
     KDEHIP_CHECK(hipMemcpyAsync(d_fin.p, fins.data(), sizeof(FinishProblem) * na, hipMemcpyHostToDevice, nullptr));
     rc = launch_partial_dims(1, d_prob.as<EvalProblem>(), na, N, N, 1, nullptr);
     if (rc != KDEHIP_OK) return rc;
-    hipLaunchKernelGGL(eval_finish_kernel, dim3(static_cast<unsigned>((N + 255) / 256), static_cast<unsigned>(na)),
-                       dim3(256), 0, nullptr, d_fin.as<FinishProblem>(), 1);
+    hipLaunchKernelGGL(loo_entropy_kernel, dim3(static_cast<unsigned>(nfb), static_cast<unsigned>(na)),
+                       dim3(kFinishThreads), 0, nullptr, d_fin.as<FinishProblem>(), d_h.as<double>(), nfb);
     KDEHIP_CHECK(hipGetLastError());
-    KDEHIP_CHECK(hipMemcpy(p_host.data(), d_out.p, sizeof(double) * D * N, hipMemcpyDeviceToHost));
+    KDEHIP_CHECK(hipMemcpy(h_host.data(), d_h.p, sizeof(double) * na * nfb, hipMemcpyDeviceToHost));
     for (int a = 0; a < na; ++a) {
       const int d = active[a];
       Golden &s = g[d];
-      // entropy = -evalAvgLogL (src/DualTree01.jl:450-474,505-508): -(log.(L)' * W), original order
-      const double *L = p_host.data() + static_cast<size_t>(d) * N;
-      const double *Wd = W.data() + static_cast<size_t>(d) * N;
-      bool bad = false;
-      for (int64_t q = 0; q < N; ++q) if (L[q] == 0.0 && Wd[q] != 0.0) bad = true;
-      double H;
-      if (bad) H = INFINITY;
-      else {
-        double ll = 0.0;
-        for (int64_t q = 0; q < N; ++q) ll += std::log(L[q] == 0.0 ? 1.0 : L[q]) * Wd[q];
-        H = -ll;
-      }
+      double ll = 0.0;
+      for (int b = 0; b < nfb; ++b) ll += h_host[static_cast<size_t>(a) * nfb + b];
+      const double H = -ll;  // entropy = -evalAvgLogL (src/DualTree01.jl:505-508); -(-Inf) = +Inf
       s.bcur = (s.bcur * a2[a]) / a2[a];
       s.nevals += 1;
       if (s.pending == 1) s.f1 = H; else s.f2 = H;

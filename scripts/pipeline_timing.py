@@ -1,0 +1,21 @@
+"""End-to-end timing of the `*` pipeline pieces (host tree build, plan creation = pack + upload, Gibbs
+kernel, LOOCV bandwidth of the product, final tree) at the headline shape."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import kdehip, bench
+D, M, N, Nout, Niter, prec, cid = bench.CONFIGS[sys.argv[1] if len(sys.argv) > 1 else "c3"]
+pts, bws = bench.synth_inputs(kdehip, D, M, N, cid)
+def T(f, n=5):
+    f(); t = time.perf_counter()
+    for _ in range(n): r = f()
+    return (time.perf_counter() - t) / n * 1e3, r
+t_tree, trees = T(lambda: [kdehip.kde(p, b) for p, b in zip(pts, bws)])
+t_plan, plan = T(lambda: kdehip.ProductPlan(trees))
+t_samp, (pGM, ind) = T(lambda: plan.sample(Nout, Niter=Niter, seed=1))
+t_bw, bw = T(lambda: kdehip.auto_bandwidth(pGM), 3)
+t_final, _ = T(lambda: kdehip.kde(pGM, bw))
+t_eval, _ = T(lambda: kdehip.evaluateDualTree(trees[0], pGM))
+print(f"{sys.argv[1] if len(sys.argv)>1 else 'c3'}: host trees of {M} inputs {t_tree:.2f} ms | plan (pack+upload) {t_plan:.2f} ms | "
+      f"sample {Nout} chains incl. alloc+D2H {t_samp:.2f} ms | LOOCV bandwidth of pGM ({D}x{Nout}) {t_bw:.2f} ms | "
+      f"final tree {t_final:.2f} ms | evaluate {N}x{Nout} {t_eval:.2f} ms")
