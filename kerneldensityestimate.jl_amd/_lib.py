@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkdehip.so")
+LIB_PATH = os.environ.get("KDEHIP_LIB", os.path.join(_HERE, "libkdehip.so"))  # KDEHIP_LIB: diagnostic builds
 
 f64p = C.POINTER(C.c_double)
 i64p = C.POINTER(C.c_int64)

@@ -83,6 +83,20 @@ __device__ __forceinline__ double exp_nonpos(double x, const double *__restrict_
   return ldexp(fma(t, p, t), ki >> 5);
 }
 
+// 1/x for positive, finite, normal x (the fast paths guarantee that at pack time): hardware
+// reciprocal + two Newton steps, ~half the dependent latency of the IEEE division sequence.
+__device__ __forceinline__ double fast_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  double e = fma(-x, r, 1.0);
+  r = fma(r, e, r);
+  e = fma(-x, r, 1.0);
+  return fma(r, e, r);
+}
+__device__ __forceinline__ float fast_rcp(float x) {
+  float r = __builtin_amdgcn_rcpf(x);
+  return fmaf(r, fmaf(-x, r, 1.0f), r);
+}
+
 template <typename T> struct Num;
 template <> struct Num<double> {
   static __device__ __forceinline__ double exp(double x) { return ::exp(x); }
@@ -106,13 +120,15 @@ template <> struct Num<float> {
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_fetch(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, false);
-  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, false);
+  constexpr bool kBound = (ROW_MASK == 0xF);  // full row mask: bound_ctrl supplies the zeros
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, kBound);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, kBound);
   return __hiloint2double(hi, lo);
 }
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_fetch(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+  constexpr bool kBound = (ROW_MASK == 0xF);
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, kBound));
 }
 
 // Inclusive prefix sum over the 64 lanes of a wavefront with DPP row shifts / row broadcasts
@@ -144,6 +160,18 @@ __device__ __forceinline__ float lane_read(float v, int src) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
 }
 
+// ---- phase stamps (diagnostic build only, -DKDEHIP_STAMPS; never part of the product library) ----
+#ifdef KDEHIP_STAMPS
+__device__ unsigned long long g_stamp_acc[16];
+#define KSTAMP(var) unsigned long long var = __builtin_amdgcn_s_memtime()
+#define KSTAMP_ARGS , stamp_acc, stamp_on
+#define KSTAMP_ADD(slot, t0, t1) do { if (stamp_on) stamp_acc[slot] += (t1) - (t0); } while (0)
+#else
+#define KSTAMP(var) do {} while (0)
+#define KSTAMP_ARGS
+#define KSTAMP_ADD(slot, t0, t1) do {} while (0)
+#endif
+
 // ---- kernel evaluation of one frontier entry -----------------------------------------------------
 // `e` points at (row, field 0, lane) of the entry (LDS or global pointer); field f is at e[f*64].
 
@@ -160,8 +188,9 @@ struct EvalUniform {
       const T dl = e[d * 64] - center[d];
       acc = Num<T>::fma(dl * dl, ninv[d], acc);
     }
-    const T p = (e[D * 64] * scale) * Num<T>::exp_fast(acc, tab);
-    return (p != p) ? T(0) : p;  // suppress NaNs, :302
+    // (no per-entry NaN test: on the fast paths every tile value is finite and positive, so a NaN can
+    // only come from the wave-uniform centre/cov and then hits every entry -- handled on the total)
+    return (e[D * 64] * scale) * Num<T>::exp_fast(acc, tab);
   }
 };
 
@@ -194,8 +223,7 @@ struct EvalFast {
     for (int d = 0; d < D; ++d) num = Num<T>::fma(d2[d], pre[d] * suf[d], num);
     const T r = Num<T>::rsqrt(prod);
     const T q = num * r * r;  // = sum_d delta_d^2 / c_d
-    const T p = (w * r) * Num<T>::exp_fast(T(-0.5) * q, tab);
-    return (p != p) ? T(0) : p;
+    return (w * r) * Num<T>::exp_fast(T(-0.5) * q, tab);
   }
 };
 
@@ -230,18 +258,25 @@ struct EvalGeneric {
 // (selectLabelOnLevel :330-351 applied to the CDF of makeFasterSampleIndex! :318-325).
 // `rows` points at row 0, field 0, lane 0 of the tile (LDS or global pointer type P).
 template <typename T, typename P, typename Eval>
-__device__ __forceinline__ int draw_label(P rows, const LevelDesc &ds, int lane, const Eval &ev, double u) {
+__device__ __forceinline__ int draw_label(P rows, const LevelDesc &ds, int lane, const Eval &ev, double u
+#ifdef KDEHIP_STAMPS
+                                          , unsigned long long *stamp_acc, bool stamp_on
+#endif
+) {
   const int n = ds.n, B = ds.B, F = ds.F;
+  KSTAMP(tp0);
   const int RS = F * 64 + 1;
   // pass 1: private sum over the lane's contiguous entries (every field row is one coalesced read)
   T S = T(0);
   P e = rows + lane;
 #pragma unroll 2
   for (int i = 0; i < B; ++i, e += RS) S += ev(e);
+  KSTAMP(tp1);
+  KSTAMP_ADD(2, tp0, tp1);
   const T incl = wave_inclusive_scan(S);
   const T total = lane_read(incl, 63);
 
-  if (total < Num<T>::tiny_total()) {
+  if (!(total >= Num<T>::tiny_total())) {  // also taken when every weight is NaN (:302 zeroes them all)
     // "stick with selection of others": uniform over the frontier (:311-315); with a zero/NaN
     // last weight the reference's CDF is all-NaN and the last entry is taken.
     const int zl = n - 1;
@@ -259,6 +294,8 @@ __device__ __forceinline__ int draw_label(P rows, const LevelDesc &ds, int lane,
   const int last_lane = (n - 1) / B;
   int lstar = hit ? (__ffsll(hit) - 1) : last_lane;
   if (lstar > last_lane) lstar = last_lane;
+  KSTAMP(tp2);
+  KSTAMP_ADD(3, tp1, tp2);
   if (B == 1) return lstar;
 
   // pass 2: narrow inside the winning lane's block until a single node is left
@@ -288,6 +325,8 @@ __device__ __forceinline__ int draw_label(P rows, const LevelDesc &ds, int lane,
   const T inc3 = wave_inclusive_scan(p2);
   const unsigned long long h3 = __ballot((target <= base + inc3) && (lane < len));
   const int istar = h3 ? (__ffsll(h3) - 1) : (len - 1);
+  KSTAMP(tp3);
+  KSTAMP_ADD(4, tp2, tp3);
   return (r0 + istar) * 64 + lstar;
 }
 
@@ -361,6 +400,10 @@ __global__ __launch_bounds__(kWgWaves * 64) void gibbs_product_kernel(PlanDev pl
   const int dl = lane < D ? lane : D - 1;  // this lane's dimension in the "lanes = dimensions" phases
 
   const int vlev = a.variant % 1000, vflags = a.variant / 1000;  // timing/ablation experiments only
+#ifdef KDEHIP_STAMPS
+  unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  bool stamp_on = false;
+#endif
   uint32_t any_bits = 0;  // dimensions informed by at least one density
   for (int j = 0; j < M; ++j) any_bits |= levels[j * (L + 1)].mask_bits;
 
@@ -371,7 +414,7 @@ __global__ __launch_bounds__(kWgWaves * 64) void gibbs_product_kernel(PlanDev pl
     const T mu = e[dl * 64];
     const T var = ds.uniform_bw ? hdr[dl] : e[(D + dl) * 64];
     const bool on = (ds.mask_bits >> dl) & 1u;
-    const T l = on ? T(1) / var : T(0);
+    const T l = on ? (FAST ? fast_rcp(var) : T(1) / var) : T(0);
     if (lane < D) {
       lam[j * D + dl] = l;
       lmu[j * D + dl] = on ? mu * l : T(0);
@@ -402,7 +445,7 @@ __global__ __launch_bounds__(kWgWaves * 64) void gibbs_product_kernel(PlanDev pl
       ms += (k != skip) ? m1 : T(0);
     }
     const bool on = (info_bits >> dl) & 1u;
-    cov = on ? T(1) / ls : T(0);
+    cov = on ? (FAST ? fast_rcp(ls) : T(1) / ls) : T(0);
     mean = on ? cov * ms : T(0);
   };
 
@@ -416,7 +459,7 @@ __global__ __launch_bounds__(kWgWaves * 64) void gibbs_product_kernel(PlanDev pl
         EvalUniform<T, D> ev;
         ev.tab = sExpTab;
         const T c = hdr[dl] + cov;
-        const T ni = T(-0.5) / c;
+        const T ni = T(-0.5) * fast_rcp(c);
         T Pr = T(1);
 #pragma unroll
         for (int d = 0; d < D; ++d) {
@@ -425,7 +468,7 @@ __global__ __launch_bounds__(kWgWaves * 64) void gibbs_product_kernel(PlanDev pl
           Pr *= lane_read(c, d);
         }
         ev.scale = Num<T>::rsqrt(Pr);
-        return draw_label<T, P>(rows, ds, lane, ev, u);
+        return draw_label<T, P>(rows, ds, lane, ev, u KSTAMP_ARGS);
       }
       EvalFast<T, D> ev;
       ev.tab = sExpTab;
@@ -434,7 +477,7 @@ __global__ __launch_bounds__(kWgWaves * 64) void gibbs_product_kernel(PlanDev pl
         ev.center[d] = lane_read(mean, d);
         ev.cov[d] = lane_read(cov, d);
       }
-      return draw_label<T, P>(rows, ds, lane, ev, u);
+      return draw_label<T, P>(rows, ds, lane, ev, u KSTAMP_ARGS);
     } else {
       EvalGeneric<T, D> ev;
       ev.act = ds.mask_bits & ds.others_bits;
@@ -443,7 +486,7 @@ __global__ __launch_bounds__(kWgWaves * 64) void gibbs_product_kernel(PlanDev pl
         ev.center[d] = lane_read(mean, d);
         ev.cov[d] = lane_read(cov, d);
       }
-      return draw_label<T, P>(rows, ds, lane, ev, u);
+      return draw_label<T, P>(rows, ds, lane, ev, u KSTAMP_ARGS);
     }
   };
 
@@ -451,10 +494,15 @@ __global__ __launch_bounds__(kWgWaves * 64) void gibbs_product_kernel(PlanDev pl
   // after the draw is equivalent to the reference's deferred calcIndices! (:383): within the
   // sampleIndices! pass nothing reads the selected kernels.
   auto step = [&](int j, const LevelDesc &ds, auto hdr, T mean, T cov, double u) {
+    KSTAMP(ts0);
     const int pos = (vflags & 8) ? 0 : draw(ds, hdr, mean, cov, u);
     wave_sync();
+    KSTAMP(ts1);
     if (!(vflags & 2)) set_particle(j, ds, hdr, pos);
     wave_sync();
+    KSTAMP(ts2);
+    KSTAMP_ADD(1, ts0, ts1);  // whole draw (setup + passes + scans)
+    KSTAMP_ADD(5, ts1, ts2);  // set_particle
   };
 
   // init: frontier = {root}, label = root (levelInit!/initIndices!/calcIndices!, :587-589)
@@ -531,8 +579,14 @@ __global__ __launch_bounds__(kWgWaves * 64) void gibbs_product_kernel(PlanDev pl
       const int jn = (j + 1 == M) ? 0 : j + 1;
       ds_next = levels[jn * (L + 1) + l];
       T mean = x, cov = T(0);      // sampleIndices! (:364-385): against the point just drawn
+#ifdef KDEHIP_STAMPS
+      stamp_on = (l == (vflags >> 8)) ;  // stamp only the level selected by the experiment
+#endif
+      KSTAMP(tq0);
       if (t >= M && !(vflags & 4)) product_dim(j, ds.others_bits, mean, cov);  // sampleIndex (:404-429): leave j out
       const double u = next_uniform();
+      KSTAMP(tq1);
+      KSTAMP_ADD(0, tq0, tq1);
       if (mode == kStageGlobal) {
         step(j, ds, data + ds.hdr_off, mean, cov, u);
       } else if (mode == kStageResident) {
@@ -540,7 +594,10 @@ __global__ __launch_bounds__(kWgWaves * 64) void gibbs_product_kernel(PlanDev pl
       } else {
         // tile t has been copied by all wavefronts once everyone passes this barrier; buffer
         // (t+1)&1 was last read in step t-1, which everyone has left -> start the next copy
+        KSTAMP(tb0);
         __syncthreads();
+        KSTAMP(tb1);
+        KSTAMP_ADD(6, tb0, tb1);
         if (t + 1 < nsteps)
           stage_tile(reinterpret_cast<const unsigned char *>(data + ds_next.hdr_off),
                      pool + ((t + 1) & 1) * (kLdsPoolBytes / 2), ds_next.stage_bytes, wave, lane);
@@ -556,6 +613,10 @@ __global__ __launch_bounds__(kWgWaves * 64) void gibbs_product_kernel(PlanDev pl
     }
   }
 
+#ifdef KDEHIP_STAMPS
+  if (blockIdx.x == 3 && wave == 1 && lane == 0)
+    for (int k = 0; k < 8; ++k) g_stamp_acc[k] = stamp_acc[k];
+#endif
   // final labels (:612-616) and final point (:625)
   if (live && lane == 0) {
     for (int k = 0; k < M; ++k) {
@@ -611,3 +672,10 @@ int launch_gibbs(int precision, bool fast, const PlanDev &plan, const RunArgs &a
 }
 
 }  // namespace kdehip
+
+#ifdef KDEHIP_STAMPS
+extern "C" int kdehip_debug_read_stamps(unsigned long long *out) {
+  (void)hipDeviceSynchronize();
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(kdehip::g_stamp_acc), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -5;
+}
+#endif
