@@ -57,6 +57,14 @@ def main():
         out["hbm_bytes_per_launch_raw"] = (fetch_kib + write_kib) * 1024.0
         out["fetch_calibration"] = calib
         out["hbm_bytes_per_launch"] = (fetch_kib * calib + write_kib) * 1024.0
+    # The binding resource is the fp64 VALU pipe, not HBM: share of SIMD-cycles with a VALU instruction
+    # in flight (SQ_ACTIVE_INST_VALU counts quad-cycles summed over waves; 1024 SIMDs; cycles from the
+    # kernel duration at the 2.4 GHz maximum clock, i.e. a lower bound on the utilisation).
+    if "SQ_ACTIVE_INST_VALU" in pmc:
+        simd_cycles = out["avg_ns"] * 1e-9 * 2.4e9 * 1024
+        out["valu_pipe_busy_frac_lower_bound"] = pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / simd_cycles
+        if "SQ_INSTS_VALU" in pmc and "SQ_WAVES" in pmc:
+            out["valu_insts_per_chain"] = pmc["SQ_INSTS_VALU"] / pmc["SQ_WAVES"]
     bench = {}
     try:
         bench = json.loads(open(os.path.join(d, "bench_stats.json")).read().strip().splitlines()[-1])
@@ -84,6 +92,9 @@ def main():
     if "hbm_bytes_per_launch" in out:
         lines += [f"HBM bytes per launch: raw (FETCH_SIZE+WRITE_SIZE)*1024 = {out['hbm_bytes_per_launch_raw']:.4g}; "
                   f"with FETCH_SIZE x {calib} = {out['hbm_bytes_per_launch']:.4g}", ""]
+    if "valu_pipe_busy_frac_lower_bound" in out:
+        lines += [f"fp64 VALU pipe busy (lower bound, 2.4 GHz): {out['valu_pipe_busy_frac_lower_bound']:.3f}; "
+                  f"VALU instructions per chain: {out.get('valu_insts_per_chain', float('nan')):.0f}", ""]
     lines += [f"bench line under the profiler: {out['bench_line_under_profiler']}", ""]
     with open(os.path.join(ROOT, "profiles", f"{tag}_rocprof_summary.md"), "w") as f:
         f.write("\n".join(lines))
