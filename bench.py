@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--nout", type=int, default=0, help="override chains per GPU (experiments; 0 = the config's)")
     args = ap.parse_args()
 
     import torch
@@ -115,6 +116,8 @@ def main():
     from kdehip.sharded import ShardedProduct
 
     D, M, N, Nout, Niter, prec, cid = CONFIGS[args.config]
+    if args.nout > 0:
+        Nout = args.nout
     workload = f"{args.config}: {D}-D, {M} densities x {N} pts, Nout={Nout}/GPU, Niter={Niter}, fp{prec}"
     pts_all, bw_all = synth_inputs(kdehip, D, M, N, cid)
     trees = [kdehip.kde(p, b) for p, b in zip(pts_all, bw_all)]

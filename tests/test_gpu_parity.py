@@ -288,3 +288,39 @@ def test_committed_known_answer_fixtures(golden_dir, name):
                                        addEntropy=addEntropy)
         assert np.array_equal(i, z["indices"])
         assert np.allclose(p, z[key], rtol=1e-12, atol=1e-12)
+
+
+def test_config4_shape_full_density_size():
+    """BASELINE config 4 shape (3-D, 8 densities x 5000 points, Niter = 10; chains reduced to 24 so the
+    oracle finishes in seconds): frontiers beyond 4096 nodes, tiles too large for LDS (global mode)."""
+    D, M, N, Np, Niter, seed = 3, 8, 5000, 24, 10, 11
+    gp, op = _make_inputs(44, D, M, N)
+    with kdehip.ProductPlan(gp) as plan:
+        assert plan.nlevels == 13 and plan.evals_per_sample(Niter) == 1160720   # BASELINE.md table
+        K, R = plan.randu_per_sample(Niter), plan.randn_per_sample()
+        assert (K, R) == (1152, 42)
+        g = plan.sample(Np, Niter=Niter, seed=seed)
+    u, n = kdehip.philox_streams(seed, 0, Np, K, R)
+    _compare(g, oracle.gibbs1(op, Np, Niter, u, n), tol=1e-11)
+
+
+def test_config5_shape_fp64_parity_and_fp32_agreement():
+    """BASELINE config 5 shape (6-D, 4 x 10000 points, Niter = 20).  The fp64 plan must match the oracle
+    exactly on a few chains; the fp32 plan (the configuration's precision) must pick the same labels for
+    the overwhelming majority of draws and agree in distribution."""
+    D, M, N, Niter, seed = 6, 4, 10000, 20, 5
+    gp, op = _make_inputs(55, D, M, N)
+    with kdehip.ProductPlan(gp, precision=64) as p64, kdehip.ProductPlan(gp, precision=32) as p32:
+        assert p64.nlevels == 14 and p64.evals_per_sample(Niter) == 2216088 and p32.bytes_per_eval == 52
+        K, R = p64.randu_per_sample(Niter), p64.randn_per_sample()
+        assert (K, R) == (1180, 90)
+        ns = 8
+        g = p64.sample(ns, Niter=Niter, seed=seed)
+        u, n = kdehip.philox_streams(seed, 0, ns, K, R)
+        _compare(g, oracle.gibbs1(op, ns, Niter, u, n), tol=1e-11)
+        Np = 1024
+        a, ia = p64.sample(Np, Niter=Niter, seed=seed)
+        b, ib = p32.sample(Np, Niter=Niter, seed=seed)
+    assert (ia != ib).mean() < 0.15
+    sd = a.std(axis=1)
+    assert np.all(np.abs(a.mean(axis=1) - b.mean(axis=1)) < 6.0 / np.sqrt(Np) * sd)
