@@ -334,11 +334,11 @@ __device__ __forceinline__ int draw_label(P rows, const LevelDesc &ds, int lane,
 
 // LDS of one workgroup (ONE object, so the compiler keeps direct-to-LDS loads asynchronous):
 //   [exp table 256 B][per-wave chain state][tile pool kLdsPoolBytes]
-template <typename T, int D>
+template <typename T, int D, int WAVES>
 struct LdsLayout {
   static constexpr int kStatePerWave = (2 * KDEHIP_MAX_DENS * D) * int(sizeof(T)) + KDEHIP_MAX_DENS * int(sizeof(int));
   static constexpr int kStateOff = 256;
-  static constexpr int kPoolOff = (kStateOff + kWgWaves * kStatePerWave + 1023) / 1024 * 1024;
+  static constexpr int kPoolOff = (kStateOff + WAVES * kStatePerWave + 1023) / 1024 * 1024;
   static constexpr int kBytes = kPoolOff + kLdsPoolBytes;
   static_assert(kBytes <= 160 * 1024, "LDS budget of one CU exceeded");
 };
@@ -361,17 +361,18 @@ using GlobalVoidPtr = const __attribute__((address_space(1))) void *;
 
 // Cooperative, asynchronous copy of one tile image (bytes is a multiple of 1 KiB) into the pool:
 // every wavefront issues global_load_lds_dwordx4 for its share of 1-KiB pieces.
+template <int WAVES>
 __device__ __forceinline__ void stage_tile(const unsigned char *__restrict__ src, unsigned char *dst,
                                            int bytes, int wave, int lane) {
   const int pieces = bytes >> 10;
-  for (int c = wave; c < pieces; c += kWgWaves)
+  for (int c = wave; c < pieces; c += WAVES)
     __builtin_amdgcn_global_load_lds((GlobalVoidPtr)(src + (c << 10) + (lane << 4)),
                                      (LdsVoidPtr)(dst + (c << 10)), 16, 0, 0);
 }
 
-template <typename T, int D, bool FAST>
-__global__ __launch_bounds__(kWgWaves * 64) void gibbs_product_kernel(PlanDev plan, RunArgs a) {
-  using Lay = LdsLayout<T, D>;
+template <typename T, int D, bool FAST, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan, RunArgs a) {
+  using Lay = LdsLayout<T, D, WAVES>;
   __shared__ __attribute__((aligned(1024))) unsigned char smem[Lay::kBytes];
 
   double *sExpTab = reinterpret_cast<double *>(smem);
@@ -382,7 +383,7 @@ __global__ __launch_bounds__(kWgWaves * 64) void gibbs_product_kernel(PlanDev pl
   // readfirstlane makes the wave id (and everything derived from it: sample index, RNG counters,
   // descriptor addresses) provably wave-uniform, so it lives in SGPRs / runs on the scalar unit
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
-  int64_t s = static_cast<int64_t>(blockIdx.x) * kWgWaves + wave;
+  int64_t s = static_cast<int64_t>(blockIdx.x) * WAVES + wave;
   // surplus wavefronts of the last workgroup keep taking part in staging and barriers: they replay
   // the last chain and store nothing
   const bool live = s < a.Np;
@@ -562,14 +563,14 @@ __global__ __launch_bounds__(kWgWaves * 64) void gibbs_product_kernel(PlanDev pl
       __syncthreads();  // every wavefront is done reading the previous level's images
       for (int j = 0; j < M; ++j) {
         const LevelDesc ds = levels[j * (L + 1) + l];
-        stage_tile(reinterpret_cast<const unsigned char *>(data + ds.hdr_off), pool + ds.lds_off,
+        stage_tile<WAVES>(reinterpret_cast<const unsigned char *>(data + ds.hdr_off), pool + ds.lds_off,
                    ds.stage_bytes, wave, lane);
       }
       __syncthreads();  // (waits for this wavefront's copies, then for everyone's)
     } else if (mode == kStageStream) {
       __syncthreads();
       const LevelDesc ds0 = levels[l];
-      stage_tile(reinterpret_cast<const unsigned char *>(data + ds0.hdr_off), pool, ds0.stage_bytes, wave, lane);
+      stage_tile<WAVES>(reinterpret_cast<const unsigned char *>(data + ds0.hdr_off), pool, ds0.stage_bytes, wave, lane);
     }
 
     int j = 0;
@@ -599,7 +600,7 @@ __global__ __launch_bounds__(kWgWaves * 64) void gibbs_product_kernel(PlanDev pl
         KSTAMP(tb1);
         KSTAMP_ADD(6, tb0, tb1);
         if (t + 1 < nsteps)
-          stage_tile(reinterpret_cast<const unsigned char *>(data + ds_next.hdr_off),
+          stage_tile<WAVES>(reinterpret_cast<const unsigned char *>(data + ds_next.hdr_off),
                      pool + ((t + 1) & 1) * (kLdsPoolBytes / 2), ds_next.stage_bytes, wave, lane);
         step(j, ds, (LdsPtr<T>)(pool + (t & 1) * (kLdsPoolBytes / 2)), mean, cov, u);
       }
@@ -635,12 +636,23 @@ __global__ __launch_bounds__(kWgWaves * 64) void gibbs_product_kernel(PlanDev pl
 
 // ---- launcher --------------------------------------------------------------------------------------
 
+// Workgroup size: 8 chains per workgroup fill all 256 CUs from 2048 chains on; with >= 4096 chains
+// 16 chains share each staged tile, which doubles the wavefronts per SIMD (2 -> 4) available to hide
+// the per-step dependency chains (the LDS pool admits one workgroup per CU either way).
+template <typename T, int D, bool FAST, int WAVES>
+static int launch_waves(const PlanDev &plan, const RunArgs &args, hipStream_t stream) {
+  const int64_t blocks = (args.Np + WAVES - 1) / WAVES;
+  hipLaunchKernelGGL((gibbs_product_kernel<T, D, FAST, WAVES>), dim3(static_cast<unsigned>(blocks)),
+                     dim3(WAVES * 64), 0, stream, plan, args);
+  return 0;
+}
+
 template <typename T, int D, bool FAST>
 static int launch_one(const PlanDev &plan, const RunArgs &args, hipStream_t stream) {
-  const int64_t blocks = (args.Np + kWgWaves - 1) / kWgWaves;
-  if (blocks <= 0) return KDEHIP_OK;
-  hipLaunchKernelGGL((gibbs_product_kernel<T, D, FAST>), dim3(static_cast<unsigned>(blocks)),
-                     dim3(kWgWaves * 64), 0, stream, plan, args);
+  if (args.Np <= 0) return KDEHIP_OK;
+  const bool wide = (args.variant % 1000 == 16) || (args.variant % 1000 != 8 && args.Np >= 16 * 256);
+  if (wide) launch_waves<T, D, FAST, 16>(plan, args, stream);
+  else launch_waves<T, D, FAST, 8>(plan, args, stream);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess)
     return set_error(KDEHIP_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString(e));

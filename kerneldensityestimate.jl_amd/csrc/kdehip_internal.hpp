@@ -35,8 +35,7 @@ enum StageMode : int32_t {
   kStageResident = 1,  // all densities' tiles of the level fit the LDS pool at once
   kStageStream = 2     // one tile per step, double-buffered in the LDS pool
 };
-constexpr int kWgWaves = 8;                 // wavefronts (= chains) per workgroup
-constexpr int kLdsPoolBytes = 140 * 1024;   // LDS bytes for staged tiles (of 160 KiB per CU)
+constexpr int kLdsPoolBytes = 120 * 1024;   // LDS bytes for staged tiles (of 160 KiB per CU; the rest: chain state)
 
 struct LevelDesc {
   int32_t n;            // frontier size n_{j,l}

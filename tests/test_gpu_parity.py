@@ -324,3 +324,19 @@ def test_config5_shape_fp64_parity_and_fp32_agreement():
     assert (ia != ib).mean() < 0.15
     sd = a.std(axis=1)
     assert np.all(np.abs(a.mean(axis=1) - b.mean(axis=1)) < 6.0 / np.sqrt(Np) * sd)
+
+
+@pytest.mark.parametrize("variant", [8, 16, 1])
+def test_workgroup_width_variants_give_identical_results(variant):
+    """8 or 16 chains per workgroup, and the all-global-memory staging mode, are scheduling choices only."""
+    D, M, N, Np, Niter, seed = 6, 4, 1000, 100, 3, 9
+    gp, op = _make_inputs(66, D, M, N)
+    with kdehip.ProductPlan(gp) as plan:
+        ref = plan.sample(Np, Niter=Niter, seed=seed, want_labels=True)
+        plan.set_variant(variant)
+        got = plan.sample(Np, Niter=Niter, seed=seed, want_labels=True)
+        K, R = plan.randu_per_sample(Niter), plan.randn_per_sample()
+    for a, b in zip(ref, got):
+        assert np.array_equal(a, b)
+    u, n = kdehip.philox_streams(seed, 0, Np, K, R)
+    _compare(got[:2], oracle.gibbs1(op, Np, Niter, u, n), tol=1e-11)
