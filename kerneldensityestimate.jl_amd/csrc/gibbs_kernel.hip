@@ -400,7 +400,14 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan,
   unsigned char *pool = smem + Lay::kPoolOff;
   const int dl = lane < D ? lane : D - 1;  // this lane's dimension in the "lanes = dimensions" phases
 
-  const int vlev = a.variant % 1000, vflags = a.variant / 1000;  // timing/ablation experiments only
+  // variant: 0 default; 1 = read every tile from global memory (no LDS staging); 8 / 16 = workgroup width.
+  // Diagnostic builds (-DKDEHIP_EXPERIMENTS, scripts/) add level cut-offs and ablation flags.
+  const int vlev = a.variant % 1000;
+#ifdef KDEHIP_EXPERIMENTS
+  const int vflags = a.variant / 1000;
+#else
+  constexpr int vflags = 0;
+#endif
 #ifdef KDEHIP_STAMPS
   unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   bool stamp_on = false;
@@ -547,8 +554,11 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan,
   };
 
   const int nsteps = M * (a.Niter + 1);  // per level: M sampleIndices! draws, then Niter sweeps of M
-  // (timing experiments only: variant 100+k stops the anneal after level k)
+#ifdef KDEHIP_EXPERIMENTS
   const int Lrun = (vlev >= 100 && vlev - 100 < L) ? vlev - 100 : L;
+#else
+  const int Lrun = L;
+#endif
   for (int l = 1; l <= Lrun; ++l) {
     // samplePoint! (:440-463): x = mean + sqrt(cov) * randn, all densities included
     T x;

@@ -1,4 +1,4 @@
-"""Ablation timing: kernel time for levels <= k with pieces of a step disabled (variant flags)."""
+"""(needs the diagnostic build, scripts/stamps.sh all) Ablation timing: kernel time for levels <= k with pieces of a step disabled (variant flags)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,4 +1,4 @@
-"""Timing experiment: cumulative kernel time when the anneal stops after level k (variant 100+k)."""
+"""(needs the diagnostic build, scripts/stamps.sh all) Timing experiment: cumulative kernel time when the anneal stops after level k (variant 100+k)."""
 import sys, os, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np

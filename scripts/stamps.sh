@@ -6,9 +6,13 @@ cd $REPO/kerneldensityestimate.jl_amd/csrc
 mkdir -p $REPO/gpurun_out/stamps
 for f in balltree.cpp pack_levels.cpp; do /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off -x hip --offload-arch=gfx950 -c $f -o $REPO/gpurun_out/stamps/$f.o & done
 for f in product.hip evaluate.hip; do /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -c $f -o $REPO/gpurun_out/stamps/$f.o & done
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -DKDEHIP_STAMPS -c gibbs_kernel.hip -o $REPO/gpurun_out/stamps/gibbs_kernel.o &
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -DKDEHIP_STAMPS -DKDEHIP_EXPERIMENTS -c gibbs_kernel.hip -o $REPO/gpurun_out/stamps/gibbs_kernel.o &
 wait
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $REPO/gpurun_out/stamps/libkdehip_stamps.so $REPO/gpurun_out/stamps/*.o
 cd $REPO
 KDEHIP_LIB=$REPO/gpurun_out/stamps/libkdehip_stamps.so python scripts/stamps.py
+if [ "$1" = "all" ]; then
+  KDEHIP_LIB=$REPO/gpurun_out/stamps/libkdehip_stamps.so python scripts/level_timing.py
+  KDEHIP_LIB=$REPO/gpurun_out/stamps/libkdehip_stamps.so python scripts/ablate.py
+fi
 rm -f $REPO/gpurun_out/stamps/*.o $REPO/gpurun_out/stamps/*.so
