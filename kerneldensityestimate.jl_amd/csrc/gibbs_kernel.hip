@@ -257,22 +257,27 @@ struct EvalGeneric {
 // the entry selected by the uniform draw `u`: the first z with u <= cdf[z], else the last
 // (selectLabelOnLevel :330-351 applied to the CDF of makeFasterSampleIndex! :318-325).
 // `rows` points at row 0, field 0, lane 0 of the tile (LDS or global pointer type P).
+// pass 1 over rows held at `rows` (LDS or global): the lane's private sum over its contiguous entries
 template <typename T, typename P, typename Eval>
-__device__ __forceinline__ int draw_label(P rows, const LevelDesc &ds, int lane, const Eval &ev, double u
-#ifdef KDEHIP_STAMPS
-                                          , unsigned long long *stamp_acc, bool stamp_on
-#endif
-) {
-  const int n = ds.n, B = ds.B, F = ds.F;
-  KSTAMP(tp0);
-  const int RS = F * 64 + 1;
-  // pass 1: private sum over the lane's contiguous entries (every field row is one coalesced read)
+__device__ __forceinline__ T lane_sum_rows(P rows, int nrows, int RS, int lane, const Eval &ev) {
   T S = T(0);
   P e = rows + lane;
 #pragma unroll 2
-  for (int i = 0; i < B; ++i, e += RS) S += ev(e);
+  for (int i = 0; i < nrows; ++i, e += RS) S += ev(e);
+  return S;
+}
+
+// Selection from the lane sums S: wavefront scan, winning lane, then pass 2 over the winning lane's
+// block read through `rows` (row 0, field 0, lane 0 of the whole tile; LDS or global).
+template <typename T, typename P, typename Eval>
+__device__ __forceinline__ int select_label(T S, P rows, const LevelDesc &ds, int lane, const Eval &ev, double u
+#ifdef KDEHIP_STAMPS
+                                            , unsigned long long *stamp_acc, bool stamp_on
+#endif
+) {
+  const int n = ds.n, B = ds.B, F = ds.F;
+  const int RS = F * 64 + 1;
   KSTAMP(tp1);
-  KSTAMP_ADD(2, tp0, tp1);
   const T incl = wave_inclusive_scan(S);
   const T total = lane_read(incl, 63);
 
@@ -328,6 +333,20 @@ __device__ __forceinline__ int draw_label(P rows, const LevelDesc &ds, int lane,
   KSTAMP(tp3);
   KSTAMP_ADD(4, tp2, tp3);
   return (r0 + istar) * 64 + lstar;
+}
+
+// whole tile readable through one pointer (resident / streamed LDS image, or global memory)
+template <typename T, typename P, typename Eval>
+__device__ __forceinline__ int draw_label(P rows, const LevelDesc &ds, int lane, const Eval &ev, double u
+#ifdef KDEHIP_STAMPS
+                                          , unsigned long long *stamp_acc, bool stamp_on
+#endif
+) {
+  KSTAMP(tp0);
+  const T S = lane_sum_rows<T, P>(rows, ds.B, ds.F * 64 + 1, lane, ev);
+  KSTAMP(tp1);
+  KSTAMP_ADD(2, tp0, tp1);
+  return select_label<T, P>(S, rows, ds, lane, ev, u KSTAMP_ARGS);
 }
 
 // ---- the sampler ----------------------------------------------------------------------------------
@@ -457,11 +476,10 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan,
     mean = on ? cov * ms : T(0);
   };
 
-  // one label draw of density j on level descriptor ds against the per-dimension (mean, cov)
-  // held by the dimension lanes; `hdr` = tile header (LDS or global pointer)
-  auto draw = [&](const LevelDesc &ds, auto hdr, T mean, T cov, double u) -> int {
-    auto rows = hdr + kTileHeader;
-    using P = decltype(rows);
+  // One label draw of a density on level descriptor ds against the per-dimension (mean, cov) held by
+  // the dimension lanes.  `hdr` = tile header (LDS or global pointer); `run(ev)` evaluates the frontier
+  // with the functor it is handed and returns the selected tile position.
+  auto draw = [&](const LevelDesc &ds, auto hdr, T mean, T cov, auto &&run) -> int {
     if constexpr (FAST) {
       if (ds.uniform_bw) {
         EvalUniform<T, D> ev;
@@ -476,7 +494,7 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan,
           Pr *= lane_read(c, d);
         }
         ev.scale = Num<T>::rsqrt(Pr);
-        return draw_label<T, P>(rows, ds, lane, ev, u KSTAMP_ARGS);
+        return run(ev);
       }
       EvalFast<T, D> ev;
       ev.tab = sExpTab;
@@ -485,7 +503,7 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan,
         ev.center[d] = lane_read(mean, d);
         ev.cov[d] = lane_read(cov, d);
       }
-      return draw_label<T, P>(rows, ds, lane, ev, u KSTAMP_ARGS);
+      return run(ev);
     } else {
       EvalGeneric<T, D> ev;
       ev.act = ds.mask_bits & ds.others_bits;
@@ -494,16 +512,20 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan,
         ev.center[d] = lane_read(mean, d);
         ev.cov[d] = lane_read(cov, d);
       }
-      return draw_label<T, P>(rows, ds, lane, ev, u KSTAMP_ARGS);
+      return run(ev);
     }
   };
 
-  // one (pass, density) step: draw the label and adopt it.  Updating the selected kernel right
-  // after the draw is equivalent to the reference's deferred calcIndices! (:383): within the
-  // sampleIndices! pass nothing reads the selected kernels.
+  // one (pass, density) step on a tile that is readable through one pointer: draw the label and adopt
+  // it.  Updating the selected kernel right after the draw is equivalent to the reference's deferred
+  // calcIndices! (:383): within the sampleIndices! pass nothing reads the selected kernels.
   auto step = [&](int j, const LevelDesc &ds, auto hdr, T mean, T cov, double u) {
     KSTAMP(ts0);
-    const int pos = (vflags & 8) ? 0 : draw(ds, hdr, mean, cov, u);
+    auto rows = hdr + kTileHeader;
+    using P = decltype(rows);
+    const int pos = (vflags & 8) ? 0 : draw(ds, hdr, mean, cov, [&](const auto &ev) {
+      return draw_label<T, P>(rows, ds, lane, ev, u KSTAMP_ARGS);
+    });
     wave_sync();
     KSTAMP(ts1);
     if (!(vflags & 2)) set_particle(j, ds, hdr, pos);
@@ -511,6 +533,42 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan,
     KSTAMP(ts2);
     KSTAMP_ADD(1, ts0, ts1);  // whole draw (setup + passes + scans)
     KSTAMP_ADD(5, ts1, ts2);  // set_particle
+  };
+
+  // Chunked step for tiles larger than half the LDS pool: pass 1 streams the rows through the two
+  // pool halves `rc` rows at a time (copy of chunk g+1 overlaps the evaluation of chunk g, one barrier
+  // per chunk); the short second pass and the new kernel are read from global memory.  `gchunk` is the
+  // workgroup-wide running chunk counter that selects the pool half; the chunk after this tile's last
+  // one is the first chunk of `dn` (the next step's tile), if there is a next step.
+  int gchunk = 0;
+  auto chunk_rows = [&](const LevelDesc &ds) -> int {
+    const int row_bytes = (ds.F * 64 + 1) * int(sizeof(T));
+    return ((kLdsPoolBytes / 2 - 1024) / row_bytes) & ~3;  // multiple of 4 rows: 16-byte aligned chunks
+  };
+  auto stage_chunk = [&](const LevelDesc &ds, int r0, int half) {
+    const int RS = ds.F * 64 + 1, rc = chunk_rows(ds);
+    const int nrows = (ds.B - r0 < rc) ? (ds.B - r0) : rc;
+    const int bytes = (nrows * RS * int(sizeof(T)) + 1023) & ~1023;
+    stage_tile<WAVES>(reinterpret_cast<const unsigned char *>(data + ds.hdr_off + kTileHeader + static_cast<int64_t>(r0) * RS),
+                      pool + half * (kLdsPoolBytes / 2), bytes, wave, lane);
+  };
+  auto step_chunked = [&](int j, const LevelDesc &ds, const LevelDesc &dn, bool has_next, T mean, T cov, double u) {
+    const T *hdr = data + ds.hdr_off;
+    const int pos = draw(ds, hdr, mean, cov, [&](const auto &ev) {
+      const int RS = ds.F * 64 + 1, rc = chunk_rows(ds);
+      T S = T(0);
+      for (int r0 = 0; r0 < ds.B; r0 += rc, ++gchunk) {
+        __syncthreads();  // this chunk has landed for every wavefront; the other half is free again
+        if (r0 + rc < ds.B) stage_chunk(ds, r0 + rc, (gchunk + 1) & 1);
+        else if (has_next) stage_chunk(dn, 0, (gchunk + 1) & 1);
+        const int nrows = (ds.B - r0 < rc) ? (ds.B - r0) : rc;
+        S += lane_sum_rows<T, LdsPtr<T>>((LdsPtr<T>)(pool + (gchunk & 1) * (kLdsPoolBytes / 2)), nrows, RS, lane, ev);
+      }
+      return select_label<T, const T *>(S, hdr + kTileHeader, ds, lane, ev, u KSTAMP_ARGS);
+    });
+    wave_sync();
+    set_particle(j, ds, hdr, pos);
+    wave_sync();
   };
 
   // init: frontier = {root}, label = root (levelInit!/initIndices!/calcIndices!, :587-589)
@@ -581,6 +639,9 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan,
       __syncthreads();
       const LevelDesc ds0 = levels[l];
       stage_tile<WAVES>(reinterpret_cast<const unsigned char *>(data + ds0.hdr_off), pool, ds0.stage_bytes, wave, lane);
+    } else if (mode == kStageChunked) {
+      __syncthreads();
+      stage_chunk(levels[l], 0, gchunk & 1);
     }
 
     int j = 0;
@@ -602,6 +663,8 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan,
         step(j, ds, data + ds.hdr_off, mean, cov, u);
       } else if (mode == kStageResident) {
         step(j, ds, (LdsPtr<T>)(pool + ds.lds_off), mean, cov, u);
+      } else if (mode == kStageChunked) {
+        step_chunked(j, ds, ds_next, t + 1 < nsteps, mean, cov, u);
       } else {
         // tile t has been copied by all wavefronts once everyone passes this barrier; buffer
         // (t+1)&1 was last read in step t-1, which everyone has left -> start the next copy

@@ -33,7 +33,8 @@ constexpr int kTileHeader = 8;
 enum StageMode : int32_t {
   kStageGlobal = 0,    // tile too large for LDS: wavefronts read it from global memory (L1/L2)
   kStageResident = 1,  // all densities' tiles of the level fit the LDS pool at once
-  kStageStream = 2     // one tile per step, double-buffered in the LDS pool
+  kStageStream = 2,    // one tile per step, double-buffered in the LDS pool
+  kStageChunked = 3    // tile larger than half the pool: rows streamed through the two halves in chunks
 };
 constexpr int kLdsPoolBytes = 120 * 1024;   // LDS bytes for staged tiles (of 160 KiB per CU; the rest: chain state)
 

@@ -182,6 +182,7 @@ int pack_levels(int Ndens, const kdehip_density *trees, int ndims, const uint8_t
     if (l == 0) mode = kStageGlobal;  // the roots are read once, straight from memory
     else if (sum <= kLdsPoolBytes) mode = kStageResident;
     else if (mx <= kLdsPoolBytes / 2) mode = kStageStream;
+    else mode = kStageChunked;
     int64_t off = 0;
     for (int j = 0; j < M; ++j) {
       LevelDesc &ds = out.levels[static_cast<size_t>(j) * (L + 1) + l];
