@@ -112,7 +112,11 @@ int pack_levels(int Ndens, const kdehip_density *trees, int ndims, const uint8_t
     if (lo < 1.0) dn *= lo;
   }
   const bool in_range = (precision == 64) ? (up < 1e120 && dn > 1e-120) : (up < 1e15 && dn > 1e-15);
-  out.fast = finite_ok && in_range && !out.masked;
+  // the fast forms evaluate every dimension: they need every dimension of every density to be informed by
+  // some OTHER density too (false for a one-density "product", where the reference weighs by w alone)
+  bool all_active = true;
+  for (int j = 0; j < M; ++j) if ((mask_bits[j] & others_bits[j]) != all) all_active = false;
+  out.fast = finite_ok && in_range && !out.masked && all_active;
 
   // ---- phase 2: write the tiles
   const int64_t esz = (precision == 64) ? 8 : 4;

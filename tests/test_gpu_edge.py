@@ -1,0 +1,95 @@
+"""Edge cases and size-independent properties of the HIP product path at and beyond the BASELINE sizes."""
+import numpy as np
+import pytest
+
+import kdehip
+from oracle import oracle
+from tests.test_gpu_parity import _closed_form_points, _compare, _make_inputs, _pair
+
+pytestmark = pytest.mark.gpu
+
+
+def test_maximum_density_count_and_dimension():
+    """16 densities (KDEHIP_MAX_DENS) in 8 dimensions (KDEHIP_MAX_DIMS)."""
+    D, M, N, Np, Niter = 8, 16, 40, 24, 1
+    gp, op = _make_inputs(5, D, M, N)
+    K, R, nU, nN = oracle.rng_sizes(M, D, Np, Niter, [N] * M)
+    rng = np.random.default_rng(1)
+    randU, randN = rng.random(nU), rng.standard_normal(nN)
+    g = kdehip.prodAppxMSGibbsS(None, gp, None, None, Niter=Niter, Np=Np, randU=randU, randN=randN)
+    _compare(g, oracle.gibbs1(op, Np, Niter, randU, randN))
+
+
+def test_all_single_point_densities_and_single_density_product():
+    a, ao = _pair(np.array([[0.3], [1.0]]), [0.5])
+    b, bo = _pair(np.array([[-0.2], [2.0]]), [0.25])
+    rng = np.random.default_rng(2)
+    Np, Niter = 16, 2
+    K, R, nU, nN = oracle.rng_sizes(2, 2, Np, Niter, [1, 1])
+    randU, randN = rng.random(nU), rng.standard_normal(nN)
+    g = kdehip.prodAppxMSGibbsS(None, [a, b], None, None, Niter=Niter, Np=Np, randU=randU, randN=randN)
+    _compare(g, oracle.gibbs1([ao, bo], Np, Niter, randU, randN))
+    assert np.all(g[1] == 2)  # the only point of each density
+    # a "product" of one density is resampling it
+    c, co = _pair(rng.standard_normal((2, 50)), [0.3])
+    K, R, nU, nN = oracle.rng_sizes(1, 2, Np, Niter, [50])
+    randU, randN = rng.random(nU), rng.standard_normal(nN)
+    g = kdehip.prodAppxMSGibbsS(None, [c], None, None, Niter=Niter, Np=Np, randU=randU, randN=randN)
+    _compare(g, oracle.gibbs1([co], Np, Niter, randU, randN))
+
+
+def test_duplicate_points_and_extreme_weights():
+    rng = np.random.default_rng(3)
+    pts = rng.standard_normal((2, 64))
+    pts[:, 10:30] = pts[:, [5]]                     # 20 identical points (ties in the tree build)
+    w = np.ones(64)
+    w[3], w[40] = 1e-12, 1e3                         # nearly-zero and dominating weights
+    a, ao = _pair(pts, [0.2, 0.4], w)
+    b, bo = _pair(rng.standard_normal((2, 64)) * 0.5, [0.3])
+    Np, Niter = 200, 3
+    K, R, nU, nN = oracle.rng_sizes(2, 2, Np, Niter, [64, 64])
+    randU, randN = rng.random(nU), rng.standard_normal(nN)
+    g = kdehip.prodAppxMSGibbsS(None, [a, b], None, None, Niter=Niter, Np=Np, randU=randU, randN=randN)
+    _compare(g, oracle.gibbs1([ao, bo], Np, Niter, randU, randN))
+
+
+def test_many_chains_properties_and_batch_invariance():
+    """100k chains in one call: label range, closed-form invariant, and equality with the same chains
+    drawn in several smaller calls (Philox keyed by the global sample index)."""
+    D, M, N, Np, Niter, seed = 3, 3, 300, 100_000, 2, 77
+    gp, _ = _make_inputs(9, D, M, N)
+    with kdehip.ProductPlan(gp) as plan:
+        p, i = plan.sample(Np, Niter=Niter, seed=seed, addEntropy=False)
+        parts = [plan.sample(n, Niter=Niter, seed=seed, sample_offset=o, addEntropy=False)
+                 for o, n in ((0, 1), (1, 4095), (4096, 50_000), (54_096, Np - 54_096))]
+    assert i.min() >= 2 and i.max() <= N + 1
+    assert np.allclose(p, _closed_form_points(gp, i), rtol=1e-11, atol=1e-12)
+    assert np.array_equal(np.concatenate([q[0] for q in parts], axis=1), p)
+    assert np.array_equal(np.concatenate([q[1] for q in parts], axis=1), i)
+    # every leaf of every density is reachable
+    assert all(len(np.unique(i[j])) > 0.9 * N for j in range(M))
+
+
+def test_config4_full_batch_properties():
+    """BASELINE config 4 at its full per-GPU batch (2048 chains of the 16384, 8 x 5000 points)."""
+    D, M, N, Np, Niter, seed = 3, 8, 5000, 2048, 10, 4
+    gp, _ = _make_inputs(44, D, M, N)
+    with kdehip.ProductPlan(gp) as plan:
+        pe, ie = plan.sample(Np, Niter=Niter, seed=seed, addEntropy=True)
+        pn, i_n = plan.sample(Np, Niter=Niter, seed=seed, addEntropy=False)
+    assert np.array_equal(ie, i_n) and ie.min() >= 2 and ie.max() <= N + 1
+    assert np.allclose(pn, _closed_form_points(gp, i_n), rtol=1e-11, atol=1e-12)
+    assert np.isfinite(pe).all()
+
+
+def test_zero_chains_and_argument_errors():
+    gp, _ = _make_inputs(1, 2, 2, 20)
+    with kdehip.ProductPlan(gp) as plan:
+        p, i = plan.sample(0)
+        assert p.shape == (2, 0) and i.shape == (2, 0)
+        with pytest.raises(kdehip.KdeHipError):
+            plan.sample(4, Niter=-1)
+    with pytest.raises(kdehip.KdeHipError):
+        kdehip.ProductPlan(gp, precision=16)
+    with pytest.raises(kdehip.KdeHipError):
+        kdehip.ProductPlan(gp, device=99)
