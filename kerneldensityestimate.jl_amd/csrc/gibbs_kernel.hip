@@ -55,7 +55,7 @@ namespace kdehip {
 // ---- small device helpers ------------------------------------------------------------------------
 
 // 2^(j/32), j = 0..31, correctly rounded
-__constant__ double kExp2Tab[32] = {
+static __constant__ double kExp2Tab[32] = {
     0x1.0000000000000p+0, 0x1.059b0d3158574p+0, 0x1.0b5586cf9890fp+0, 0x1.11301d0125b51p+0,
     0x1.172b83c7d517bp+0, 0x1.1d4873168b9aap+0, 0x1.2387a6e756238p+0, 0x1.29e9df51fdee1p+0,
     0x1.306fe0a31b715p+0, 0x1.371a7373aa9cbp+0, 0x1.3dea64c123422p+0, 0x1.44e086061892dp+0,
@@ -162,7 +162,7 @@ __device__ __forceinline__ float lane_read(float v, int src) {
 
 // ---- phase stamps (diagnostic build only, -DKDEHIP_STAMPS; never part of the product library) ----
 #ifdef KDEHIP_STAMPS
-__device__ unsigned long long g_stamp_acc[16];
+static __device__ unsigned long long g_stamp_acc[16];
 #define KSTAMP(var) unsigned long long var = __builtin_amdgcn_s_memtime()
 #define KSTAMP_ARGS , stamp_acc, stamp_on
 #define KSTAMP_ADD(slot, t0, t1) do { if (stamp_on) stamp_acc[slot] += (t1) - (t0); } while (0)
@@ -195,10 +195,11 @@ struct EvalUniform {
 };
 
 // FAST: per-node bandwidths; one rsqrt instead of D divides and D logs.
-template <typename T, int D>
+template <typename T, int D, bool MASKED>
 struct EvalFast {
   T center[D], cov[D];
   const double *tab;
+  uint32_t act;  // MASKED: dimensions that take part (:282); an inactive one contributes c = 1, delta = 0
   template <typename P>
   __device__ __forceinline__ T operator()(P e) const {
     T c[D], d2[D];
@@ -207,6 +208,11 @@ struct EvalFast {
       c[d] = e[(D + d) * 64] + cov[d];
       const T dl = e[d * 64] - center[d];
       d2[d] = dl * dl;
+      if constexpr (MASKED) {
+        const bool on = (act >> d) & 1u;
+        c[d] = on ? c[d] : T(1);
+        d2[d] = on ? d2[d] : T(0);
+      }
     }
     const T w = e[2 * D * 64];
     // pre[d]*suf[d] = prod_{k != d} c[k]; P = prod_k c[k]
@@ -389,8 +395,10 @@ __device__ __forceinline__ void stage_tile(const unsigned char *__restrict__ src
                                      (LdsVoidPtr)(dst + (c << 10)), 16, 0, 0);
 }
 
-template <typename T, int D, bool FAST, int WAVES>
+template <typename T, int D, int MODE, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan, RunArgs a) {
+  constexpr bool FAST = (MODE != kModeGeneric);      // product/rsqrt + uniform-bandwidth forms
+  constexpr bool MASKED = (MODE == kModeFastMasked);  // ... with inactive dimensions
   using Lay = LdsLayout<T, D, WAVES>;
   __shared__ __attribute__((aligned(1024))) unsigned char smem[Lay::kBytes];
 
@@ -481,11 +489,17 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan,
   // with the functor it is handed and returns the selected tile position.
   auto draw = [&](const LevelDesc &ds, auto hdr, T mean, T cov, auto &&run) -> int {
     if constexpr (FAST) {
+      const uint32_t act = ds.mask_bits & ds.others_bits;
       if (ds.uniform_bw) {
         EvalUniform<T, D> ev;
         ev.tab = sExpTab;
-        const T c = hdr[dl] + cov;
-        const T ni = T(-0.5) * fast_rcp(c);
+        T c = hdr[dl] + cov;
+        T ni = T(-0.5) * fast_rcp(c);
+        if constexpr (MASKED) {  // an inactive dimension contributes nothing: c = 1, weight 0
+          const bool on = (act >> dl) & 1u;
+          c = on ? c : T(1);
+          ni = on ? ni : T(0);
+        }
         T Pr = T(1);
 #pragma unroll
         for (int d = 0; d < D; ++d) {
@@ -496,8 +510,9 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan,
         ev.scale = Num<T>::rsqrt(Pr);
         return run(ev);
       }
-      EvalFast<T, D> ev;
+      EvalFast<T, D, MASKED> ev;
       ev.tab = sExpTab;
+      ev.act = act;
 #pragma unroll
       for (int d = 0; d < D; ++d) {
         ev.center[d] = lane_read(mean, d);
@@ -712,53 +727,53 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan,
 // Workgroup size: 8 chains per workgroup fill all 256 CUs from 2048 chains on; with >= 4096 chains
 // 16 chains share each staged tile, which doubles the wavefronts per SIMD (2 -> 4) available to hide
 // the per-step dependency chains (the LDS pool admits one workgroup per CU either way).
-template <typename T, int D, bool FAST, int WAVES>
+template <typename T, int D, int MODE, int WAVES>
 static int launch_waves(const PlanDev &plan, const RunArgs &args, hipStream_t stream) {
   const int64_t blocks = (args.Np + WAVES - 1) / WAVES;
-  hipLaunchKernelGGL((gibbs_product_kernel<T, D, FAST, WAVES>), dim3(static_cast<unsigned>(blocks)),
+  hipLaunchKernelGGL((gibbs_product_kernel<T, D, MODE, WAVES>), dim3(static_cast<unsigned>(blocks)),
                      dim3(WAVES * 64), 0, stream, plan, args);
   return 0;
 }
 
-template <typename T, int D, bool FAST>
+template <typename T, int D, int MODE>
 static int launch_one(const PlanDev &plan, const RunArgs &args, hipStream_t stream) {
   if (args.Np <= 0) return KDEHIP_OK;
   const bool wide = (args.variant % 1000 == 16) || (args.variant % 1000 != 8 && args.Np >= 16 * 256);
-  if (wide) launch_waves<T, D, FAST, 16>(plan, args, stream);
-  else launch_waves<T, D, FAST, 8>(plan, args, stream);
+  if (wide) launch_waves<T, D, MODE, 16>(plan, args, stream);
+  else launch_waves<T, D, MODE, 8>(plan, args, stream);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess)
     return set_error(KDEHIP_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString(e));
   return KDEHIP_OK;
 }
 
-template <typename T, bool FAST>
-static int launch_dims(const PlanDev &plan, const RunArgs &args, hipStream_t stream) {
-  switch (plan.D) {
-    case 1: return launch_one<T, 1, FAST>(plan, args, stream);
-    case 2: return launch_one<T, 2, FAST>(plan, args, stream);
-    case 3: return launch_one<T, 3, FAST>(plan, args, stream);
-    case 4: return launch_one<T, 4, FAST>(plan, args, stream);
-    case 5: return launch_one<T, 5, FAST>(plan, args, stream);
-    case 6: return launch_one<T, 6, FAST>(plan, args, stream);
-    case 7: return launch_one<T, 7, FAST>(plan, args, stream);
-    case 8: return launch_one<T, 8, FAST>(plan, args, stream);
-    default: return set_error(KDEHIP_ERR_UNSUPPORTED, "ndims outside 1..KDEHIP_MAX_DIMS");
-  }
-}
+// This file is compiled once per dimension count (-DKDEHIP_DIM=1..8, see the Makefile) so the 12 kernel
+// variants of each dimension (2 precisions x 3 arithmetic modes x 2 workgroup widths) build in parallel.
+#ifndef KDEHIP_DIM
+#error "compile gibbs_kernel.hip with -DKDEHIP_DIM=<1..8>"
+#endif
+#define KDEHIP_CAT2(a, b) a##b
+#define KDEHIP_CAT(a, b) KDEHIP_CAT2(a, b)
 
-int launch_gibbs(int precision, bool fast, const PlanDev &plan, const RunArgs &args, void *stream) {
+int KDEHIP_CAT(launch_gibbs_d, KDEHIP_DIM)(int precision, int mode, const PlanDev &plan, const RunArgs &args,
+                                           void *stream) {
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (precision == 64)
-    return fast ? launch_dims<double, true>(plan, args, st) : launch_dims<double, false>(plan, args, st);
-  if (precision == 32)
-    return fast ? launch_dims<float, true>(plan, args, st) : launch_dims<float, false>(plan, args, st);
-  return set_error(KDEHIP_ERR_ARG, "precision must be 64 or 32");
+  constexpr int D = KDEHIP_DIM;
+  if (precision != 64 && precision != 32) return set_error(KDEHIP_ERR_ARG, "precision must be 64 or 32");
+  switch (mode) {
+    case kModeGeneric:
+      return precision == 64 ? launch_one<double, D, kModeGeneric>(plan, args, st) : launch_one<float, D, kModeGeneric>(plan, args, st);
+    case kModeFast:
+      return precision == 64 ? launch_one<double, D, kModeFast>(plan, args, st) : launch_one<float, D, kModeFast>(plan, args, st);
+    case kModeFastMasked:
+      return precision == 64 ? launch_one<double, D, kModeFastMasked>(plan, args, st) : launch_one<float, D, kModeFastMasked>(plan, args, st);
+    default: return set_error(KDEHIP_ERR_ARG, "unknown arithmetic mode");
+  }
 }
 
 }  // namespace kdehip
 
-#ifdef KDEHIP_STAMPS
+#if defined(KDEHIP_STAMPS) && KDEHIP_DIM == 6
 extern "C" int kdehip_debug_read_stamps(unsigned long long *out) {
   (void)hipDeviceSynchronize();
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(kdehip::g_stamp_acc), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -5;

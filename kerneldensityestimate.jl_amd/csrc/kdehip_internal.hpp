@@ -87,6 +87,7 @@ struct PackedProduct {
   std::vector<int32_t> perm;
   int64_t nodes_per_sweep = 0;     // sum_j sum_{l>=1} n_{j,l}
   bool fast = true;                // product/rsqrt arithmetic + compact uniform tiles in use
+  bool all_active = true;          // every dimension of every density is informed by another density
   bool masked = false;
 };
 
@@ -100,7 +101,12 @@ int pack_levels(int Ndens, const kdehip_density *trees, int ndims, const uint8_t
 int nlevels_for(int64_t maxNp);
 
 // ---- kernel launch (gibbs_kernel.hip) ----------------------------------------------------------
-// precision 64/32, fast = product/rsqrt evaluation, otherwise the per-dimension divide+log form.
-int launch_gibbs(int precision, bool fast, const PlanDev &plan, const RunArgs &args, void *stream);
+// Arithmetic form of the kernel evaluation (see gibbs_kernel.hip).
+enum ArithMode : int {
+  kModeGeneric = 0,    // the reference's per-dimension divide + log with its NaN rules
+  kModeFast = 1,       // product/rsqrt + uniform-bandwidth forms, every dimension active
+  kModeFastMasked = 2  // the same with partialDimMask / uninformed dimensions
+};
+int launch_gibbs(int precision, int mode, const PlanDev &plan, const RunArgs &args, void *stream);
 
 }  // namespace kdehip

@@ -103,8 +103,8 @@ int pack_levels(int Ndens, const kdehip_density *trees, int ndims, const uint8_t
 
   // The product/rsqrt form multiplies up to D variances c_d in [bw_lo, 2*bw_hi] (bandwidth plus a
   // leave-one-out product variance that is never larger than the largest bandwidth).  It is used
-  // only when no partial product can leave the comfortable range of T; otherwise, and for masked
-  // products, the per-dimension divide+log form (the reference's own arithmetic) runs.
+  // only when no partial product can leave the comfortable range of T; otherwise the per-dimension
+  // divide+log form (the reference's own arithmetic) runs.
   double up = 1.0, dn = 1.0;
   for (int d = 0; d < D; ++d) {
     const double hi = 2.0 * bw_hi[d], lo = bw_lo[d];
@@ -114,9 +114,10 @@ int pack_levels(int Ndens, const kdehip_density *trees, int ndims, const uint8_t
   const bool in_range = (precision == 64) ? (up < 1e120 && dn > 1e-120) : (up < 1e15 && dn > 1e-15);
   // the fast forms evaluate every dimension: they need every dimension of every density to be informed by
   // some OTHER density too (false for a one-density "product", where the reference weighs by w alone)
-  bool all_active = true;
-  for (int j = 0; j < M; ++j) if ((mask_bits[j] & others_bits[j]) != all) all_active = false;
-  out.fast = finite_ok && in_range && !out.masked && all_active;
+  // (a one-density "product" or a partialDimMask leaves dimensions inactive: masked fast form)
+  out.all_active = true;
+  for (int j = 0; j < M; ++j) if ((mask_bits[j] & others_bits[j]) != all) out.all_active = false;
+  out.fast = finite_ok && in_range;
 
   // ---- phase 2: write the tiles
   const int64_t esz = (precision == 64) ? 8 : 4;

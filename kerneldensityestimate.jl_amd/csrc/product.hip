@@ -17,6 +17,7 @@ struct kdehip_product {
   int device = 0;
   int precision = 64;
   bool fast = true;
+  int mode = kModeFast;
   int variant = 0;
   PackedProduct host;  // descriptors (payload vectors are released after upload)
   void *d_data = nullptr;
@@ -91,6 +92,7 @@ int kdehip_product_create(kdehip_product **out, int Ndens, const kdehip_density 
   p->device = device;
   p->precision = precision;
   p->fast = p->host.fast;
+  p->mode = !p->host.fast ? kModeGeneric : (p->host.all_active ? kModeFast : kModeFastMasked);
 
   const size_t nelem = p->host.data.size();
   const size_t esz = (precision == 64) ? sizeof(double) : sizeof(float);
@@ -195,7 +197,7 @@ int kdehip_product_sample_streams(kdehip_product *plan, int64_t Np, int Niter, c
   a.randU = d_randU; a.randN = d_randN; a.K = K; a.R = R; a.nU = nU; a.nN = nN;
   a.seed = 0; a.sample_offset = 0;
   a.points = d_points; a.indices = d_indices; a.labels = d_labels;
-  return launch_gibbs(plan->precision, plan->fast, plan->dev, a, stream);
+  return launch_gibbs(plan->precision, plan->mode, plan->dev, a, stream);
 }
 
 int kdehip_product_sample_philox(kdehip_product *plan, int64_t Np, int Niter, uint64_t seed,
@@ -214,7 +216,7 @@ int kdehip_product_sample_philox(kdehip_product *plan, int64_t Np, int Niter, ui
   a.R = kdehip_product_randn_per_sample(plan);
   a.seed = seed; a.sample_offset = sample_offset;
   a.points = d_points; a.indices = d_indices; a.labels = d_labels;
-  return launch_gibbs(plan->precision, plan->fast, plan->dev, a, stream);
+  return launch_gibbs(plan->precision, plan->mode, plan->dev, a, stream);
 }
 
 int kdehip_product_sample_philox_host(kdehip_product *plan, int64_t Np, int Niter, uint64_t seed,
