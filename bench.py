@@ -152,8 +152,7 @@ def main():
                                   stream.cuda_stream)
         ev[i][1].record(stream)
         if use_dist:
-            dist.all_gather_into_tensor(bufs["all_pts"], bufs["pts"])
-            dist.all_gather_into_tensor(bufs["all_ind"], bufs["ind"])
+            sp.gather(bufs)  # the single all-gather of [pGM | labels]
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()

@@ -28,17 +28,21 @@ class ShardedProduct:
         self._bufs = {}
 
     def _buffers(self, Np):
+        """Per-rank send buffer [points | indices] and the gathered receive buffer, both viewed as 8-byte
+        words so that ONE all-gather moves the product samples and their labels together."""
         key = int(Np)
         if key not in self._bufs:
             D, M, G = self.plan.ndims, self.plan.Ndens, self.world
             chunk = max(shard_range(Np, r, G)[1] - shard_range(Np, r, G)[0] for r in range(G))
-            self._bufs[key] = dict(
-                chunk=chunk,
-                pts=torch.zeros(chunk * D, dtype=torch.float64, device=self.device),
-                ind=torch.zeros(chunk * M, dtype=torch.int64, device=self.device),
-                all_pts=torch.zeros(G * chunk * D, dtype=torch.float64, device=self.device),
-                all_ind=torch.zeros(G * chunk * M, dtype=torch.int64, device=self.device))
+            send = torch.zeros(chunk * (D + M), dtype=torch.float64, device=self.device)
+            recv = torch.zeros(G * chunk * (D + M), dtype=torch.float64, device=self.device)
+            self._bufs[key] = dict(chunk=chunk, send=send, recv=recv,
+                                   pts=send[: chunk * D], ind=send[chunk * D:].view(torch.int64))
         return self._bufs[key]
+
+    def gather(self, b):
+        """The one collective of the path (RCCL all-gather over xGMI when the backend is "nccl")."""
+        dist.all_gather_into_tensor(b["recv"], b["send"], group=self.group)
 
     def sample(self, Np, Niter=3, seed=0, addEntropy=True, sample_base=0):
         """All ranks return the same (points[D, Np], indices[M, Np]) device tensors."""
@@ -53,12 +57,12 @@ class ShardedProduct:
                                            None, stream)
         if G == 1:
             return b["pts"][: Np * D].view(Np, D).t(), b["ind"][: Np * M].view(Np, M).t()
-        # the one collective of the path: all-gather of pGM (+ labels); equal-sized padded chunks
-        dist.all_gather_into_tensor(b["all_pts"], b["pts"], group=self.group)
-        dist.all_gather_into_tensor(b["all_ind"], b["ind"], group=self.group)
+        self.gather(b)
         c = b["chunk"]
-        pts = torch.cat([b["all_pts"][r * c * D: r * c * D + (shard_range(Np, r, G)[1] - shard_range(Np, r, G)[0]) * D]
-                         for r in range(G)])
-        ind = torch.cat([b["all_ind"][r * c * M: r * c * M + (shard_range(Np, r, G)[1] - shard_range(Np, r, G)[0]) * M]
-                         for r in range(G)])
-        return pts.view(Np, D).t(), ind.view(Np, M).t()
+        w = c * (D + M)
+        pts, ind = [], []
+        for r in range(G):
+            n = shard_range(Np, r, G)[1] - shard_range(Np, r, G)[0]
+            pts.append(b["recv"][r * w: r * w + n * D])
+            ind.append(b["recv"][r * w + c * D: r * w + c * D + n * M].view(torch.int64))
+        return torch.cat(pts).view(Np, D).t(), torch.cat(ind).view(Np, M).t()

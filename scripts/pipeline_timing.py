@@ -19,3 +19,10 @@ t_eval, _ = T(lambda: kdehip.evaluateDualTree(trees[0], pGM))
 print(f"{sys.argv[1] if len(sys.argv)>1 else 'c3'}: host trees of {M} inputs {t_tree:.2f} ms | plan (pack+upload) {t_plan:.2f} ms | "
       f"sample {Nout} chains incl. alloc+D2H {t_samp:.2f} ms | LOOCV bandwidth of pGM ({D}x{Nout}) {t_bw:.2f} ms | "
       f"final tree {t_final:.2f} ms | evaluate {N}x{Nout} {t_eval:.2f} ms")
+# host-buffer drop-in (kdehip_gibbs1): pack + H2D of streams + kernel + D2H, the PCIe-inclusive figure
+K, R = plan.randu_per_sample(Niter), plan.randn_per_sample()
+randU, randN = kdehip.philox_streams(1, 0, Nout, K, R)
+t_g1, _ = T(lambda: kdehip.prodAppxMSGibbsS(None, trees, None, None, Niter=Niter, Np=Nout, randU=randU, randN=randN), 5)
+print(f"kdehip_gibbs1 host-to-host ({randU.nbytes/1e6:.1f} MB of randU over PCIe): {t_g1:.2f} ms = {Nout/t_g1*1e3:.0f} samples/s")
+t_ph, _ = T(lambda: kdehip.prodAppxMSGibbsS(None, trees, None, None, Niter=Niter, Np=Nout, seed=3), 5)
+print(f"prodAppxMSGibbsS host-to-host with device Philox (plan create + run + D2H): {t_ph:.2f} ms = {Nout/t_ph*1e3:.0f} samples/s")
