@@ -84,7 +84,7 @@ typedef struct kdehip_product_info_t {
   int64_t nodes_per_sweep;           /* sum_j sum_{l=1..L} n_{j,l}: kernel evals of one sweep      */
   int64_t bytes_per_eval;            /* (2*ndims+1)*sizeof(T)                           */
   int64_t packed_bytes;              /* device bytes held by the plan                              */
-  int32_t fast_math_path;            /* 1: product/rsqrt evaluation; 0: per-dim divide+log (SAFE)  */
+  int32_t fast_math_path;            /* 1: product/rsqrt forms; 0: the reference's divide+log form  */
   int32_t device;
 } kdehip_product_info_t;
 
@@ -115,7 +115,8 @@ int kdehip_product_sample_philox(kdehip_product *plan, int64_t Np, int Niter, ui
 int kdehip_product_sample_philox_host(kdehip_product *plan, int64_t Np, int Niter, uint64_t seed,
                                       int64_t sample_offset, int addEntropy, double *points,
                                       int64_t *indices, int32_t *labels);
-/* Tuning knob for experiments/benchmarks: kernel variant (0 = library default). */
+/* Scheduling knob for experiments/benchmarks; results never depend on it.  0 = library default,
+ * 1 = read every tile from global memory (no LDS staging), 8 / 16 = chains per workgroup. */
 int kdehip_product_set_variant(kdehip_product *plan, int variant);
 
 /* ---- (3) host twin of the device RNG ----------------------------------------------------------

@@ -8,12 +8,13 @@
 //
 // Mapping (MI355X-first, not a translation of the Julia loop nest):
 //   * one 64-lane wavefront owns one output sample (one Gibbs chain); chains never communicate.
-//     Eight chains share a workgroup (one per CU at the headline size) and walk the data-independent
-//     (level, pass, density) schedule in lock step so that the tile every wavefront is about to read
-//     is staged ONCE per workgroup into LDS with direct-to-LDS loads (global_load_lds_dwordx4):
-//     levels whose tiles all fit stay resident for the whole level, larger ones are streamed one
-//     tile per step through a double buffer (the copy of step t+1 overlaps the evaluation of step
-//     t, one barrier per step), and only tiles beyond half the pool are read from L2 directly;
+//     8 chains (16 from 4096 chains on) share a workgroup, one workgroup per CU, and walk the
+//     data-independent (level, pass, density) schedule in lock step so that the tile every wavefront
+//     is about to read is staged ONCE per workgroup into LDS with direct-to-LDS loads
+//     (global_load_lds_dwordx4): levels whose tiles all fit the 120 KiB pool stay resident for the
+//     whole level; larger ones are streamed one tile per step through a double buffer (the copy of
+//     step t+1 overlaps the evaluation of step t, one barrier per step); tiles beyond half the pool
+//     are streamed through the two halves a few rows at a time (one barrier per chunk);
 //   * inside a (level, density) step the lanes are the frontier nodes: lane `ln` owns the
 //     contiguous entries ln*B .. ln*B+B-1 (B = ceil(n/64)), reads them row by row with coalesced
 //     loads (one address per row, fields at constant offsets), keeps a private running sum, and
@@ -29,15 +30,17 @@
 //     order) or from an on-device Philox4x32-10 keyed by (seed, global sample, draw), which the
 //     compiler runs on the scalar unit because every input is wave-uniform.
 //
-// Three arithmetic forms of the kernel evaluation p_z = w_z * N(center; mean_z, bw_z + cov):
+// Arithmetic forms of the kernel evaluation p_z = w_z * N(center; mean_z, bw_z + cov) (kernel
+// template MODE: generic, fast, fast with inactive dimensions):
 //   UNIFORM  levels whose nodes share one bandwidth vector (every leaf level): the D reciprocals and
 //            the normalisation are wave-uniform and hoisted; per node D subtracts, D multiplies,
 //            D fused multiply-adds and one exp;
 //   FAST     p = w * rsqrt(prod_d c_d) * exp(-1/2 * sum_d delta_d^2 / c_d), the D reciprocals
 //            obtained from ONE rsqrt via prefix/suffix products -- no divide, no log;
 //   GENERIC  the reference's own per-dimension divide + log with its NaN rules (:287-303), used for
-//            partialDimMask products and for inputs whose variance products could leave the range
-//            of T.
+//            inputs whose variance products could leave the range of T or are not finite/positive.
+// partialDimMask products (and one-density "products") run UNIFORM/FAST with the inactive dimensions
+// contributing c = 1, delta = 0 (MODE = fast-masked).
 // fp64 exp on the fast forms is a 32-entry-table (LDS, one bank row, conflict free) + degree-6
 // polynomial, ~1 ulp; the GENERIC form calls the library exp/log.
 //
@@ -50,7 +53,6 @@
 #include "philox.hpp"
 
 namespace kdehip {
-
 
 // ---- small device helpers ------------------------------------------------------------------------
 

@@ -13,6 +13,8 @@
  *     none for this path and Julia is not available here to run it.  It is constrained only by the
  *     reference's statistical acceptance tests (test/runtests.jl:167-201, test/testPartialProd.jl)
  *     and closed-form invariants, all replayed in tests/.
+ *   - direct evaluation + LOOCV bandwidth (okde_eval_direct, okde_auto_bandwidth): PINNED by the
+ *     reference's golden test1Dlcv100Result.txt (kde!(x) at the reference's 1e-4, UnitTest1Dlcv01).
  *
  * Every function cites the reference file:line it follows (paths relative to /root/reference).
  * Node ids are the reference's 1-based ids; array element [id-1] stores node `id`.
