@@ -275,6 +275,14 @@ __device__ __forceinline__ T lane_sum_rows(P rows, int nrows, int RS, int lane, 
   return S;
 }
 
+template <typename T, typename P, typename Eval>
+__device__ __forceinline__ int select_from_scan(T incl, T S, P rows, const LevelDesc &ds, int lane, const Eval &ev,
+                                                double u
+#ifdef KDEHIP_STAMPS
+                                                , unsigned long long *stamp_acc, bool stamp_on
+#endif
+);
+
 // Selection from the lane sums S: wavefront scan, winning lane, then pass 2 over the winning lane's
 // block read through `rows` (row 0, field 0, lane 0 of the whole tile; LDS or global).
 template <typename T, typename P, typename Eval>
@@ -283,10 +291,21 @@ __device__ __forceinline__ int select_label(T S, P rows, const LevelDesc &ds, in
                                             , unsigned long long *stamp_acc, bool stamp_on
 #endif
 ) {
+  return select_from_scan<T, P>(wave_inclusive_scan(S), S, rows, ds, lane, ev, u KSTAMP_ARGS);
+}
+
+// The selection proper, from the inclusive wavefront scan `incl` of the lane sums S.  Also entered
+// directly with a scan that was computed ahead of time (conditional tables, single-row frontiers).
+template <typename T, typename P, typename Eval>
+__device__ __forceinline__ int select_from_scan(T incl, T S, P rows, const LevelDesc &ds, int lane, const Eval &ev,
+                                                double u
+#ifdef KDEHIP_STAMPS
+                                                , unsigned long long *stamp_acc, bool stamp_on
+#endif
+) {
   const int n = ds.n, B = ds.B, F = ds.F;
   const int RS = F * 64 + 1;
   KSTAMP(tp1);
-  const T incl = wave_inclusive_scan(S);
   const T total = lane_read(incl, 63);
 
   if (!(total >= Num<T>::tiny_total())) {  // also taken when every weight is NaN (:302 zeroes them all)
@@ -383,6 +402,18 @@ struct LevelTable {
     return d;
   }
 };
+// conditional-table descriptors (32 B each) through the constant address space, like LevelTable
+typedef int kdehip_v8i __attribute__((ext_vector_type(8)));
+struct TabTable {
+  const __attribute__((address_space(4))) kdehip_v8i *p;
+  __device__ __forceinline__ TabDesc operator[](int idx) const {
+    const kdehip_v8i raw = p[idx];  // one s_load_dwordx8
+    TabDesc d;
+    __builtin_memcpy(&d, &raw, sizeof(TabDesc));
+    return d;
+  }
+};
+
 using LdsVoidPtr = __attribute__((address_space(3))) void *;
 using GlobalVoidPtr = const __attribute__((address_space(1))) void *;
 
@@ -588,6 +619,53 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan,
     wave_sync();
   };
 
+  // ---- conditional tables ------------------------------------------------------------------------
+  // While a level's frontiers have at most 64 nodes, the conditional distribution a Gibbs step draws
+  // from depends on the chain only through the OTHER densities' current labels -- finitely many
+  // configurations, the same for every chain.  For the levels the plan selected (cfg counts within its
+  // memory budget) the inclusive scans of all these conditionals are computed ONCE per plan by this
+  // same kernel code (a.table_build: one wavefront per (level, density, configuration)), so a sweep
+  // step on such a level is one table row load + the unchanged selection: bit-identical results
+  // without the kernel evaluation, scan and state update on the per-step critical path.
+  const TabTable tabs{(const __attribute__((address_space(4))) kdehip_v8i *)(plan.tabdesc)};
+  T *tables = static_cast<T *>(const_cast<void *>(plan.tables));
+  if (a.table_build) {
+    const int64_t g = static_cast<int64_t>(blockIdx.x) * WAVES + wave;
+    if (g >= plan.tab_rows_total) return;
+    int tl = 1, tj = 0;
+    TabDesc td = tabs[1];
+    for (int l = 1; l <= plan.Lt; ++l)
+      for (int j = 0; j < M; ++j) {
+        const TabDesc c = tabs[j * (L + 1) + l];
+        if (g >= c.row_base && g < c.row_base + c.ncfg) { td = c; tl = l; tj = j; }
+      }
+    const int cfg = static_cast<int>(g - td.row_base);
+    // row index -> packed label word (the digit of density tj is the hole between the two parts)
+    const uint32_t word = (static_cast<uint32_t>(cfg) & ((1u << td.shift) - 1u)) |
+                          ((static_cast<uint32_t>(cfg) >> td.shift) << (td.shift + td.bits));
+    for (int k = 0; k < M; ++k) {
+      if (k == tj) continue;
+      const TabDesc tk = tabs[k * (L + 1) + tl];
+      const LevelDesc dk = levels[k * (L + 1) + tl];
+      set_particle(k, dk, data + dk.hdr_off, static_cast<int>((word >> tk.shift) & ((1u << tk.bits) - 1u)));
+    }
+    wave_sync();
+    const LevelDesc ds = levels[tj * (L + 1) + tl];
+    T mean, cov;
+    product_dim(tj, ds.others_bits, mean, cov);
+    const T *hdr = data + ds.hdr_off;
+    T *row = tables + td.off + static_cast<int64_t>(cfg) * (td.n + 1);
+    draw(ds, hdr, mean, cov, [&](const auto &ev) {
+      const T S = lane_sum_rows<T, const T *>(hdr + kTileHeader, 1, ds.F * 64 + 1, lane, ev);
+      const T incl = wave_inclusive_scan(S);
+      if (lane < td.n) row[lane] = incl;
+      if (lane == 63) row[td.n] = incl;  // the total the selection reads from lane 63
+      return 0;
+    });
+    return;
+  }
+  const int Lt = (vlev == 1 || vlev == 4 || !a.use_tables) ? 0 : plan.Lt;  // variant 4: tables off (A/B, tests)
+
   // init: frontier = {root}, label = root (levelInit!/initIndices!/calcIndices!, :587-589)
   for (int j = 0; j < M; ++j) {
     const LevelDesc ds = levels[j * (L + 1)];
@@ -662,11 +740,45 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan,
     }
 
     int j = 0;
+    uint32_t word = 0;  // packed labels (tabulated levels)
     LevelDesc ds_next = levels[l];  // descriptor of step 0; each step fetches its successor's early
     for (int t = 0; t < nsteps; ++t) {
       const LevelDesc ds = ds_next;
       const int jn = (j + 1 == M) ? 0 : j + 1;
       ds_next = levels[jn * (L + 1) + l];
+      if (l <= Lt && t >= M) {
+        // tabulated sweep step.  The labels of all densities are kept packed in one scalar word
+        // (density k in bits [shift_k, shift_k + bits_k): frontier sizes are powers of two here); the
+        // row of density j is addressed by the word with j's digit squeezed out.  The row holds the
+        // inclusive scan the regular path would compute (lanes >= n read the total, which is what
+        // they would hold after the scan), so the selection code below is the unchanged one.
+        const TabDesc td = tabs[j * (L + 1) + l];
+        if (t == M) {  // first sweep step of the level: pack the labels the sampleIndices! pass chose
+          word = 0;
+          for (int k = 0; k < M; ++k)
+            word |= static_cast<uint32_t>(psel[k]) << tabs[k * (L + 1) + l].shift;
+          word = __builtin_amdgcn_readfirstlane(word);
+        }
+        const uint32_t cfg = (word & ((1u << td.shift) - 1u)) | ((word >> (td.shift + td.bits)) << td.shift);
+        const T *row = tables + td.off + static_cast<int64_t>(cfg) * (td.n + 1);
+        const T incl = row[lane < td.n ? lane : td.n];
+        const double u = next_uniform();
+        const LdsPtr<T> rows = (LdsPtr<T>)(pool + ds.lds_off) + kTileHeader;
+        EvalGeneric<T, D> unused{};  // single-row frontiers never reach the second pass
+        const int pos = select_from_scan<T, LdsPtr<T>>(incl, T(0), rows, ds, lane, unused, u KSTAMP_ARGS);
+        word = (word & ~(((1u << td.bits) - 1u) << td.shift)) | (static_cast<uint32_t>(pos) << td.shift);
+        if (lane == 0) psel[j] = pos;
+        if (t + 1 == nsteps) {  // the level's last step: adopt the selected kernels for what follows
+          wave_sync();
+          for (int k = 0; k < M; ++k) {
+            const LevelDesc dk = levels[k * (L + 1) + l];
+            set_particle(k, dk, (LdsPtr<T>)(pool + dk.lds_off), psel[k]);
+          }
+          wave_sync();
+        }
+        j = jn;
+        continue;
+      }
       T mean = x, cov = T(0);      // sampleIndices! (:364-385): against the point just drawn
 #ifdef KDEHIP_STAMPS
       stamp_on = (l == (vflags >> 8)) ;  // stamp only the level selected by the experiment

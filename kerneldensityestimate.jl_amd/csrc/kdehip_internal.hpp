@@ -54,11 +54,31 @@ struct LevelDesc {
 };
 static_assert(sizeof(LevelDesc) == 64, "LevelDesc is read with scalar loads; keep it 64 bytes");
 
+// Conditional table of density j on level l (see gibbs_kernel.hip "conditional tables"): rows of n+1
+// values (inclusive scan over the n frontier nodes, then the total).  Only levels whose frontier sizes
+// are powers of two (and <= 64) are tabulated: the labels of all densities are packed into one word,
+// density k occupying bits [shift, shift+bits) of it, and the row index of density j is that word with
+// j's own digit removed.
+struct TabDesc {
+  int64_t off;        // element offset (units of T) of row 0 in the plan's table buffer; -1 = not tabulated
+  int64_t row_base;   // index of row 0 in the global row enumeration (table build: one wavefront per row)
+  int32_t n;          // frontier size of density j on this level (= 1 << bits)
+  int32_t ncfg;       // number of rows = product of the other densities' frontier sizes
+  int32_t shift;      // position of this density's digit in the packed label word
+  int32_t bits;       // width of the digit
+};
+static_assert(sizeof(TabDesc) == 32, "TabDesc is read with one 32-byte scalar load");
+constexpr int64_t kTabMaxEntries = 512 * 1024;  // table budget per plan (4 MiB in fp64)
+constexpr int64_t kTabMinChains = 256;          // tables are built at the first run with this many chains
+
 struct PlanDev {
   const void *data;          // T[...]
   const int32_t *perm;       // int32[...]
   const LevelDesc *levels;   // [M][L+1], level 0 = root
-  int32_t M, L, D, pad_;
+  const void *tables;        // T[...] conditional tables (may be unbuilt: RunArgs.use_tables)
+  const TabDesc *tabdesc;    // [M][L+1]
+  int64_t tab_rows_total;
+  int32_t M, L, D, Lt;       // Lt: levels 1..Lt are tabulated (0 = none)
 };
 
 struct RunArgs {
@@ -67,6 +87,8 @@ struct RunArgs {
   int32_t addEntropy;
   int32_t rng_philox;   // 0: read d_randU/d_randN, 1: on-device Philox
   int32_t variant;
+  int32_t table_build;  // 1: this launch fills the conditional tables instead of sampling
+  int32_t use_tables;   // 1: the tables are built and may be used
   const double *randU;
   const double *randN;
   int64_t K, R;         // per-sample consumption
@@ -88,6 +110,9 @@ struct PackedProduct {
   int64_t nodes_per_sweep = 0;     // sum_j sum_{l>=1} n_{j,l}
   bool fast = true;                // product/rsqrt arithmetic + compact uniform tiles in use
   bool all_active = true;          // every dimension of every density is informed by another density
+  std::vector<TabDesc> tabdesc;    // [M][L+1]
+  int Lt = 0;                      // tabulated levels 1..Lt
+  int64_t tab_entries = 0, tab_rows = 0;
   bool masked = false;
 };
 

@@ -196,6 +196,46 @@ int pack_levels(int Ndens, const kdehip_density *trees, int ndims, const uint8_t
       off += ds.stage_bytes;
     }
   }
+
+  // ---- phase 4: conditional tables (gibbs_kernel.hip): levels whose frontiers all fit one wavefront row
+  // and have power-of-two sizes, as long as the rows of all densities stay within the entry budget
+  out.tabdesc.assign(static_cast<size_t>(M) * (L + 1), TabDesc{});
+  for (auto &t : out.tabdesc) t.off = -1;
+  if (out.fast && M >= 2) {
+    int64_t entries = 0, rows = 0;
+    for (int l = 1; l <= L; ++l) {
+      bool ok = true;
+      int total_bits = 0;
+      std::vector<int> bits(M, 0);
+      for (int j = 0; j < M && ok; ++j) {
+        const LevelDesc &dj = out.levels[static_cast<size_t>(j) * (L + 1) + l];
+        if (dj.B != 1 || dj.stage_mode != kStageResident || (dj.n & (dj.n - 1)) != 0) { ok = false; break; }
+        while ((1 << bits[j]) < dj.n) ++bits[j];
+        total_bits += bits[j];
+      }
+      if (!ok || total_bits > 30) break;
+      int64_t lvl_entries = 0;
+      for (int j = 0; j < M; ++j)
+        lvl_entries += (int64_t(1) << (total_bits - bits[j])) * ((int64_t(1) << bits[j]) + 1);
+      if (entries + lvl_entries > kTabMaxEntries) break;
+      int shift = 0;
+      for (int j = 0; j < M; ++j) {
+        TabDesc &td = out.tabdesc[static_cast<size_t>(j) * (L + 1) + l];
+        td.n = 1 << bits[j];
+        td.bits = bits[j];
+        td.shift = shift;
+        shift += bits[j];
+        td.ncfg = 1 << (total_bits - bits[j]);
+        td.off = entries;
+        td.row_base = rows;
+        entries += static_cast<int64_t>(td.ncfg) * (td.n + 1);
+        rows += td.ncfg;
+      }
+      out.Lt = l;
+    }
+    out.tab_entries = entries;
+    out.tab_rows = rows;
+  }
   return KDEHIP_OK;
 }
 

@@ -23,6 +23,9 @@ struct kdehip_product {
   void *d_data = nullptr;
   int32_t *d_perm = nullptr;
   LevelDesc *d_levels = nullptr;
+  void *d_tables = nullptr;
+  TabDesc *d_tabdesc = nullptr;
+  bool tables_built = false;
   int64_t packed_bytes = 0;
   PlanDev dev{};
 };
@@ -63,6 +66,26 @@ int check_run(const kdehip_product *plan, int64_t Np, int Niter, const void *d_p
   if (Niter < 0) return set_error(KDEHIP_ERR_ARG, "Niter must be >= 0");
   if (Np > 0 && (!d_points || !d_indices)) return set_error(KDEHIP_ERR_ARG, "null output pointer");
   if (Np > (int64_t(1) << 31) * 4 - 8) return set_error(KDEHIP_ERR_UNSUPPORTED, "Np too large for one launch");
+  return KDEHIP_OK;
+}
+
+// Conditional tables are filled by the sampler kernel itself (table_build launch), on the caller's stream,
+// the first time a run is large enough to pay for them.
+int maybe_build_tables(kdehip_product *plan, int64_t Np, RunArgs &a, void *stream) {
+  a.table_build = 0;
+  a.use_tables = 0;
+  if (plan->dev.Lt <= 0 || plan->dev.tab_rows_total <= 0) return KDEHIP_OK;
+  if (!plan->tables_built) {
+    if (Np < kTabMinChains) return KDEHIP_OK;
+    RunArgs b = a;
+    b.table_build = 1;
+    b.Np = plan->dev.tab_rows_total;  // one wavefront per table row
+    b.variant = 8;
+    const int rc = launch_gibbs(plan->precision, plan->mode, plan->dev, b, stream);
+    if (rc != KDEHIP_OK) return rc;
+    plan->tables_built = true;
+  }
+  a.use_tables = 1;
   return KDEHIP_OK;
 }
 
@@ -121,17 +144,28 @@ int kdehip_product_create(kdehip_product **out, int Ndens, const kdehip_density 
     return fail(e, "hipMemcpy(perm)");
   if ((e = hipMemcpy(p->d_levels, p->host.levels.data(), nlev * sizeof(LevelDesc), hipMemcpyHostToDevice)) != hipSuccess)
     return fail(e, "hipMemcpy(levels)");
-  p->packed_bytes = static_cast<int64_t>(nelem * esz + nperm * sizeof(int32_t) + nlev * sizeof(LevelDesc));
+  const size_t ntab = p->host.tabdesc.size();
+  const size_t tab_bytes = static_cast<size_t>(p->host.tab_entries) * esz;
+  if ((e = hipMalloc(reinterpret_cast<void **>(&p->d_tabdesc), ntab * sizeof(TabDesc))) != hipSuccess)
+    return fail(e, "hipMalloc(tabdesc)");
+  if ((e = hipMemcpy(p->d_tabdesc, p->host.tabdesc.data(), ntab * sizeof(TabDesc), hipMemcpyHostToDevice)) != hipSuccess)
+    return fail(e, "hipMemcpy(tabdesc)");
+  if (tab_bytes && (e = hipMalloc(&p->d_tables, tab_bytes)) != hipSuccess) return fail(e, "hipMalloc(tables)");
+  p->packed_bytes = static_cast<int64_t>(nelem * esz + nperm * sizeof(int32_t) + nlev * sizeof(LevelDesc) +
+                                         ntab * sizeof(TabDesc) + tab_bytes);
   std::vector<double>().swap(p->host.data);
   std::vector<int32_t>().swap(p->host.perm);
 
   p->dev.data = p->d_data;
   p->dev.perm = p->d_perm;
   p->dev.levels = p->d_levels;
+  p->dev.tables = p->d_tables;
+  p->dev.tabdesc = p->d_tabdesc;
+  p->dev.tab_rows_total = p->host.tab_rows;
   p->dev.M = p->host.M;
   p->dev.L = p->host.L;
   p->dev.D = p->host.D;
-  p->dev.pad_ = 0;
+  p->dev.Lt = (p->mode == kModeGeneric) ? 0 : p->host.Lt;
   *out = p;
   return KDEHIP_OK;
 }
@@ -142,6 +176,8 @@ void kdehip_product_destroy(kdehip_product *plan) {
     if (plan->d_data) (void)hipFree(plan->d_data);
     if (plan->d_perm) (void)hipFree(plan->d_perm);
     if (plan->d_levels) (void)hipFree(plan->d_levels);
+    if (plan->d_tables) (void)hipFree(plan->d_tables);
+    if (plan->d_tabdesc) (void)hipFree(plan->d_tabdesc);
   }
   delete plan;
 }
@@ -197,6 +233,8 @@ int kdehip_product_sample_streams(kdehip_product *plan, int64_t Np, int Niter, c
   a.randU = d_randU; a.randN = d_randN; a.K = K; a.R = R; a.nU = nU; a.nN = nN;
   a.seed = 0; a.sample_offset = 0;
   a.points = d_points; a.indices = d_indices; a.labels = d_labels;
+  rc = maybe_build_tables(plan, Np, a, stream);
+  if (rc != KDEHIP_OK) return rc;
   return launch_gibbs(plan->precision, plan->mode, plan->dev, a, stream);
 }
 
@@ -216,6 +254,8 @@ int kdehip_product_sample_philox(kdehip_product *plan, int64_t Np, int Niter, ui
   a.R = kdehip_product_randn_per_sample(plan);
   a.seed = seed; a.sample_offset = sample_offset;
   a.points = d_points; a.indices = d_indices; a.labels = d_labels;
+  rc = maybe_build_tables(plan, Np, a, stream);
+  if (rc != KDEHIP_OK) return rc;
   return launch_gibbs(plan->precision, plan->mode, plan->dev, a, stream);
 }
 

@@ -340,3 +340,28 @@ def test_workgroup_width_variants_give_identical_results(variant):
         assert np.array_equal(a, b)
     u, n = kdehip.philox_streams(seed, 0, Np, K, R)
     _compare(got[:2], oracle.gibbs1(op, Np, Niter, u, n), tol=1e-11)
+
+
+@pytest.mark.parametrize("D,M,N,weighted,mask", [(2, 2, 300, False, None), (3, 3, [60, 200, 33], True, None),
+                                                 (6, 4, 1000, False, None), (1, 5, 40, True, None),
+                                                 (2, 3, 100, False, [[1, 0], [1, 1], [0, 1]])])
+def test_conditional_tables_are_exact(D, M, N, weighted, mask):
+    """Levels whose frontiers fit one wavefront row are sampled from precomputed conditional tables once a
+    run has >= 256 chains; the result must be bit-identical to the table-free path (variant 4) and match
+    the oracle."""
+    Np, Niter, seed = 600, 4, 21
+    gp, op = _make_inputs(300 + D + M, D, M, N, weighted)
+    for prec in (64, 32):
+        with kdehip.ProductPlan(gp, partialDimMask=mask, precision=prec) as plan:
+            plan.set_variant(4)
+            ref = plan.sample(Np, Niter=Niter, seed=seed, want_labels=True)
+            plan.set_variant(0)
+            got = plan.sample(Np, Niter=Niter, seed=seed, want_labels=True)   # builds + uses the tables
+            small = plan.sample(100, Niter=Niter, seed=seed)                  # tables stay in use once built
+            K, R = plan.randu_per_sample(Niter), plan.randn_per_sample()
+        for a, b in zip(ref, got):
+            assert np.array_equal(a, b)
+        assert np.array_equal(small[0], ref[0][:, :100]) and np.array_equal(small[1], ref[1][:, :100])
+        if prec == 64:
+            u, n = kdehip.philox_streams(seed, 0, Np, K, R)
+            _compare(got[:2], oracle.gibbs1(op, Np, Niter, u, n, partialDimMask=mask), tol=1e-11)
