@@ -69,7 +69,8 @@ struct TabDesc {
 };
 static_assert(sizeof(TabDesc) == 32, "TabDesc is read with one 32-byte scalar load");
 constexpr int64_t kTabMaxEntries = 512 * 1024;  // table budget per plan (4 MiB in fp64)
-constexpr int64_t kTabMinChains = 256;          // tables are built at the first run with this many chains
+constexpr int64_t kTabMinChains = 16;           // tables are built at the first run with this many chains (a run is
+                                                // latency bound: the ~70 us build pays off within one run)
 
 struct PlanDev {
   const void *data;          // T[...]

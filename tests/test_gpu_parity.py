@@ -346,8 +346,8 @@ def test_workgroup_width_variants_give_identical_results(variant):
                                                  (6, 4, 1000, False, None), (1, 5, 40, True, None),
                                                  (2, 3, 100, False, [[1, 0], [1, 1], [0, 1]])])
 def test_conditional_tables_are_exact(D, M, N, weighted, mask):
-    """Levels whose frontiers fit one wavefront row are sampled from precomputed conditional tables once a
-    run has >= 256 chains; the result must be bit-identical to the table-free path (variant 4) and match
+    """Levels whose frontiers fit one wavefront row (power-of-two sizes) are sampled from conditional tables
+    built at the first run; the result must be bit-identical to the table-free path (variant 4) and match
     the oracle."""
     Np, Niter, seed = 600, 4, 21
     gp, op = _make_inputs(300 + D + M, D, M, N, weighted)
