@@ -74,8 +74,10 @@ int kdehip_gibbs1(int Ndens, const kdehip_density *trees, int64_t Np, int Niter,
                   int addEntropy, int ndims, const uint8_t *partialDimMask, int device);
 
 /* ---- (2) resident product plan ----------------------------------------------------------------
- * The densities are re-laid-out once (per-level SoA, "pack_levels") and kept in HBM so repeated
- * products -- and bench.py's timed region -- start with inputs resident on the device. */
+ * The densities are re-laid-out once (per-level tiles, "pack_levels") and kept in HBM so repeated
+ * products -- and bench.py's timed region -- start with inputs resident on the device.  The first run
+ * of a plan additionally fills its conditional tables (tens of microseconds) and synchronises its
+ * stream once; later runs only enqueue work.  A plan may be used from several threads/streams. */
 typedef struct kdehip_product kdehip_product;
 
 typedef struct kdehip_product_info_t {

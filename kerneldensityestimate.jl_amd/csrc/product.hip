@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -26,6 +27,7 @@ struct kdehip_product {
   void *d_tables = nullptr;
   TabDesc *d_tabdesc = nullptr;
   bool tables_built = false;
+  std::mutex tables_mutex;  // concurrent first runs on one plan build the tables once
   int64_t packed_bytes = 0;
   PlanDev dev{};
 };
@@ -75,6 +77,7 @@ int maybe_build_tables(kdehip_product *plan, int64_t Np, RunArgs &a, void *strea
   a.table_build = 0;
   a.use_tables = 0;
   if (plan->dev.Lt <= 0 || plan->dev.tab_rows_total <= 0) return KDEHIP_OK;
+  std::lock_guard<std::mutex> lock(plan->tables_mutex);
   if (!plan->tables_built) {
     if (Np < kTabMinChains) return KDEHIP_OK;
     RunArgs b = a;
@@ -83,6 +86,8 @@ int maybe_build_tables(kdehip_product *plan, int64_t Np, RunArgs &a, void *strea
     b.variant = 8;
     const int rc = launch_gibbs(plan->precision, plan->mode, plan->dev, b, stream);
     if (rc != KDEHIP_OK) return rc;
+    // one-time: runs on other streams must not overtake the build
+    KDEHIP_CHECK(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
     plan->tables_built = true;
   }
   a.use_tables = 1;
