@@ -1,6 +1,7 @@
 """Edge cases and size-independent properties of the HIP product path at and beyond the BASELINE sizes."""
 import numpy as np
 import pytest
+import torch  # before the first HIP call of libkdehip: torch brings its own HIP runtime build
 
 import kdehip
 from oracle import oracle
@@ -93,3 +94,29 @@ def test_zero_chains_and_argument_errors():
         kdehip.ProductPlan(gp, precision=16)
     with pytest.raises(kdehip.KdeHipError):
         kdehip.ProductPlan(gp, device=99)
+
+
+def test_runs_can_be_captured_in_a_hip_graph():
+    """After the first run (which builds the conditional tables) a run only enqueues one kernel: it can be
+    captured into a HIP graph and replayed, e.g. to batch many small products without launch overhead."""
+    D, M, N, Np, Niter, seed = 2, 3, 200, 256, 5, 3
+    gp, _ = _make_inputs(12, D, M, N)
+    dev = torch.device("cuda", 0)
+    with kdehip.ProductPlan(gp) as plan:
+        ref_p, ref_i = plan.sample(Np, Niter=Niter, seed=seed)          # first run: tables built here
+        P = torch.zeros(Np * D, dtype=torch.float64, device=dev)
+        I = torch.zeros(Np * M, dtype=torch.int64, device=dev)
+        side = torch.cuda.Stream(device=dev)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            plan.sample_philox_device(Np, Niter, seed, 0, True, P, I, None, side.cuda_stream)  # warm-up on this stream
+        side.synchronize()
+        with torch.cuda.graph(graph, stream=side):
+            plan.sample_philox_device(Np, Niter, seed, 0, True, P, I, None, torch.cuda.current_stream(dev).cuda_stream)
+        P.zero_()
+        I.zero_()
+        for _ in range(3):
+            graph.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(P.cpu().numpy().reshape(Np, D).T, ref_p)
+        assert np.array_equal(I.cpu().numpy().reshape(Np, M).T, ref_i)
