@@ -75,7 +75,27 @@ class KdeHipError(RuntimeError):
         self.code = code
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so (no SONAME), while libkdehip.so links the
+    system one (libamdhip64.so.7).  Two HIP runtimes in one process fight over the device: whichever
+    initialises second sees "No HIP GPUs".  Binding libkdehip's hip* symbols to torch's copy (global
+    scope, loaded first) keeps ONE runtime whatever the import order.  No torch -> system runtime."""
+    if os.environ.get("KDEHIP_NO_TORCH_HIP") == "1":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:  # noqa: BLE001  (purely a courtesy; the system runtime still works on its own)
+        pass
+
+
 def _load():
+    _share_hip_runtime_with_torch()
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
