@@ -131,6 +131,41 @@ function prodAppxMSGibbsS(npd0::BallTreeDensity, trees::Array{BallTreeDensity,1}
 end
 
 """
+    evaluateDualTree(bd, pos, lvFlag=false)
+
+`evaluateDualTree` / `bd(pos)` with the reference's default `FORCE_EVAL_DIRECT = true`
+(src/DualTree01.jl:370-446) on the GPU.  `lvFlag=true`: leave-one-out at `bd`'s own points.
+"""
+function evaluateDualTree(bd::BallTreeDensity, pos::AbstractMatrix{Float64}, lvFlag::Bool=false; device::Int=0)
+  Ndim(bd) == size(pos, 1) || error("bd and pos must have the same dimension")
+  Nq = lvFlag ? Npts(bd) : size(pos, 2)
+  out = zeros(Nq)
+  cd = Ref(CDensity(bd))
+  posd = Matrix{Float64}(pos)
+  GC.@preserve bd posd begin
+    check(ccall((:kdehip_evaluate, libkdehip), Cint, (Ref{CDensity}, Ptr{Float64}, Int64, Cint, Ptr{Float64}, Cint),
+                cd, posd, size(pos, 2), lvFlag ? 1 : 0, out, device))
+  end
+  return out
+end
+
+"""
+    kde!(points)
+
+`kde!(points)` (src/KDE01.jl:3-27): per-dimension LOOCV bandwidth found on the GPU, then the reference's
+own explicit-bandwidth constructor builds the density.
+"""
+function kde!(points::AbstractMatrix{Float64}; device::Int=0)
+  D, N = size(points)
+  bw = zeros(D)
+  nev = Ref{Int32}(0)
+  pts = Matrix{Float64}(points)
+  check(ccall((:kdehip_auto_bandwidth, libkdehip), Cint, (Int64, Int64, Ptr{Float64}, Ptr{Float64}, Ref{Int32}, Cint),
+              D, N, pts, bw, nev, device))
+  return KDE.kde!(pts, bw)
+end
+
+"""
     enable!()
 
 Route `KernelDensityEstimate.gibbs1` -- and with it `prodAppxMSGibbsS`, `*` and every downstream
