@@ -11,9 +11,13 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "kdehip_internal.hpp"
@@ -48,13 +52,16 @@ struct EvalProblem {
   int64_t N, Nq;
 };
 
+// A launch handles up to KDEHIP_MAX_DIMS independent problems (the D one-dimensional searches of
+// kde!(points) in one round); their descriptors travel as kernel arguments, not through memory.
+struct EvalBatch { EvalProblem p[KDEHIP_MAX_DIMS]; };
+
 // partial[c][q] = sum_{i in chunk c, (i != q if loo)} w_i exp(-1/2 sum_k (x_qk - c_ik)^2 / bw_k)
 // (the kernel value of distGauss!, src/DualTree01.jl:14-47, with leaf ranges 0 and uniform bandwidth)
 template <int D>
-__global__ __launch_bounds__(kEvalThreads) void eval_partial_kernel(const EvalProblem *__restrict__ problems,
-                                                                    int loo) {
+__global__ __launch_bounds__(kEvalThreads) void eval_partial_kernel(const EvalBatch batch, int loo) {
   __shared__ double sSrc[kEvalChunk * (D + 1)];
-  const EvalProblem pb = problems[blockIdx.z];
+  const EvalProblem &pb = batch.p[blockIdx.z];
   const int64_t q = static_cast<int64_t>(blockIdx.x) * kEvalThreads + threadIdx.x;
   const int64_t i0 = static_cast<int64_t>(blockIdx.y) * kEvalChunk;
   if (i0 >= pb.N || static_cast<int64_t>(blockIdx.x) * kEvalThreads >= pb.Nq) return;  // block-uniform
@@ -94,9 +101,11 @@ struct FinishProblem {
   int nchunks;
 };
 
+struct FinishBatch { FinishProblem p[KDEHIP_MAX_DIMS]; };
+
 // p[q] = (sum over chunks, in chunk order) / norm [/ (1 - w_q)]   (src/DualTree01.jl:325-340)
-__global__ void eval_finish_kernel(const FinishProblem *__restrict__ problems, int loo) {
-  const FinishProblem pb = problems[blockIdx.y];
+__global__ void eval_finish_kernel(const FinishBatch batch, int loo) {
+  const FinishProblem &pb = batch.p[blockIdx.y];
   const int64_t q = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (q >= pb.Nq) return;
   double s = 0.0;
@@ -110,10 +119,10 @@ __global__ void eval_finish_kernel(const FinishProblem *__restrict__ problems, i
 // hpart[y][b] = sum over its queries of W_q * log(p_q)  (evalAvgLogL, src/DualTree01.jl:450-474;
 // a zero likelihood that carries weight makes the log-likelihood -Inf, :460-463).
 constexpr int kFinishThreads = 256;
-__global__ __launch_bounds__(kFinishThreads) void loo_entropy_kernel(const FinishProblem *__restrict__ problems,
+__global__ __launch_bounds__(kFinishThreads) void loo_entropy_kernel(const FinishBatch batch,
                                                                    double *__restrict__ hpart, int nblocks) {
   __shared__ double red[kFinishThreads];
-  const FinishProblem pb = problems[blockIdx.y];
+  const FinishProblem &pb = batch.p[blockIdx.y];
   const int64_t q = static_cast<int64_t>(blockIdx.x) * kFinishThreads + threadIdx.x;
   double term = 0.0;
   if (q < pb.Nq) {
@@ -134,14 +143,14 @@ __global__ __launch_bounds__(kFinishThreads) void loo_entropy_kernel(const Finis
 }
 
 template <int D>
-void launch_partial(const EvalProblem *d_problems, int nprob, int64_t maxNq, int64_t maxN, int loo,
+void launch_partial(const EvalBatch &d_problems, int nprob, int64_t maxNq, int64_t maxN, int loo,
                     hipStream_t st) {
   dim3 grid(static_cast<unsigned>((maxNq + kEvalThreads - 1) / kEvalThreads),
             static_cast<unsigned>((maxN + kEvalChunk - 1) / kEvalChunk), static_cast<unsigned>(nprob));
   hipLaunchKernelGGL((eval_partial_kernel<D>), grid, dim3(kEvalThreads), 0, st, d_problems, loo);
 }
 
-int launch_partial_dims(int D, const EvalProblem *d_problems, int nprob, int64_t maxNq, int64_t maxN, int loo,
+int launch_partial_dims(int D, const EvalBatch &d_problems, int nprob, int64_t maxNq, int64_t maxN, int loo,
                         hipStream_t st) {
   switch (D) {
     case 1: launch_partial<1>(d_problems, nprob, maxNq, maxN, loo, st); break;
@@ -202,13 +211,11 @@ extern "C" int kdehip_evaluate(const kdehip_density *bd, const double *pos, int6
   if (rc != KDEHIP_OK) return rc;
 
   const int nchunks = static_cast<int>((N + kEvalChunk - 1) / kEvalChunk);
-  DevBuf d_src, d_w, d_q, d_part, d_out, d_idx, d_prob, d_fin;
+  DevBuf d_src, d_w, d_q, d_part, d_out, d_idx;
   KDEHIP_CHECK(d_src.alloc(sizeof(double) * N * D));
   KDEHIP_CHECK(d_w.alloc(sizeof(double) * N));
   KDEHIP_CHECK(d_part.alloc(sizeof(double) * nchunks * Nq));
   KDEHIP_CHECK(d_out.alloc(sizeof(double) * Nq));
-  KDEHIP_CHECK(d_prob.alloc(sizeof(EvalProblem)));
-  KDEHIP_CHECK(d_fin.alloc(sizeof(FinishProblem)));
   KDEHIP_CHECK(hipMemcpy(d_src.p, leaf_pts, sizeof(double) * N * D, hipMemcpyHostToDevice));
   KDEHIP_CHECK(hipMemcpy(d_w.p, bd->weights + N, sizeof(double) * N, hipMemcpyHostToDevice));
   std::vector<int64_t> idx;
@@ -221,21 +228,21 @@ extern "C" int kdehip_evaluate(const kdehip_density *bd, const double *pos, int6
     KDEHIP_CHECK(d_q.alloc(sizeof(double) * Nq * D));
     KDEHIP_CHECK(hipMemcpy(d_q.p, pos, sizeof(double) * Nq * D, hipMemcpyHostToDevice));
   }
-  EvalProblem pb{};
+  EvalBatch eb{};
+  FinishBatch fb{};
+  EvalProblem &pb = eb.p[0];
   pb.src = d_src.as<double>(); pb.w = d_w.as<double>();
   pb.qry = leave_one_out ? d_src.as<double>() : d_q.as<double>();
   pb.partial = d_part.as<double>(); pb.N = N; pb.Nq = Nq;
   for (int k = 0; k < D; ++k) pb.nhib[k] = -0.5 / bw[k];
-  FinishProblem fp{};
+  FinishProblem &fp = fb.p[0];
   fp.partial = d_part.as<double>(); fp.w = d_w.as<double>();
   fp.out_idx = leave_one_out ? d_idx.as<int64_t>() : nullptr;
   fp.out = d_out.as<double>(); fp.inv_norm = 1.0 / gauss_norm(bw, D); fp.Nq = Nq; fp.nchunks = nchunks;
-  KDEHIP_CHECK(hipMemcpy(d_prob.p, &pb, sizeof(pb), hipMemcpyHostToDevice));
-  KDEHIP_CHECK(hipMemcpy(d_fin.p, &fp, sizeof(fp), hipMemcpyHostToDevice));
-  rc = launch_partial_dims(D, d_prob.as<EvalProblem>(), 1, Nq, N, leave_one_out ? 1 : 0, nullptr);
+  rc = launch_partial_dims(D, eb, 1, Nq, N, leave_one_out ? 1 : 0, nullptr);
   if (rc != KDEHIP_OK) return rc;
   hipLaunchKernelGGL(eval_finish_kernel, dim3(static_cast<unsigned>((Nq + 255) / 256), 1), dim3(256), 0, nullptr,
-                     d_fin.as<FinishProblem>(), leave_one_out ? 1 : 0);
+                     fb, leave_one_out ? 1 : 0);
   KDEHIP_CHECK(hipGetLastError());
   KDEHIP_CHECK(hipDeviceSynchronize());
   KDEHIP_CHECK(hipMemcpy(p_out, d_out.p, sizeof(double) * Nq, hipMemcpyDeviceToHost));
@@ -289,13 +296,16 @@ extern "C" int kdehip_auto_bandwidth(int64_t D64, int64_t N, const double *point
   const int D = static_cast<int>(D64);
   int rc = use_device(device);
   if (rc != KDEHIP_OK) return rc;
+  const bool timing = std::getenv("KDEHIP_TIMING") != nullptr;
+  auto tnow = [] { return std::chrono::steady_clock::now(); };
+  auto t_begin = tnow();
 
   // Per dimension d: the marginal's tree ranges give neighborMinMax; the search density is
   // kde!(x_d, (minm+maxm)/2) (ksize, src/CrossValidation.jl:110-120).  The GPU evaluates the
   // leave-one-out likelihood over the points in their ORIGINAL order (the tree order only fixes the
   // reference's summation order), so no tree is built here.
   std::vector<Golden> g(D);
-  std::vector<double> xo(static_cast<size_t>(D) * N), wts(static_cast<size_t>(D) * N), xs(N);
+  std::vector<double> xo(static_cast<size_t>(D) * N), wts(static_cast<size_t>(D) * N);
   {
     // weights: ones -> /N (kde!(points,[1.0])) -> renormalised by the marginal's kde! (src/KDE01.jl:46,152)
     std::vector<double> w0(N), w1(N);
@@ -303,7 +313,9 @@ extern "C" int kdehip_auto_bandwidth(int64_t D64, int64_t N, const double *point
     double t = 0.0;
     for (int64_t i = 0; i < N; ++i) t += w0[i];
     for (int64_t i = 0; i < N; ++i) w1[i] = w0[i] / t;
-    for (int d = 0; d < D; ++d) {
+    // the D marginals are independent: one host thread each (the sort dominates this phase)
+    auto prep = [&](int d) {
+      std::vector<double> xs(static_cast<size_t>(N));
       for (int64_t i = 0; i < N; ++i) {
         xo[static_cast<size_t>(d) * N + i] = points[i * D + d];
         wts[static_cast<size_t>(d) * N + i] = w1[i];
@@ -323,24 +335,38 @@ extern "C" int kdehip_auto_bandwidth(int64_t D64, int64_t N, const double *point
       if (std::fabs(cx - bx) > std::fabs(bx - ax)) { s.x1 = bx; s.x2 = bx + C * (cx - bx); }
       else { s.x1 = bx - C * (bx - ax); s.x2 = bx; }
       s.phase = 0; s.nevals = 0; s.pending = 0; s.alpha = 0; s.f1 = s.f2 = 0; s.result = 0;
+    };
+    if (D > 1 && N >= 512) {
+      std::vector<std::thread> th;
+      for (int d = 1; d < D; ++d) th.emplace_back(prep, d);
+      prep(0);
+      for (auto &t2 : th) t2.join();
+    } else {
+      for (int d = 0; d < D; ++d) prep(d);
     }
   }
 
+  auto t_host = tnow();
   const int nchunks = static_cast<int>((N + kEvalChunk - 1) / kEvalChunk);
   const int nfb = static_cast<int>((N + kFinishThreads - 1) / kFinishThreads);
-  DevBuf d_x, d_w, d_part, d_prob, d_fin, d_h;
+  DevBuf d_x, d_w, d_part;
   KDEHIP_CHECK(d_x.alloc(sizeof(double) * D * N));
   KDEHIP_CHECK(d_w.alloc(sizeof(double) * D * N));
   KDEHIP_CHECK(d_part.alloc(sizeof(double) * D * nchunks * N));
-  KDEHIP_CHECK(d_prob.alloc(sizeof(EvalProblem) * D));
-  KDEHIP_CHECK(d_fin.alloc(sizeof(FinishProblem) * D));
-  KDEHIP_CHECK(d_h.alloc(sizeof(double) * D * nfb));
+  // the per-round result (D x nfb partial log-likelihoods) is written by the kernel straight into
+  // pinned host memory: no device buffer, no copy, one stream synchronisation per round
+  struct Pinned {
+    double *p = nullptr;
+    ~Pinned() { if (p) (void)hipHostFree(p); }
+  } h_pin;
+  KDEHIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&h_pin.p), sizeof(double) * D * nfb, hipHostMallocDefault));
   KDEHIP_CHECK(hipMemcpy(d_x.p, xo.data(), sizeof(double) * D * N, hipMemcpyHostToDevice));
   KDEHIP_CHECK(hipMemcpy(d_w.p, wts.data(), sizeof(double) * D * N, hipMemcpyHostToDevice));
 
-  std::vector<EvalProblem> probs(D);
-  std::vector<FinishProblem> fins(D);
-  std::vector<double> h_host(static_cast<size_t>(D) * nfb);
+  auto t_upload = tnow();
+  int rounds = 0;
+  EvalBatch eb{};
+  FinishBatch fb{};
   const double C = (3.0 - std::sqrt(5.0)) / 2.0, R = 1.0 - C;
   const double tol = 1e-2;  // ksize, src/CrossValidation.jl:116
 
@@ -364,6 +390,7 @@ extern "C" int kdehip_auto_bandwidth(int64_t D64, int64_t N, const double *point
       active.push_back(d);
     }
     if (active.empty()) break;
+    ++rounds;
     // nLOO_LL (src/CrossValidation.jl:15-24): bandwidth *= alpha^2 for the evaluation, /= alpha^2 after
     const int na = static_cast<int>(active.size());
     std::vector<double> a2(na), bw_eval(na);
@@ -371,7 +398,7 @@ extern "C" int kdehip_auto_bandwidth(int64_t D64, int64_t N, const double *point
       const int d = active[a];
       a2[a] = g[d].alpha * g[d].alpha;
       bw_eval[a] = g[d].bcur * a2[a];
-      EvalProblem &pb = probs[a];
+      EvalProblem &pb = eb.p[a];
       std::memset(&pb, 0, sizeof(pb));
       pb.src = d_x.as<double>() + static_cast<size_t>(d) * N;
       pb.qry = pb.src;
@@ -379,20 +406,19 @@ extern "C" int kdehip_auto_bandwidth(int64_t D64, int64_t N, const double *point
       pb.partial = d_part.as<double>() + static_cast<size_t>(d) * nchunks * N;
       pb.nhib[0] = -0.5 / bw_eval[a];
       pb.N = N; pb.Nq = N;
-      FinishProblem &fp = fins[a];
+      FinishProblem &fp = fb.p[a];
       std::memset(&fp, 0, sizeof(fp));
       fp.partial = pb.partial; fp.w = pb.w;
       fp.inv_norm = 1.0 / gauss_norm(&bw_eval[a], 1);
       fp.Nq = N; fp.nchunks = nchunks;
     }
-    KDEHIP_CHECK(hipMemcpyAsync(d_prob.p, probs.data(), sizeof(EvalProblem) * na, hipMemcpyHostToDevice, nullptr));
-    KDEHIP_CHECK(hipMemcpyAsync(d_fin.p, fins.data(), sizeof(FinishProblem) * na, hipMemcpyHostToDevice, nullptr));
-    rc = launch_partial_dims(1, d_prob.as<EvalProblem>(), na, N, N, 1, nullptr);
+    rc = launch_partial_dims(1, eb, na, N, N, 1, nullptr);
     if (rc != KDEHIP_OK) return rc;
     hipLaunchKernelGGL(loo_entropy_kernel, dim3(static_cast<unsigned>(nfb), static_cast<unsigned>(na)),
-                       dim3(kFinishThreads), 0, nullptr, d_fin.as<FinishProblem>(), d_h.as<double>(), nfb);
+                       dim3(kFinishThreads), 0, nullptr, fb, h_pin.p, nfb);
     KDEHIP_CHECK(hipGetLastError());
-    KDEHIP_CHECK(hipMemcpy(h_host.data(), d_h.p, sizeof(double) * na * nfb, hipMemcpyDeviceToHost));
+    KDEHIP_CHECK(hipStreamSynchronize(nullptr));
+    const double *h_host = h_pin.p;
     for (int a = 0; a < na; ++a) {
       const int d = active[a];
       Golden &s = g[d];
@@ -412,5 +438,10 @@ extern "C" int kdehip_auto_bandwidth(int64_t D64, int64_t N, const double *point
     total += g[d].nevals;
   }
   if (nevals_out) *nevals_out = total;
+  if (timing) {
+    auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+    std::fprintf(stderr, "kdehip_auto_bandwidth D=%d N=%lld: host prep %.0f us, alloc+upload %.0f us, %d rounds %.0f us\n", D,
+                 static_cast<long long>(N), us(t_begin, t_host), us(t_host, t_upload), rounds, us(t_upload, tnow()));
+  }
   return KDEHIP_OK;
 }
