@@ -20,6 +20,7 @@
 #include <thread>
 #include <vector>
 
+#include "fastexp.hpp"
 #include "kdehip_internal.hpp"
 
 namespace kdehip {
@@ -61,6 +62,8 @@ struct EvalBatch { EvalProblem p[KDEHIP_MAX_DIMS]; };
 template <int D>
 __global__ __launch_bounds__(kEvalThreads) void eval_partial_kernel(const EvalBatch batch, int loo) {
   __shared__ double sSrc[kEvalChunk * (D + 1)];
+  __shared__ double sExpTab[32];
+  if (threadIdx.x < 32) sExpTab[threadIdx.x] = kExp2Tab[threadIdx.x];
   const EvalProblem &pb = batch.p[blockIdx.z];
   const int64_t q = static_cast<int64_t>(blockIdx.x) * kEvalThreads + threadIdx.x;
   const int64_t i0 = static_cast<int64_t>(blockIdx.y) * kEvalChunk;
@@ -84,7 +87,7 @@ __global__ __launch_bounds__(kEvalThreads) void eval_partial_kernel(const EvalBa
       const double d = x[k] - s[k];
       acc = fma(d * d, pb.nhib[k], acc);
     }
-    double v = s[D] * exp(acc);
+    double v = s[D] * exp_nonpos(acc, sExpTab);  // acc <= 0
     if (loo && i0 + i == q) v = 0.0;  // leave-one-out: skip the self term (:141)
     sum += v;
   }
