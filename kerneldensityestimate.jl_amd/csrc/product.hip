@@ -21,6 +21,7 @@ struct kdehip_product {
   int mode = kModeFast;
   int variant = 0;
   PackedProduct host;  // descriptors (payload vectors are released after upload)
+  void *d_blob = nullptr;   // the one device allocation of the plan; the pointers below point into it
   void *d_data = nullptr;
   int32_t *d_perm = nullptr;
   LevelDesc *d_levels = nullptr;
@@ -28,6 +29,9 @@ struct kdehip_product {
   TabDesc *d_tabdesc = nullptr;
   bool tables_built = false;
   std::mutex tables_mutex;  // concurrent first runs on one plan build the tables once
+  void *d_work = nullptr;   // scratch of the host-buffer entry points (outputs / uploaded streams), grown on demand
+  size_t work_cap = 0;
+  std::mutex work_mutex;    // host-buffer calls on one plan are serialised
   int64_t packed_bytes = 0;
   PlanDev dev{};
 };
@@ -53,13 +57,6 @@ int use_device(int device) {
     return set_error(KDEHIP_ERR_NO_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e));
   return KDEHIP_OK;
 }
-
-// RAII device buffer for the host-pointer convenience paths
-struct DevBuf {
-  void *p = nullptr;
-  ~DevBuf() { if (p) (void)hipFree(p); }
-  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
-};
 
 int check_run(const kdehip_product *plan, int64_t Np, int Niter, const void *d_points,
               const void *d_indices) {
@@ -94,6 +91,18 @@ int maybe_build_tables(kdehip_product *plan, int64_t Np, RunArgs &a, void *strea
   return KDEHIP_OK;
 }
 
+// Scratch of the host-buffer entry points: one device buffer per plan, grown on demand (no per-call
+// hipMalloc / hipFree once it is large enough).  Callers hold plan->work_mutex.
+int reserve_work(kdehip_product *plan, size_t bytes) {
+  if (bytes <= plan->work_cap) return KDEHIP_OK;
+  if (plan->d_work) { (void)hipFree(plan->d_work); plan->d_work = nullptr; plan->work_cap = 0; }
+  const size_t cap = (bytes + (bytes >> 2) + 4095) & ~static_cast<size_t>(4095);
+  KDEHIP_CHECK(hipMalloc(&plan->d_work, cap));
+  plan->work_cap = cap;
+  return KDEHIP_OK;
+}
+inline size_t align256(size_t x) { return (x + 255) & ~static_cast<size_t>(255); }
+
 }  // namespace
 
 extern "C" {
@@ -122,42 +131,46 @@ int kdehip_product_create(kdehip_product **out, int Ndens, const kdehip_density 
   p->fast = p->host.fast;
   p->mode = !p->host.fast ? kModeGeneric : (p->host.all_active ? kModeFast : kModeFastMasked);
 
+  // One device allocation and one upload per plan (hipMalloc / hipFree cost tens of microseconds each and
+  // dominate a one-shot small product): [levels | table descriptors | permutation | tiles | tables], the
+  // table region is filled later by the table-build launch.
   const size_t nelem = p->host.data.size();
   const size_t esz = (precision == 64) ? sizeof(double) : sizeof(float);
   const size_t nperm = p->host.perm.size();
   const size_t nlev = p->host.levels.size();
-  auto fail = [&](hipError_t e, const char *what) {
-    std::string m = std::string(what) + ": " + hipGetErrorString(e);
-    kdehip_product_destroy(p);
-    return set_error(KDEHIP_ERR_HIP, m);
-  };
-  hipError_t e;
-  if ((e = hipMalloc(&p->d_data, nelem * esz)) != hipSuccess) return fail(e, "hipMalloc(data)");
-  if ((e = hipMalloc(reinterpret_cast<void **>(&p->d_perm), nperm * sizeof(int32_t))) != hipSuccess)
-    return fail(e, "hipMalloc(perm)");
-  if ((e = hipMalloc(reinterpret_cast<void **>(&p->d_levels), nlev * sizeof(LevelDesc))) != hipSuccess)
-    return fail(e, "hipMalloc(levels)");
-  if (precision == 64) {
-    e = hipMemcpy(p->d_data, p->host.data.data(), nelem * esz, hipMemcpyHostToDevice);
-  } else {
-    std::vector<float> f(nelem);
-    for (size_t i = 0; i < nelem; ++i) f[i] = static_cast<float>(p->host.data[i]);
-    e = hipMemcpy(p->d_data, f.data(), nelem * esz, hipMemcpyHostToDevice);
-  }
-  if (e != hipSuccess) return fail(e, "hipMemcpy(data)");
-  if ((e = hipMemcpy(p->d_perm, p->host.perm.data(), nperm * sizeof(int32_t), hipMemcpyHostToDevice)) != hipSuccess)
-    return fail(e, "hipMemcpy(perm)");
-  if ((e = hipMemcpy(p->d_levels, p->host.levels.data(), nlev * sizeof(LevelDesc), hipMemcpyHostToDevice)) != hipSuccess)
-    return fail(e, "hipMemcpy(levels)");
   const size_t ntab = p->host.tabdesc.size();
   const size_t tab_bytes = static_cast<size_t>(p->host.tab_entries) * esz;
-  if ((e = hipMalloc(reinterpret_cast<void **>(&p->d_tabdesc), ntab * sizeof(TabDesc))) != hipSuccess)
-    return fail(e, "hipMalloc(tabdesc)");
-  if ((e = hipMemcpy(p->d_tabdesc, p->host.tabdesc.data(), ntab * sizeof(TabDesc), hipMemcpyHostToDevice)) != hipSuccess)
-    return fail(e, "hipMemcpy(tabdesc)");
-  if (tab_bytes && (e = hipMalloc(&p->d_tables, tab_bytes)) != hipSuccess) return fail(e, "hipMalloc(tables)");
-  p->packed_bytes = static_cast<int64_t>(nelem * esz + nperm * sizeof(int32_t) + nlev * sizeof(LevelDesc) +
-                                         ntab * sizeof(TabDesc) + tab_bytes);
+  auto align = [](size_t x) { return (x + 255) & ~static_cast<size_t>(255); };
+  const size_t off_lev = 0;
+  const size_t off_tab = align(off_lev + nlev * sizeof(LevelDesc));
+  const size_t off_perm = align(off_tab + ntab * sizeof(TabDesc));
+  const size_t off_data = align(off_perm + nperm * sizeof(int32_t));
+  const size_t off_tables = align(off_data + nelem * esz);
+  const size_t total = off_tables + tab_bytes;
+  std::vector<unsigned char> blob(off_tables, 0);
+  std::memcpy(blob.data() + off_lev, p->host.levels.data(), nlev * sizeof(LevelDesc));
+  std::memcpy(blob.data() + off_tab, p->host.tabdesc.data(), ntab * sizeof(TabDesc));
+  std::memcpy(blob.data() + off_perm, p->host.perm.data(), nperm * sizeof(int32_t));
+  if (precision == 64) {
+    std::memcpy(blob.data() + off_data, p->host.data.data(), nelem * esz);
+  } else {
+    float *f = reinterpret_cast<float *>(blob.data() + off_data);
+    for (size_t i = 0; i < nelem; ++i) f[i] = static_cast<float>(p->host.data[i]);
+  }
+  hipError_t e = hipMalloc(&p->d_blob, total);
+  if (e == hipSuccess) e = hipMemcpy(p->d_blob, blob.data(), off_tables, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    const std::string m = std::string("plan upload: ") + hipGetErrorString(e);
+    kdehip_product_destroy(p);
+    return set_error(KDEHIP_ERR_HIP, m);
+  }
+  unsigned char *base = static_cast<unsigned char *>(p->d_blob);
+  p->d_levels = reinterpret_cast<LevelDesc *>(base + off_lev);
+  p->d_tabdesc = reinterpret_cast<TabDesc *>(base + off_tab);
+  p->d_perm = reinterpret_cast<int32_t *>(base + off_perm);
+  p->d_data = base + off_data;
+  p->d_tables = tab_bytes ? base + off_tables : nullptr;
+  p->packed_bytes = static_cast<int64_t>(total);
   std::vector<double>().swap(p->host.data);
   std::vector<int32_t>().swap(p->host.perm);
 
@@ -178,11 +191,8 @@ int kdehip_product_create(kdehip_product **out, int Ndens, const kdehip_density 
 void kdehip_product_destroy(kdehip_product *plan) {
   if (!plan) return;
   if (hipSetDevice(plan->device) == hipSuccess) {
-    if (plan->d_data) (void)hipFree(plan->d_data);
-    if (plan->d_perm) (void)hipFree(plan->d_perm);
-    if (plan->d_levels) (void)hipFree(plan->d_levels);
-    if (plan->d_tables) (void)hipFree(plan->d_tables);
-    if (plan->d_tabdesc) (void)hipFree(plan->d_tabdesc);
+    if (plan->d_blob) (void)hipFree(plan->d_blob);
+    if (plan->d_work) (void)hipFree(plan->d_work);
   }
   delete plan;
 }
@@ -272,18 +282,21 @@ int kdehip_product_sample_philox_host(kdehip_product *plan, int64_t Np, int Nite
   if (Np == 0) return KDEHIP_OK;
   KDEHIP_CHECK(hipSetDevice(plan->device));
   const size_t D = plan->host.D, M = plan->host.M, L = plan->host.L;
-  DevBuf dp, di, dl;
-  KDEHIP_CHECK(dp.alloc(sizeof(double) * D * Np));
-  KDEHIP_CHECK(di.alloc(sizeof(int64_t) * M * Np));
-  if (labels) KDEHIP_CHECK(dl.alloc(sizeof(int32_t) * M * L * Np));
-  rc = kdehip_product_sample_philox(plan, Np, Niter, seed, sample_offset, addEntropy,
-                                    static_cast<double *>(dp.p), static_cast<int64_t *>(di.p),
-                                    labels ? static_cast<int32_t *>(dl.p) : nullptr, nullptr);
+  std::lock_guard<std::mutex> lock(plan->work_mutex);
+  const size_t off_i = align256(sizeof(double) * D * Np);
+  const size_t off_l = align256(off_i + sizeof(int64_t) * M * Np);
+  rc = reserve_work(plan, off_l + (labels ? sizeof(int32_t) * M * L * Np : 0));
   if (rc != KDEHIP_OK) return rc;
-  KDEHIP_CHECK(hipDeviceSynchronize());
-  KDEHIP_CHECK(hipMemcpy(points, dp.p, sizeof(double) * D * Np, hipMemcpyDeviceToHost));
-  KDEHIP_CHECK(hipMemcpy(indices, di.p, sizeof(int64_t) * M * Np, hipMemcpyDeviceToHost));
-  if (labels) KDEHIP_CHECK(hipMemcpy(labels, dl.p, sizeof(int32_t) * M * L * Np, hipMemcpyDeviceToHost));
+  unsigned char *w = static_cast<unsigned char *>(plan->d_work);
+  double *dp = reinterpret_cast<double *>(w);
+  int64_t *di = reinterpret_cast<int64_t *>(w + off_i);
+  int32_t *dl = labels ? reinterpret_cast<int32_t *>(w + off_l) : nullptr;
+  rc = kdehip_product_sample_philox(plan, Np, Niter, seed, sample_offset, addEntropy, dp, di, dl, nullptr);
+  if (rc != KDEHIP_OK) return rc;
+  // (the blocking copies on the null stream wait for the kernel)
+  KDEHIP_CHECK(hipMemcpy(points, dp, sizeof(double) * D * Np, hipMemcpyDeviceToHost));
+  KDEHIP_CHECK(hipMemcpy(indices, di, sizeof(int64_t) * M * Np, hipMemcpyDeviceToHost));
+  if (labels) KDEHIP_CHECK(hipMemcpy(labels, dl, sizeof(int32_t) * M * L * Np, hipMemcpyDeviceToHost));
   return KDEHIP_OK;
 }
 
@@ -305,21 +318,22 @@ int kdehip_gibbs1(int Ndens, const kdehip_density *trees, int64_t Np, int Niter,
     return set_error(KDEHIP_ERR_RAND_SHORT, "randN shorter than Np*R values (Julia: BoundsError)");
   const size_t D = ndims, M = Ndens;
   const int64_t useU = (nU < Np * K) ? nU : Np * K, useN = Np * R;
-  DevBuf du, dn, dp, di;
-  KDEHIP_CHECK(du.alloc(sizeof(double) * useU));
-  KDEHIP_CHECK(dn.alloc(sizeof(double) * useN));
-  KDEHIP_CHECK(dp.alloc(sizeof(double) * D * Np));
-  KDEHIP_CHECK(di.alloc(sizeof(int64_t) * M * Np));
-  KDEHIP_CHECK(hipMemcpy(du.p, randU, sizeof(double) * useU, hipMemcpyHostToDevice));
-  KDEHIP_CHECK(hipMemcpy(dn.p, randN, sizeof(double) * useN, hipMemcpyHostToDevice));
-  rc = kdehip_product_sample_streams(plan, Np, Niter, static_cast<const double *>(du.p), useU,
-                                     static_cast<const double *>(dn.p), useN, addEntropy,
-                                     static_cast<double *>(dp.p), static_cast<int64_t *>(di.p),
-                                     nullptr, nullptr);
+  std::lock_guard<std::mutex> lock(plan->work_mutex);
+  const size_t off_n = align256(sizeof(double) * useU);
+  const size_t off_p = align256(off_n + sizeof(double) * useN);
+  const size_t off_i = align256(off_p + sizeof(double) * D * Np);
+  rc = reserve_work(plan, off_i + sizeof(int64_t) * M * Np);
   if (rc != KDEHIP_OK) return rc;
-  KDEHIP_CHECK(hipDeviceSynchronize());
-  KDEHIP_CHECK(hipMemcpy(pts, dp.p, sizeof(double) * D * Np, hipMemcpyDeviceToHost));
-  KDEHIP_CHECK(hipMemcpy(ind, di.p, sizeof(int64_t) * M * Np, hipMemcpyDeviceToHost));
+  unsigned char *w = static_cast<unsigned char *>(plan->d_work);
+  double *du = reinterpret_cast<double *>(w), *dn = reinterpret_cast<double *>(w + off_n);
+  double *dp = reinterpret_cast<double *>(w + off_p);
+  int64_t *di = reinterpret_cast<int64_t *>(w + off_i);
+  KDEHIP_CHECK(hipMemcpy(du, randU, sizeof(double) * useU, hipMemcpyHostToDevice));
+  KDEHIP_CHECK(hipMemcpy(dn, randN, sizeof(double) * useN, hipMemcpyHostToDevice));
+  rc = kdehip_product_sample_streams(plan, Np, Niter, du, useU, dn, useN, addEntropy, dp, di, nullptr, nullptr);
+  if (rc != KDEHIP_OK) return rc;
+  KDEHIP_CHECK(hipMemcpy(pts, dp, sizeof(double) * D * Np, hipMemcpyDeviceToHost));
+  KDEHIP_CHECK(hipMemcpy(ind, di, sizeof(int64_t) * M * Np, hipMemcpyDeviceToHost));
   return KDEHIP_OK;
 }
 
