@@ -195,6 +195,14 @@ def main():
                          "kernel": "gibbs_product_kernel", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "working set is cache-resident: normalised throughput vs HBM peak, not DRAM traffic"},
+            # second view of the same kernel: the path is bound by the fp64 vector pipe, not by HBM.  Algorithmic
+            # flops per kernel evaluation = 6D+4; 78.6 TFLOP/s = MI355X fp64 vector peak (fp32: 157.3).
+            "compute": {"bound": "valu", "flops_per_eval": 6 * D + 4,
+                        "achieved": Nout * E * (6 * D + 4) / (kern_ms * 1e-3) / 1e12,
+                        "peak": 78.6 if prec == 64 else 157.3, "unit": "TFLOP/s",
+                        "frac": Nout * E * (6 * D + 4) / (kern_ms * 1e-3) / 1e12 / (78.6 if prec == 64 else 157.3),
+                        "note": "algorithmic flops only (exp, rsqrt, scans, selection not counted); measured VALU pipe "
+                                "utilisation is in profiles/*_rocprof_summary.md"},
             "kernel_samples_per_sec": Nout / (kern_ms * 1e-3),
             "fast_math_path": plan.fast_math_path,
         }
