@@ -8,7 +8,9 @@
  *
  * Pinning status (see DESIGN.md "Oracle"):
  *   - tree / density layout (okde_make_density): PINNED against the reference's own golden files
- *     test/testdata/test1DResult.txt, test2DResult.txt, test2DvarResult.txt (tests/golden/).
+ *     test/testdata/test1DResult.txt, test2DResult.txt, test2DvarResult.txt, and the 100-point
+ *     structures test1Dlcv100Result.txt, test2Dlcv100Result.txt, test2Dvarlcv100Result.txt
+ *     (tests/golden/).
  *   - Gibbs arithmetic (okde_gibbs1): PARITY UNPINNED by any golden vector -- the reference holds
  *     none for this path and Julia is not available here to run it.  It is constrained only by the
  *     reference's statistical acceptance tests (test/runtests.jl:167-201, test/testPartialProd.jl)

@@ -54,6 +54,13 @@ def test_product_tree_builder_matches_reference_goldens(golden_dir):
     x = np.loadtxt(os.path.join(golden_dir, "test1Dlcv100.txt")).ravel()
     d = kdehip.kde(x, [np.sqrt(gold["bandwidth"][100])])
     check_density_against_golden(_Flat(d), gold, 1e-4)
+    # 2-D, 100 points (goldens of the reference's disabled UnitTest2Dlcv01 / UnitTest2Dvarlcv01, runtests.jl:131-141,
+    # :155-165): bandwidth taken from the golden, tree + statistics reproduced at the reference's own tolerances
+    for name, tol in (("test2Dlcv100", 1e-4), ("test2Dvarlcv100", 2e-3)):
+        gold = parse_mat_print_kde(os.path.join(golden_dir, name + "Result.txt"))
+        pts = np.ascontiguousarray(np.loadtxt(os.path.join(golden_dir, name + ".txt")).T)
+        d = kdehip.kde(pts, np.sqrt(gold["bandwidth"][200:202]))
+        check_density_against_golden(_Flat(d), gold, tol)
 
 
 @pytest.mark.parametrize("D,N,weighted", [(1, 1, False), (1, 2, False), (1, 7, True), (2, 33, False),
