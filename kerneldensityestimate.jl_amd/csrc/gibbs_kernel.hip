@@ -48,6 +48,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <type_traits>
 
 #include "fastexp.hpp"
 #include "kdehip_internal.hpp"
@@ -154,18 +155,28 @@ template <typename T, int D>
 struct EvalUniform {
   T center[D], ninv[D], scale;
   const double *tab;
+  struct Row { T m[D], w; };  // the fields of one entry, in registers
   template <typename P>
-  __device__ __forceinline__ T operator()(P e) const {
+  __device__ __forceinline__ Row load(P e) const {
+    Row r;
+#pragma unroll
+    for (int d = 0; d < D; ++d) r.m[d] = e[d * 64];
+    r.w = e[D * 64];
+    return r;
+  }
+  __device__ __forceinline__ T operator()(const Row &r) const {
     T acc = T(0);
 #pragma unroll
     for (int d = 0; d < D; ++d) {
-      const T dl = e[d * 64] - center[d];
+      const T dl = r.m[d] - center[d];
       acc = Num<T>::fma(dl * dl, ninv[d], acc);
     }
     // (no per-entry NaN test: on the fast paths every tile value is finite and positive, so a NaN can
     // only come from the wave-uniform centre/cov and then hits every entry -- handled on the total)
-    return (e[D * 64] * scale) * Num<T>::exp_fast(acc, tab);
+    return (r.w * scale) * Num<T>::exp_fast(acc, tab);
   }
+  template <typename P>
+  __device__ __forceinline__ T operator()(P e) const { return (*this)(load(e)); }
 };
 
 // FAST: per-node bandwidths; one rsqrt instead of D divides and D logs.
@@ -174,13 +185,21 @@ struct EvalFast {
   T center[D], cov[D];
   const double *tab;
   uint32_t act;  // MASKED: dimensions that take part (:282); an inactive one contributes c = 1, delta = 0
+  struct Row { T m[D], v[D], w; };
   template <typename P>
-  __device__ __forceinline__ T operator()(P e) const {
+  __device__ __forceinline__ Row load(P e) const {
+    Row r;
+#pragma unroll
+    for (int d = 0; d < D; ++d) { r.m[d] = e[d * 64]; r.v[d] = e[(D + d) * 64]; }
+    r.w = e[2 * D * 64];
+    return r;
+  }
+  __device__ __forceinline__ T operator()(const Row &row) const {
     T c[D], d2[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) {
-      c[d] = e[(D + d) * 64] + cov[d];
-      const T dl = e[d * 64] - center[d];
+      c[d] = row.v[d] + cov[d];
+      const T dl = row.m[d] - center[d];
       d2[d] = dl * dl;
       if constexpr (MASKED) {
         const bool on = (act >> d) & 1u;
@@ -188,7 +207,7 @@ struct EvalFast {
         d2[d] = on ? d2[d] : T(0);
       }
     }
-    const T w = e[2 * D * 64];
+    const T w = row.w;
     // pre[d]*suf[d] = prod_{k != d} c[k]; P = prod_k c[k]
     T pre[D], suf[D];
     pre[0] = T(1);
@@ -205,6 +224,8 @@ struct EvalFast {
     const T q = num * r * r;  // = sum_d delta_d^2 / c_d
     return (w * r) * Num<T>::exp_fast(T(-0.5) * q, tab);
   }
+  template <typename P>
+  __device__ __forceinline__ T operator()(P e) const { return (*this)(load(e)); }
 };
 
 // GENERIC: literally the reference's accumulation (:280-303) incl. inactive dimensions.
@@ -212,14 +233,22 @@ template <typename T, int D>
 struct EvalGeneric {
   T center[D], cov[D];
   uint32_t act;
+  struct Row { T m[D], v[D], w; };
   template <typename P>
-  __device__ __forceinline__ T operator()(P e) const {
+  __device__ __forceinline__ Row load(P e) const {
+    Row r;
+#pragma unroll
+    for (int d = 0; d < D; ++d) { r.m[d] = e[d * 64]; r.v[d] = e[(D + d) * 64]; }
+    r.w = e[2 * D * 64];
+    return r;
+  }
+  __device__ __forceinline__ T operator()(const Row &row) const {
     T acc = T(0);
 #pragma unroll
     for (int d = 0; d < D; ++d) {
       if ((act >> d) & 1u) {
-        const T c = e[(D + d) * 64] + cov[d];
-        const T dl = e[d * 64] - center[d];
+        const T c = row.v[d] + cov[d];
+        const T dl = row.m[d] - center[d];
         const T distr = (dl * dl) / c;
         if (distr == distr) {
           acc += distr;
@@ -227,9 +256,11 @@ struct EvalGeneric {
         }
       }
     }
-    const T p = Num<T>::exp(T(-0.5) * acc) * e[2 * D * 64];
+    const T p = Num<T>::exp(T(-0.5) * acc) * row.w;
     return (p != p) ? T(0) : p;
   }
+  template <typename P>
+  __device__ __forceinline__ T operator()(P e) const { return (*this)(load(e)); }
 };
 
 // ---- one categorical label draw over a frontier -------------------------------------------------
@@ -238,12 +269,38 @@ struct EvalGeneric {
 // (selectLabelOnLevel :330-351 applied to the CDF of makeFasterSampleIndex! :318-325).
 // `rows` points at row 0, field 0, lane 0 of the tile (LDS or global pointer type P).
 // pass 1 over rows held at `rows` (LDS or global): the lane's private sum over its contiguous entries
-template <typename T, typename P, typename Eval>
+template <typename P> constexpr bool kIsLdsPtr = false;
+template <typename T> constexpr bool kIsLdsPtr<const __attribute__((address_space(3))) T *> = true;
+
+template <typename T, typename P, typename Eval, bool PREFETCH = true>
 __device__ __forceinline__ T lane_sum_rows(P rows, int nrows, int RS, int lane, const Eval &ev) {
+  if constexpr (!PREFETCH) {
+    T S0 = T(0);
+    P e0 = rows + lane;
+#pragma unroll 2
+    for (int i = 0; i < nrows; ++i, e0 += RS) S0 += ev(e0);
+    return S0;
+  }
+  // software pipelined, two rows per trip with ping-pong register sets (no copies): the fields of the
+  // next row are requested before the current row is evaluated, so the LDS (or L2) round trip overlaps
+  // ~40-100 fp64 instructions instead of stalling in front of each of them.
   T S = T(0);
   P e = rows + lane;
-#pragma unroll 2
-  for (int i = 0; i < nrows; ++i, e += RS) S += ev(e);
+  typename Eval::Row ra = ev.load(e);
+  // LDS tiles: have row 0 landed before the loop, otherwise the compiler's wait-count bookkeeping merges
+  // "row 0 pending" into the loop head and waits for every prefetch right after issuing it
+  if constexpr (kIsLdsPtr<P>) __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) only
+  int i = 0;
+  for (; i + 2 <= nrows; i += 2) {
+    const typename Eval::Row rb = ev.load(e + RS);  // row i+1
+    __builtin_amdgcn_sched_barrier(0);              // keep the requests above the arithmetic
+    S += ev(ra);
+    e += (i + 2 < nrows) ? 2 * RS : RS;             // row i+2, or row i+1 again (never past the tile)
+    ra = ev.load(e);
+    __builtin_amdgcn_sched_barrier(0);
+    S += ev(rb);
+  }
+  if (i < nrows) S += ev(ra);
   return S;
 }
 
@@ -335,14 +392,14 @@ __device__ __forceinline__ int select_from_scan(T incl, T S, P rows, const Level
 }
 
 // whole tile readable through one pointer (resident / streamed LDS image, or global memory)
-template <typename T, typename P, typename Eval>
+template <typename T, typename P, bool PREFETCH, typename Eval>
 __device__ __forceinline__ int draw_label(P rows, const LevelDesc &ds, int lane, const Eval &ev, double u
 #ifdef KDEHIP_STAMPS
                                           , unsigned long long *stamp_acc, bool stamp_on
 #endif
 ) {
   KSTAMP(tp0);
-  const T S = lane_sum_rows<T, P>(rows, ds.B, ds.F * 64 + 1, lane, ev);
+  const T S = lane_sum_rows<T, P, Eval, PREFETCH>(rows, ds.B, ds.F * 64 + 1, lane, ev);
   KSTAMP(tp1);
   KSTAMP_ADD(2, tp0, tp1);
   return select_label<T, P>(S, rows, ds, lane, ev, u KSTAMP_ARGS);
@@ -404,6 +461,15 @@ template <typename T, int D, int MODE, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan, RunArgs a) {
   constexpr bool FAST = (MODE != kModeGeneric);      // product/rsqrt + uniform-bandwidth forms
   constexpr bool MASKED = (MODE == kModeFastMasked);  // ... with inactive dimensions
+  // pass 1 prefetches the next row's fields while it evaluates the current one; the 16-wavefront fp64
+  // builds have 128 VGPRs and would spill from D = 6 on
+#if defined(KDEHIP_NO_PREFETCH)
+  constexpr bool kPrefetchRows = false;
+#elif defined(KDEHIP_PREFETCH_ALL)
+  constexpr bool kPrefetchRows = true;
+#else
+  constexpr bool kPrefetchRows = (WAVES == 8) || sizeof(T) == 4;
+#endif
   using Lay = LdsLayout<T, D, WAVES>;
   __shared__ __attribute__((aligned(1024))) unsigned char smem[Lay::kBytes];
 
@@ -544,7 +610,7 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan,
     auto rows = hdr + kTileHeader;
     using P = decltype(rows);
     const int pos = (vflags & 8) ? 0 : draw(ds, hdr, mean, cov, [&](const auto &ev) {
-      return draw_label<T, P>(rows, ds, lane, ev, u KSTAMP_ARGS);
+      return draw_label<T, P, kPrefetchRows>(rows, ds, lane, ev, u KSTAMP_ARGS);
     });
     wave_sync();
     KSTAMP(ts1);
@@ -582,7 +648,8 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan,
         if (r0 + rc < ds.B) stage_chunk(ds, r0 + rc, (gchunk + 1) & 1);
         else if (has_next) stage_chunk(dn, 0, (gchunk + 1) & 1);
         const int nrows = (ds.B - r0 < rc) ? (ds.B - r0) : rc;
-        S += lane_sum_rows<T, LdsPtr<T>>((LdsPtr<T>)(pool + (gchunk & 1) * (kLdsPoolBytes / 2)), nrows, RS, lane, ev);
+        S += lane_sum_rows<T, LdsPtr<T>, std::decay_t<decltype(ev)>, kPrefetchRows>(
+            (LdsPtr<T>)(pool + (gchunk & 1) * (kLdsPoolBytes / 2)), nrows, RS, lane, ev);
       }
       return select_label<T, const T *>(S, hdr + kTileHeader, ds, lane, ev, u KSTAMP_ARGS);
     });
@@ -628,7 +695,7 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan,
     const T *hdr = data + ds.hdr_off;
     T *row = tables + td.off + static_cast<int64_t>(cfg) * (td.n + 1);
     draw(ds, hdr, mean, cov, [&](const auto &ev) {
-      const T S = lane_sum_rows<T, const T *>(hdr + kTileHeader, 1, ds.F * 64 + 1, lane, ev);
+      const T S = lane_sum_rows<T, const T *, std::decay_t<decltype(ev)>, false>(hdr + kTileHeader, 1, ds.F * 64 + 1, lane, ev);
       const T incl = wave_inclusive_scan(S);
       if (lane < td.n) row[lane] = incl;
       if (lane == 63) row[td.n] = incl;  // the total the selection reads from lane 63

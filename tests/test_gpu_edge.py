@@ -120,3 +120,43 @@ def test_runs_can_be_captured_in_a_hip_graph():
         torch.cuda.synchronize()
         assert np.array_equal(P.cpu().numpy().reshape(Np, D).T, ref_p)
         assert np.array_equal(I.cpu().numpy().reshape(Np, M).T, ref_i)
+
+
+def test_concurrent_calls_from_host_threads():
+    """SURVEY 8b "Threading": the blocking entry points are safe to call concurrently.  Eight host threads
+    run different one-shot products through kdehip_gibbs1 while four more share ONE resident plan;
+    every result must equal the oracle / the single-threaded result."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    cases = []
+    for t in range(8):
+        D, M, N = 1 + t % 4, 2 + t % 3, 30 + 37 * t
+        gp, op = _make_inputs(100 + t, D, M, N)
+        Np, Niter = 64 + 16 * t, 2 + t % 3
+        K, R, nU, nN = oracle.rng_sizes(M, D, Np, Niter, [N] * M)
+        rng = np.random.default_rng(t)
+        cases.append((gp, op, Np, Niter, rng.random(nU), rng.standard_normal(nN)))
+
+    def one_shot(c):
+        gp, op, Np, Niter, randU, randN = c
+        out = None
+        for _ in range(5):
+            out = kdehip.prodAppxMSGibbsS(None, gp, None, None, Niter=Niter, Np=Np, randU=randU, randN=randN)
+        return out
+
+    gp, _ = _make_inputs(9, 3, 4, 500)
+    plan = kdehip.ProductPlan(gp)
+    want = plan.sample(4096, 3, seed=5)
+
+    def shared_plan(i):
+        return [plan.sample(4096, 3, seed=5) for _ in range(5)][-1]
+
+    with ThreadPoolExecutor(max_workers=12) as ex:
+        f1 = [ex.submit(one_shot, c) for c in cases]
+        f2 = [ex.submit(shared_plan, i) for i in range(4)]
+        r1 = [f.result() for f in f1]
+        r2 = [f.result() for f in f2]
+    for c, g in zip(cases, r1):
+        _compare(g, oracle.gibbs1(c[1], c[2], c[3], c[4], c[5]))
+    for g in r2:
+        assert np.array_equal(g[0], want[0]) and np.array_equal(g[1], want[1])
