@@ -92,6 +92,17 @@ template <> struct Num<float> {
   static __device__ __forceinline__ float tiny_total() { return 1e-37f; }  // 1e-99 is not a float
 };
 
+// Two fp32 entries per lane in one register pair: gfx950 executes v_pk_add/mul/fma_f32 on both halves at
+// the rate of one scalar fp32 instruction, so the fp32 first pass evaluates the rows two at a time.
+typedef float kdehip_f2 __attribute__((ext_vector_type(2)));
+template <> struct Num<kdehip_f2> {
+  static __device__ __forceinline__ kdehip_f2 exp_fast(kdehip_f2 x, const double *) { return {__expf(x.x), __expf(x.y)}; }
+  static __device__ __forceinline__ kdehip_f2 rsqrt(kdehip_f2 x) { return {::rsqrtf(x.x), ::rsqrtf(x.y)}; }
+  static __device__ __forceinline__ kdehip_f2 fma(kdehip_f2 a, kdehip_f2 b, kdehip_f2 c) {
+    return __builtin_elementwise_fma(a, b, c);
+  }
+};
+
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_fetch(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
@@ -155,7 +166,8 @@ template <typename T, int D>
 struct EvalUniform {
   T center[D], ninv[D], scale;
   const double *tab;
-  struct Row { T m[D], w; };  // the fields of one entry, in registers
+  template <typename V> struct RowT { V m[D], w; };  // the fields of one entry (V = T) or of two (packed pair)
+  using Row = RowT<T>;
   template <typename P>
   __device__ __forceinline__ Row load(P e) const {
     Row r;
@@ -164,19 +176,30 @@ struct EvalUniform {
     r.w = e[D * 64];
     return r;
   }
-  __device__ __forceinline__ T operator()(const Row &r) const {
-    T acc = T(0);
+  template <typename V>
+  __device__ __forceinline__ V eval(const RowT<V> &r) const {
+    V acc = V(0);
 #pragma unroll
     for (int d = 0; d < D; ++d) {
-      const T dl = r.m[d] - center[d];
-      acc = Num<T>::fma(dl * dl, ninv[d], acc);
+      const V dl = r.m[d] - center[d];
+      acc = Num<V>::fma(dl * dl, V(ninv[d]), acc);
     }
     // (no per-entry NaN test: on the fast paths every tile value is finite and positive, so a NaN can
     // only come from the wave-uniform centre/cov and then hits every entry -- handled on the total)
-    return (r.w * scale) * Num<T>::exp_fast(acc, tab);
+    return (r.w * scale) * Num<V>::exp_fast(acc, tab);
   }
+  __device__ __forceinline__ T operator()(const Row &r) const { return eval<T>(r); }
   template <typename P>
   __device__ __forceinline__ T operator()(P e) const { return (*this)(load(e)); }
+  static constexpr bool kPairs = true;
+  template <typename P>
+  __device__ __forceinline__ kdehip_f2 pair(P e, int RS) const {  // entries at e and e + RS
+    RowT<kdehip_f2> r;
+#pragma unroll
+    for (int d = 0; d < D; ++d) r.m[d] = kdehip_f2{e[d * 64], e[RS + d * 64]};
+    r.w = kdehip_f2{e[D * 64], e[RS + D * 64]};
+    return eval<kdehip_f2>(r);
+  }
 };
 
 // FAST: per-node bandwidths; one rsqrt instead of D divides and D logs.
@@ -185,7 +208,8 @@ struct EvalFast {
   T center[D], cov[D];
   const double *tab;
   uint32_t act;  // MASKED: dimensions that take part (:282); an inactive one contributes c = 1, delta = 0
-  struct Row { T m[D], v[D], w; };
+  template <typename V> struct RowT { V m[D], v[D], w; };
+  using Row = RowT<T>;
   template <typename P>
   __device__ __forceinline__ Row load(P e) const {
     Row r;
@@ -194,38 +218,52 @@ struct EvalFast {
     r.w = e[2 * D * 64];
     return r;
   }
-  __device__ __forceinline__ T operator()(const Row &row) const {
-    T c[D], d2[D];
+  template <typename V>
+  __device__ __forceinline__ V eval(const RowT<V> &row) const {
+    V c[D], d2[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) {
       c[d] = row.v[d] + cov[d];
-      const T dl = row.m[d] - center[d];
+      const V dl = row.m[d] - center[d];
       d2[d] = dl * dl;
       if constexpr (MASKED) {
         const bool on = (act >> d) & 1u;
-        c[d] = on ? c[d] : T(1);
-        d2[d] = on ? d2[d] : T(0);
+        c[d] = on ? c[d] : V(1);
+        d2[d] = on ? d2[d] : V(0);
       }
     }
-    const T w = row.w;
+    const V w = row.w;
     // pre[d]*suf[d] = prod_{k != d} c[k]; P = prod_k c[k]
-    T pre[D], suf[D];
-    pre[0] = T(1);
+    V pre[D], suf[D];
+    pre[0] = V(1);
 #pragma unroll
     for (int d = 1; d < D; ++d) pre[d] = pre[d - 1] * c[d - 1];
-    suf[D - 1] = T(1);
+    suf[D - 1] = V(1);
 #pragma unroll
     for (int d = D - 2; d >= 0; --d) suf[d] = suf[d + 1] * c[d + 1];
-    const T prod = pre[D - 1] * c[D - 1];
-    T num = T(0);
+    const V prod = pre[D - 1] * c[D - 1];
+    V num = V(0);
 #pragma unroll
-    for (int d = 0; d < D; ++d) num = Num<T>::fma(d2[d], pre[d] * suf[d], num);
-    const T r = Num<T>::rsqrt(prod);
-    const T q = num * r * r;  // = sum_d delta_d^2 / c_d
-    return (w * r) * Num<T>::exp_fast(T(-0.5) * q, tab);
+    for (int d = 0; d < D; ++d) num = Num<V>::fma(d2[d], pre[d] * suf[d], num);
+    const V r = Num<V>::rsqrt(prod);
+    const V q = num * r * r;  // = sum_d delta_d^2 / c_d
+    return (w * r) * Num<V>::exp_fast(V(-0.5) * q, tab);
   }
+  __device__ __forceinline__ T operator()(const Row &row) const { return eval<T>(row); }
   template <typename P>
   __device__ __forceinline__ T operator()(P e) const { return (*this)(load(e)); }
+  static constexpr bool kPairs = true;
+  template <typename P>
+  __device__ __forceinline__ kdehip_f2 pair(P e, int RS) const {  // entries at e and e + RS
+    RowT<kdehip_f2> r;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      r.m[d] = kdehip_f2{e[d * 64], e[RS + d * 64]};
+      r.v[d] = kdehip_f2{e[(D + d) * 64], e[RS + (D + d) * 64]};
+    }
+    r.w = kdehip_f2{e[2 * D * 64], e[RS + 2 * D * 64]};
+    return eval<kdehip_f2>(r);
+  }
 };
 
 // GENERIC: literally the reference's accumulation (:280-303) incl. inactive dimensions.
@@ -261,6 +299,7 @@ struct EvalGeneric {
   }
   template <typename P>
   __device__ __forceinline__ T operator()(P e) const { return (*this)(load(e)); }
+  static constexpr bool kPairs = false;
 };
 
 // ---- one categorical label draw over a frontier -------------------------------------------------
@@ -274,6 +313,21 @@ template <typename T> constexpr bool kIsLdsPtr<const __attribute__((address_spac
 
 template <typename T, typename P, typename Eval, bool PREFETCH = true>
 __device__ __forceinline__ T lane_sum_rows(P rows, int nrows, int RS, int lane, const Eval &ev) {
+#ifdef KDEHIP_NO_PAIRS  // A/B builds (scripts/ab_build.sh)
+  constexpr bool kUsePairs = false;
+#else
+  constexpr bool kUsePairs = sizeof(T) == 4 && Eval::kPairs;
+#endif
+  if constexpr (kUsePairs) {
+    // fp32: two rows per trip through the packed-math pipe (their 2F loads are in flight together)
+    kdehip_f2 S2 = {0.0f, 0.0f};
+    P e2 = rows + lane;
+    int i2 = 0;
+    for (; i2 + 2 <= nrows; i2 += 2, e2 += 2 * RS) S2 += ev.pair(e2, RS);
+    T Sp = S2.x + S2.y;
+    if (i2 < nrows) Sp += ev(e2);
+    return Sp;
+  }
   if constexpr (!PREFETCH) {
     T S0 = T(0);
     P e0 = rows + lane;
