@@ -102,6 +102,12 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
+    # The JSON line must be the only thing on stdout: RCCL prints a version banner through C stdio (flushed at
+    # exit, i.e. AFTER a Python print) and torchrun merges the stdout of all ranks.  File descriptor 1 points at
+    # stderr while the job runs and is restored on rank 0 only around the final print.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or os.environ.get("KDEHIP_FORCE_DIST") == "1"  # (the latter: 1-rank test of the RCCL path)
@@ -139,7 +145,9 @@ def main():
     stream = torch.cuda.current_stream(dev)
     lo, hi = (Np_total * rank) // world, (Np_total * (rank + 1)) // world
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    bufs = sp._buffers(Np_total)
+    # two buffer slots: the all-gather of step i (asynchronous collective on RCCL's stream) overlaps the kernel
+    # of step i+1; a slot is written again only after its previous gather has been waited for
+    slots = [sp._buffers(Np_total, 0), sp._buffers(Np_total, 1)]
 
     if use_dist:
         dist.barrier()
@@ -147,12 +155,20 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         base = (args.warmup + i) * Np_total
+        bufs = slots[i & 1]
+        if bufs["pending"] is not None:
+            bufs["pending"].wait()
+            bufs["pending"] = None
         ev[i][0].record(stream)
         plan.sample_philox_device(hi - lo, Niter, seed, base + lo, True, bufs["pts"], bufs["ind"], None,
                                   stream.cuda_stream)
         ev[i][1].record(stream)
         if use_dist:
-            sp.gather(bufs)  # the single all-gather of [pGM | labels]
+            bufs["pending"] = sp.gather(bufs, async_op=True)  # the single all-gather of [pGM | labels]
+    for bufs in slots:  # every product of the timed region is complete (gathered) before the clock stops
+        if bufs["pending"] is not None:
+            bufs["pending"].wait()
+            bufs["pending"] = None
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -208,9 +224,15 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out.update(cpu_baseline_and_parity(kdehip, plan, pts_all, bw_all, D, M, N, Nout, Niter, seed, args.warmup))
-        print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()
+    if rank == 0:
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)  # whatever C libraries buffered for fd 1 goes to stderr now
+        os.dup2(real_stdout, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
 
 
 def cpu_baseline_and_parity(kdehip, plan, pts_all, bw_all, D, M, N, Nout, Niter, seed, warmup):

@@ -19,8 +19,9 @@ def _run(cmd, env=None):
     e.update(env or {})
     out = subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
-    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out.stdout
+    # the JSON line is the ONLY thing on stdout (library banners -- RCCL prints one -- go to stderr)
+    lines = out.stdout.strip().splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), out.stdout
     return json.loads(lines[0])
 
 

@@ -40,6 +40,16 @@ def _worker(rank, world, port, Np, out_dir):
         pts, ind = sp.sample(Np, Niter=4, seed=9, sample_base=100)
         np.save(os.path.join(out_dir, f"pts{rank}.npy"), pts.numpy())
         np.save(os.path.join(out_dir, f"ind{rank}.npy"), ind.numpy())
+        # pipelined products: four in flight over two buffer slots, results collected afterwards in order
+        pend, got = [], []
+        for t in range(4):
+            if t >= 2:
+                got.append([x.clone() for x in pend[t - 2].result()])
+            pend.append(sp.sample_async(Np, Niter=4, seed=9, sample_base=100 + t * Np, slot=t & 1))
+        got += [[x.clone() for x in p.result()] for p in pend[2:]]
+        for t, (p, i) in enumerate(got):
+            np.save(os.path.join(out_dir, f"pipe_pts{rank}_{t}.npy"), p.numpy())
+            np.save(os.path.join(out_dir, f"pipe_ind{rank}_{t}.npy"), i.numpy())
     finally:
         dist.destroy_process_group()
 
@@ -56,8 +66,12 @@ def test_shard_ranges_partition_the_samples():
 @pytest.mark.parametrize("world,Np", [(2, 64), (2, 33), (3, 10)])
 def test_all_gather_equals_single_rank(tmp_path, world, Np):
     ref = ShardedProduct(FakePlan(), "cpu")
-    pts1, ind1 = ref.sample(Np, Niter=4, seed=9, sample_base=100)
+    pts1, ind1 = [x.clone() for x in ref.sample(Np, Niter=4, seed=9, sample_base=100)]  # (results are views of the slot's buffer)
+    pipe = [[x.clone() for x in ref.sample(Np, Niter=4, seed=9, sample_base=100 + t * Np)] for t in range(4)]
     mp.spawn(_worker, args=(world, _free_port(), Np, str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
         assert np.array_equal(np.load(tmp_path / f"pts{r}.npy"), pts1.numpy())
         assert np.array_equal(np.load(tmp_path / f"ind{r}.npy"), ind1.numpy())
+        for t, (p, i) in enumerate(pipe):
+            assert np.array_equal(np.load(tmp_path / f"pipe_pts{r}_{t}.npy"), p.numpy())
+            assert np.array_equal(np.load(tmp_path / f"pipe_ind{r}_{t}.npy"), i.numpy())
