@@ -108,8 +108,10 @@ def main():
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one process per GPU; if the launcher narrowed the visible devices per rank, take what is visible
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     use_dist = world > 1 or os.environ.get("KDEHIP_FORCE_DIST") == "1"  # (the latter: 1-rank test of the RCCL path)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -127,7 +129,7 @@ def main():
     workload = f"{args.config}: {D}-D, {M} densities x {N} pts, Nout={Nout}/GPU, Niter={Niter}, fp{prec}"
     pts_all, bw_all = synth_inputs(kdehip, D, M, N, cid)
     trees = [kdehip.kde(p, b) for p, b in zip(pts_all, bw_all)]
-    plan = kdehip.ProductPlan(trees, precision=prec, device=local_rank)
+    plan = kdehip.ProductPlan(trees, precision=prec, device=dev_index)
     if args.variant:
         plan.set_variant(args.variant)
     sp = ShardedProduct(plan, dev)

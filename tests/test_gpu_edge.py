@@ -160,3 +160,21 @@ def test_concurrent_calls_from_host_threads():
         _compare(g, oracle.gibbs1(c[1], c[2], c[3], c[4], c[5]))
     for g in r2:
         assert np.array_equal(g[0], want[0]) and np.array_equal(g[1], want[1])
+
+
+def test_very_large_ragged_densities():
+    """150 000- and 70 001-point densities (frontiers of up to 2344 rows per lane: chunked LDS streaming, two
+    rounds of second-pass narrowing) against a 3-point one; labels must still match the oracle exactly."""
+    rng = np.random.default_rng(11)
+    sizes = [150_000, 70_001, 3]
+    gp, op = [], []
+    for k, N in enumerate(sizes):
+        pts = rng.standard_normal((2, N)) * (1.0 + 0.3 * k) + 0.2 * k
+        g, o = _pair(pts, [0.05 + 0.02 * k, 0.08])
+        gp.append(g)
+        op.append(o)
+    Np, Niter = 24, 1
+    K, R, nU, nN = oracle.rng_sizes(3, 2, Np, Niter, sizes)
+    randU, randN = rng.random(nU), rng.standard_normal(nN)
+    g = kdehip.prodAppxMSGibbsS(None, gp, None, None, Niter=Niter, Np=Np, randU=randU, randN=randN)
+    _compare(g, oracle.gibbs1(op, Np, Niter, randU, randN, nthreads=8))
