@@ -73,6 +73,16 @@ int kdehip_gibbs1(int Ndens, const kdehip_density *trees, int64_t Np, int Niter,
                   int64_t *ind, const double *randU, int64_t nU, const double *randN, int64_t nN,
                   int addEntropy, int ndims, const uint8_t *partialDimMask, int device);
 
+/* gibbs1 called with glbs.recordChoosen = true (reference src/MSGibbs01.jl:29-31, :109-112, :426, :575-583):
+ * additionally returns the label trace labels[(s*Ndens + j)*nlevels + (l-1)] = bt.permutation[ind_j] as it
+ * stands after the last sampleIndex of level l = 1..nlevels (what labelsChoosen[s+1][j+1][l] ends up holding;
+ * with Niter = 0 the reference records nothing and the buffer is left as it was).  nlevels =
+ * floor(log(max_j Npts_j)/log 2 + 1) (:568).  labels == NULL makes this kdehip_gibbs1. */
+int kdehip_gibbs1_trace(int Ndens, const kdehip_density *trees, int64_t Np, int Niter, double *pts,
+                        int64_t *ind, const double *randU, int64_t nU, const double *randN, int64_t nN,
+                        int addEntropy, int ndims, const uint8_t *partialDimMask, int device,
+                        int32_t *labels);
+
 /* ---- (2) resident product plan ----------------------------------------------------------------
  * The densities are re-laid-out once (per-level tiles, "pack_levels") and kept in HBM so repeated
  * products -- and bench.py's timed region -- start with inputs resident on the device.  The first run

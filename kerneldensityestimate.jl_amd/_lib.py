@@ -46,6 +46,8 @@ SIGNATURES = {
     "kdehip_device_count": (C.c_int, []),
     "kdehip_gibbs1": (C.c_int, [C.c_int, C.POINTER(CDensity), C.c_int64, C.c_int, f64p, i64p, f64p, C.c_int64,
                                 f64p, C.c_int64, C.c_int, C.c_int, u8p, C.c_int]),
+    "kdehip_gibbs1_trace": (C.c_int, [C.c_int, C.POINTER(CDensity), C.c_int64, C.c_int, f64p, i64p, f64p, C.c_int64,
+                                      f64p, C.c_int64, C.c_int, C.c_int, u8p, C.c_int, i32p]),
     "kdehip_product_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(CDensity), C.c_int, u8p,
                                         C.c_int, C.c_int]),
     "kdehip_product_destroy": (None, [C.c_void_p]),

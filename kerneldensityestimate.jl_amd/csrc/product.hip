@@ -303,6 +303,14 @@ int kdehip_product_sample_philox_host(kdehip_product *plan, int64_t Np, int Nite
 int kdehip_gibbs1(int Ndens, const kdehip_density *trees, int64_t Np, int Niter, double *pts,
                   int64_t *ind, const double *randU, int64_t nU, const double *randN, int64_t nN,
                   int addEntropy, int ndims, const uint8_t *partialDimMask, int device) {
+  return kdehip_gibbs1_trace(Ndens, trees, Np, Niter, pts, ind, randU, nU, randN, nN, addEntropy, ndims,
+                             partialDimMask, device, nullptr);
+}
+
+int kdehip_gibbs1_trace(int Ndens, const kdehip_density *trees, int64_t Np, int Niter, double *pts,
+                        int64_t *ind, const double *randU, int64_t nU, const double *randN, int64_t nN,
+                        int addEntropy, int ndims, const uint8_t *partialDimMask, int device,
+                        int32_t *labels) {
   kdehip_product *plan = nullptr;
   int rc = kdehip_product_create(&plan, Ndens, trees, ndims, partialDimMask, 64, device);
   if (rc != KDEHIP_OK) return rc;
@@ -322,18 +330,24 @@ int kdehip_gibbs1(int Ndens, const kdehip_density *trees, int64_t Np, int Niter,
   const size_t off_n = align256(sizeof(double) * useU);
   const size_t off_p = align256(off_n + sizeof(double) * useN);
   const size_t off_i = align256(off_p + sizeof(double) * D * Np);
-  rc = reserve_work(plan, off_i + sizeof(int64_t) * M * Np);
+  const size_t off_l = align256(off_i + sizeof(int64_t) * M * Np);
+  // the reference records a label only inside sampleIndex (:426): nothing with Niter = 0
+  const bool trace = labels != nullptr && Niter > 0;
+  const size_t lab_bytes = trace ? sizeof(int32_t) * M * static_cast<size_t>(plan->host.L) * Np : 0;
+  rc = reserve_work(plan, off_l + lab_bytes);
   if (rc != KDEHIP_OK) return rc;
   unsigned char *w = static_cast<unsigned char *>(plan->d_work);
   double *du = reinterpret_cast<double *>(w), *dn = reinterpret_cast<double *>(w + off_n);
   double *dp = reinterpret_cast<double *>(w + off_p);
   int64_t *di = reinterpret_cast<int64_t *>(w + off_i);
+  int32_t *dl = trace ? reinterpret_cast<int32_t *>(w + off_l) : nullptr;
   KDEHIP_CHECK(hipMemcpy(du, randU, sizeof(double) * useU, hipMemcpyHostToDevice));
   KDEHIP_CHECK(hipMemcpy(dn, randN, sizeof(double) * useN, hipMemcpyHostToDevice));
-  rc = kdehip_product_sample_streams(plan, Np, Niter, du, useU, dn, useN, addEntropy, dp, di, nullptr, nullptr);
+  rc = kdehip_product_sample_streams(plan, Np, Niter, du, useU, dn, useN, addEntropy, dp, di, dl, nullptr);
   if (rc != KDEHIP_OK) return rc;
   KDEHIP_CHECK(hipMemcpy(pts, dp, sizeof(double) * D * Np, hipMemcpyDeviceToHost));
   KDEHIP_CHECK(hipMemcpy(ind, di, sizeof(int64_t) * M * Np, hipMemcpyDeviceToHost));
+  if (trace) KDEHIP_CHECK(hipMemcpy(labels, dl, lab_bytes, hipMemcpyDeviceToHost));
   return KDEHIP_OK;
 }
 

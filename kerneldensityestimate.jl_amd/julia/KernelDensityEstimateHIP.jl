@@ -66,21 +66,34 @@ function gibbs1(Ndens::Int, trees::Array{BallTreeDensity,1}, Np::Int, Niter::Int
                 ndims::Int=maximum(Ndim.(trees)),
                 partialDimMask::AbstractVector{<:BitVector}=[ones(Int, ndims) .== 1 for i in 1:Ndens],
                 device::Int=0)
-  if !isEuclid(addop, diffop, getMu, getLambda) || glbs.recordChoosen
+  if !isEuclid(addop, diffop, getMu, getLambda)
     return KDE.gibbs1(Ndens, trees, Np, Niter, pts, ind, randU, randN; addop=addop, diffop=diffop, getMu=getMu,
                       getLambda=getLambda, glbs=glbs, addEntropy=addEntropy, ndims=ndims,
                       partialDimMask=partialDimMask)
   end
   cds = CDensity[CDensity(t) for t in trees]
   mask = maskbytes(partialDimMask, Ndens, ndims)
-  GC.@preserve trees cds mask begin
-    rc = ccall((:kdehip_gibbs1, libkdehip), Cint,
+  # glbs.recordChoosen (src/MSGibbs01.jl:29-31): the label trace comes back as labels[level, density, sample]
+  Nlevels = floor(Int, log(Float64(maximum(Npts.(trees)))) / log(2.0) + 1.0)   # :568
+  labels = glbs.recordChoosen ? zeros(Int32, Nlevels, Ndens, Np) : Int32[]
+  GC.@preserve trees cds mask labels begin
+    rc = ccall((:kdehip_gibbs1_trace, libkdehip), Cint,
                (Cint, Ptr{CDensity}, Int64, Cint, Ptr{Float64}, Ptr{Int64}, Ptr{Float64}, Int64, Ptr{Float64},
-                Int64, Cint, Cint, Ptr{UInt8}, Cint),
+                Int64, Cint, Cint, Ptr{UInt8}, Cint, Ptr{Int32}),
                Ndens, cds, Np, Niter, pts, ind, randU, length(randU), randN, length(randN),
-               addEntropy ? 1 : 0, ndims, mask, device)
+               addEntropy ? 1 : 0, ndims, mask, device, glbs.recordChoosen ? pointer(labels) : C_NULL)
   end
   check(rc)
+  if glbs.recordChoosen   # same nesting and 1-based keys as :471-472, :575-583, :109-112
+    glbs.labelsChoosen = Dict{Int,Dict{Int,Dict{Int,Int}}}()
+    for s in 1:Np
+      glbs.labelsChoosen[s] = Dict{Int,Dict{Int,Int}}()
+      for j in 1:Ndens
+        glbs.labelsChoosen[s][j] = Niter > 0 ? Dict{Int,Int}(l => Int(labels[l, j, s]) for l in 1:Nlevels) :
+                                               Dict{Int,Int}()
+      end
+    end
+  end
   nothing
 end
 
@@ -98,7 +111,7 @@ function prodAppxMSGibbsS(npd0::BallTreeDensity, trees::Array{BallTreeDensity,1}
                           randU=nothing, randN=nothing,
                           partialDimMask::AbstractVector{<:BitVector}=[ones(Int, ndims) .== 1 for i in 1:length(trees)],
                           seed::Union{Nothing,UInt64}=nothing, device::Int=0)
-  if !isEuclid(addop, diffop, getMu, getLambda) || glbs.recordChoosen
+  if !isEuclid(addop, diffop, getMu, getLambda)
     kw = (randU === nothing) ? NamedTuple() : (randU=randU, randN=randN)
     return KDE.prodAppxMSGibbsS(npd0, trees, anFcns, anParams; Niter=Niter, addop=addop, diffop=diffop,
                                 getMu=getMu, getLambda=getLambda, glbs=glbs, addEntropy=addEntropy,
@@ -106,9 +119,17 @@ function prodAppxMSGibbsS(npd0::BallTreeDensity, trees::Array{BallTreeDensity,1}
   end
   points = zeros(ndims * Np)
   indices = ones(Int, Ndens, Np)
-  if randU !== nothing
-    gibbs1(Ndens, trees, Np, Niter, points, indices, randU, randN; addEntropy=addEntropy, ndims=Int(ndims),
-           partialDimMask=partialDimMask, device=device)
+  if randU !== nothing || glbs.recordChoosen
+    if randU === nothing   # label traces go through the drop-in: draw the streams from the host twin of the device RNG
+      s = seed === nothing ? rand(UInt64) : seed
+      Nlevels = floor(Int, log(Float64(maximum(Npts.(trees)))) / log(2.0) + 1.0)
+      K, R = Ndens * (1 + Nlevels * (Niter + 1)), ndims * (Nlevels + 1)
+      randU, randN = zeros(Np * K), zeros(Np * R)
+      ccall((:kdehip_philox_fill_uniform, libkdehip), Cvoid, (UInt64, Int64, Int64, Int64, Ptr{Float64}), s, 0, Np, K, randU)
+      ccall((:kdehip_philox_fill_normal, libkdehip), Cvoid, (UInt64, Int64, Int64, Int64, Ptr{Float64}), s, 0, Np, R, randN)
+    end
+    gibbs1(Ndens, trees, Np, Niter, points, indices, randU, randN; glbs=glbs, addEntropy=addEntropy,
+           ndims=Int(ndims), partialDimMask=partialDimMask, device=device)
     return reshape(points, ndims, Np), indices
   end
   cds = CDensity[CDensity(t) for t in trees]
@@ -183,9 +204,9 @@ function enable!()
                             getLambda=(getEuclidLambda,), glbs=makeEmptyGbGlb(), addEntropy::Bool=true,
                             ndims::Int=maximum(Ndim.(trees)),
                             partialDimMask::AbstractVector{<:BitVector}=[ones(Int, ndims) .== 1 for i in 1:Ndens])
-    if $(isEuclid)(addop, diffop, getMu, getLambda) && !glbs.recordChoosen
-      return $(gibbs1)(Ndens, trees, Np, Niter, pts, ind, randU, randN; addEntropy=addEntropy, ndims=ndims,
-                       partialDimMask=partialDimMask)
+    if $(isEuclid)(addop, diffop, getMu, getLambda)
+      return $(gibbs1)(Ndens, trees, Np, Niter, pts, ind, randU, randN; glbs=glbs, addEntropy=addEntropy,
+                       ndims=ndims, partialDimMask=partialDimMask)
     end
     return $(invoke_original)(Ndens, trees, Np, Niter, pts, ind, randU, randN; addop=addop, diffop=diffop,
                               getMu=getMu, getLambda=getLambda, glbs=glbs, addEntropy=addEntropy, ndims=ndims,

@@ -141,10 +141,33 @@ def philox_streams(seed, sample_begin, nsamples, K, R):
     return u, n
 
 
+class GbGlb:
+    """The part of the reference's `GbGlb` scratch object (src/MSGibbs01.jl:1-33) a caller can see:
+    `recordChoosen` and, after a product, `labelsChoosen[sample][density][level]` (all keys 1-based, :29-31) =
+    `bt.permutation[ind]` of the kernel the density holds after the last `sampleIndex` of that level (:109-112).
+    Everything else of the reference's scratch lives in registers/LDS of the kernel."""
+
+    def __init__(self, recordChoosen=False):
+        self.recordChoosen = bool(recordChoosen)
+        self.labelsChoosen = {}
+
+    def _fill(self, labels, Niter):
+        """labels[Np, Ndens, L] -> the reference's nested dictionaries (:471-472, :575-583)."""
+        Np, M, L = labels.shape
+        self.labelsChoosen = {s + 1: {j + 1: ({l + 1: int(labels[s, j, l]) for l in range(L)} if Niter > 0 else {})
+                                      for j in range(M)} for s in range(Np)}
+
+
+def makeEmptyGbGlb(recordChoosen=False):
+    """`makeEmptyGbGlb(;recordChoosen=false)` (reference src/MSGibbs01.jl:35-61)."""
+    return GbGlb(recordChoosen)
+
+
 def gibbs1(Ndens, trees, Np, Niter, pts, ind, randU, randN, *, addEntropy=True, ndims=None,
-           partialDimMask=None, device=0):
+           partialDimMask=None, glbs=None, device=0):
     """`gibbs1` (reference src/MSGibbs01.jl:527-537): fills the caller's `pts` (length ndims*Np,
-    column-major) and `ind` (Ndens x Np, column-major) in place; returns None."""
+    column-major) and `ind` (Ndens x Np, column-major) in place; returns None.  With
+    `glbs.recordChoosen` the label trace lands in `glbs.labelsChoosen` as in the reference."""
     trees = list(trees)
     if ndims is None:
         ndims = max(Ndim(t) for t in trees)
@@ -158,10 +181,16 @@ def gibbs1(Ndens, trees, Np, Niter, pts, ind, randU, randN, *, addEntropy=True, 
     randN = np.ascontiguousarray(randN, dtype=np.float64)
     arr = (_lib.CDensity * Ndens)(*[t._cstruct() for t in trees])
     mask = _mask_array(partialDimMask, Ndens, ndims)
-    _lib.check(_lib.lib.kdehip_gibbs1(int(Ndens), arr, int(Np), int(Niter), ptr(pts.reshape(-1), f64p),
-                                      ptr(tmp_ind, i64p), ptr(randU, f64p), randU.size, ptr(randN, f64p),
-                                      randN.size, int(bool(addEntropy)), int(ndims),
-                                      None if mask is None else ptr(mask, u8p), int(device)))
+    labels = None
+    if glbs is not None and glbs.recordChoosen:
+        labels = np.zeros((Np, Ndens, nlevels(max(Npts(t) for t in trees))), dtype=np.int32)
+    _lib.check(_lib.lib.kdehip_gibbs1_trace(int(Ndens), arr, int(Np), int(Niter), ptr(pts.reshape(-1), f64p),
+                                            ptr(tmp_ind, i64p), ptr(randU, f64p), randU.size, ptr(randN, f64p),
+                                            randN.size, int(bool(addEntropy)), int(ndims),
+                                            None if mask is None else ptr(mask, u8p), int(device),
+                                            None if labels is None else ptr(labels, i32p)))
+    if labels is not None:
+        glbs._fill(labels, Niter)
     if ind.ndim == 2:
         ind[...] = tmp_ind.reshape(Np, Ndens).T
     else:
@@ -171,7 +200,7 @@ def gibbs1(Ndens, trees, Np, Niter, pts, ind, randU, randN, *, addEntropy=True, 
 
 def prodAppxMSGibbsS(npd0, trees, anFcns=None, anParams=None, *, Niter=3, addEntropy=True, ndims=None,
                      Ndens=None, Np=None, randU=None, randN=None, partialDimMask=None,
-                     addop=None, diffop=None, getMu=None, getLambda=None,
+                     addop=None, diffop=None, getMu=None, getLambda=None, glbs=None,
                      seed=None, device=0, precision=64):
     """`prodAppxMSGibbsS` (reference src/MSGibbs01.jl:645-703).
 
@@ -197,17 +226,21 @@ def prodAppxMSGibbsS(npd0, trees, anFcns=None, anParams=None, *, Niter=3, addEnt
         points = np.zeros(ndims * Np)
         indices = np.ones((Ndens, Np), dtype=np.int64)
         gibbs1(Ndens, trees, Np, Niter, points, indices, randU, randN, addEntropy=addEntropy, ndims=ndims,
-               partialDimMask=partialDimMask, device=device)
+               partialDimMask=partialDimMask, glbs=glbs, device=device)
         return points.reshape(Np, ndims).T.copy(), indices
     if seed is None:
         seed = int.from_bytes(os.urandom(8), "little")
+    trace = glbs is not None and glbs.recordChoosen
     with ProductPlan(trees[:Ndens], partialDimMask=partialDimMask, precision=precision, device=device,
                      ndims=ndims) as plan:
-        return plan.sample(Np, Niter=Niter, seed=seed, addEntropy=addEntropy)
+        out = plan.sample(Np, Niter=Niter, seed=seed, addEntropy=addEntropy, want_labels=trace)
+    if trace:
+        glbs._fill(out[2], Niter)
+    return out[0], out[1]
 
 
-def mul(trees, *, addEntropy=True, seed=None, device=0):
-    """`*(trees)` (reference src/MSGibbs01.jl:707-726): product with Niter=5 and
+def mul(trees, *, glbs=None, addEntropy=True, seed=None, device=0):
+    """`*(trees; glbs, addEntropy)` (reference src/MSGibbs01.jl:707-726): product with Niter=5 and
     Np = round(mean(Npts)), then `kde!(pGM)` with the automatic (LOOCV) bandwidth."""
     from .bandwidth import kde_auto  # LOOCV bandwidth selection lives with the evaluation kernels
     trees = list(trees)
@@ -221,6 +254,6 @@ def mul(trees, *, addEntropy=True, seed=None, device=0):
     numpts = int(round(float(np.mean([Npts(t) for t in trees]))))
     if seed is None:
         seed = int.from_bytes(os.urandom(8), "little")
-    with ProductPlan(trees, device=device) as plan:
-        pGM, _ = plan.sample(numpts, Niter=5, seed=seed, addEntropy=addEntropy)
+    pGM, _ = prodAppxMSGibbsS(None, trees, None, None, Niter=5, addEntropy=addEntropy, Np=numpts, glbs=glbs,
+                              seed=seed, device=device)
     return kde_auto(pGM, device=device)

@@ -365,3 +365,43 @@ def test_conditional_tables_are_exact(D, M, N, weighted, mask):
         if prec == 64:
             u, n = kdehip.philox_streams(seed, 0, Np, K, R)
             _compare(got[:2], oracle.gibbs1(op, Np, Niter, u, n, partialDimMask=mask), tol=1e-11)
+
+
+def test_record_choosen_label_trace_like_the_reference_example():
+    """examples/ExtractingLabels.jl: `glbs = makeEmptyGbGlb(); glbs.recordChoosen = true; *( [X1;X2;X3], glbs=glbs,
+    addEntropy=false)` then `glbs.labelsChoosen[sample][density][level]`.  Through the drop-in (`gibbs1` with the
+    caller's streams) the trace must equal the oracle's at every level, its last level must name the returned
+    index, and with addEntropy=false the product points are the precision-weighted means of the traced leaves."""
+    X = [kdehip.kde(np.array(v), [1.0]) for v in ([1.0, 2.0, 3.0], [0.5, 1.5, 2.5], [4.0, 5.0, 6.0])]
+    O = [oracle.OracleDensity(np.array(v), [1.0]) for v in ([1.0, 2.0, 3.0], [0.5, 1.5, 2.5], [4.0, 5.0, 6.0])]
+    Np, Niter = 3, 5
+    K, R, nU, nN = oracle.rng_sizes(3, 1, Np, Niter, [3, 3, 3])
+    rng = np.random.default_rng(8)
+    randU, randN = rng.random(nU), rng.standard_normal(nN)
+    glbs = kdehip.makeEmptyGbGlb()
+    glbs.recordChoosen = True
+    pts, ind = kdehip.prodAppxMSGibbsS(None, X, None, None, Niter=Niter, Np=Np, addEntropy=False,
+                                       randU=randU, randN=randN, glbs=glbs)
+    o_pts, o_ind, o_lab = oracle.gibbs1(O, Np, Niter, randU, randN, addEntropy=False, want_labels=True)
+    lc = glbs.labelsChoosen
+    L = kdehip.nlevels(3)
+    assert sorted(lc) == [1, 2, 3] and sorted(lc[1]) == [1, 2, 3] and sorted(lc[1][1]) == list(range(1, L + 1))
+    for s in range(Np):
+        mu = 0.0
+        for j in range(3):
+            assert [lc[s + 1][j + 1][l + 1] for l in range(L)] == list(o_lab[s, j])
+            assert lc[s + 1][j + 1][L] + 1 == ind[j, s]          # newIndices = permutation + 1 (:615)
+            mu += kdehip.getPoints(X[j])[0, lc[s + 1][j + 1][L] - 1]
+        assert abs(pts[0, s] - mu / 3.0) < 1e-12                  # equal bandwidths: plain mean of the leaves
+    # the reference records inside sampleIndex only: no sweeps, no entries
+    g0 = kdehip.makeEmptyGbGlb(recordChoosen=True)
+    kdehip.prodAppxMSGibbsS(None, X, None, None, Niter=0, Np=Np, randU=randU, randN=randN, glbs=g0)
+    assert g0.labelsChoosen[1][1] == {}
+    # device-Philox front end and `*`
+    g1 = kdehip.makeEmptyGbGlb(recordChoosen=True)
+    p123 = kdehip.mul(X, glbs=g1, addEntropy=False, seed=4)
+    assert kdehip.Npts(p123) == 3 and sorted(g1.labelsChoosen[3][2]) == list(range(1, L + 1))
+    got = np.sort(kdehip.getPoints(p123)[0])
+    want = np.sort([np.mean([kdehip.getPoints(X[j])[0, g1.labelsChoosen[s][j + 1][L] - 1] for j in range(3)])
+                    for s in (1, 2, 3)])
+    assert np.allclose(got, want, atol=1e-12)
