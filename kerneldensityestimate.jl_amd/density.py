@@ -128,27 +128,29 @@ def Npts(bd: BallTreeDensity) -> int:
     return bd.bt.num_points
 
 
-def getPoints(bd: BallTreeDensity):
-    """Points in the caller's original order (reference src/KDE01.jl:91-101)."""
+def getPoints(bd: BallTreeDensity, idx=None):
+    """Points in the caller's original order (reference src/KDE01.jl:91-101); `idx` (0-based here) selects
+    columns like the reference's second argument."""
     N, D = bd.bt.num_points, bd.bt.dims
     perm = bd.bt.permutation[N:] - 1
     out = np.zeros((D, N))
     out[:, perm] = bd.bt.centers[N * D:].reshape(N, D).T
-    return out
+    return out if idx is None else out[:, idx]
 
 
-def getBW(bd: BallTreeDensity):
-    """Per-point bandwidth as standard deviation, (D, N) (reference src/KDE01.jl:109-120)."""
+def getBW(bd: BallTreeDensity, ind=None):
+    """Per-point bandwidth as standard deviation, (D, N) (reference src/KDE01.jl:109-120); `ind` 0-based."""
     N, D = bd.bt.num_points, bd.bt.dims
     perm = bd.bt.permutation[N:] - 1
     out = np.zeros((D, N))
     out[:, perm] = bd.bandwidth[N * D:].reshape(N, D).T
-    return np.sqrt(out)
+    out = np.sqrt(out)
+    return out if ind is None else out[:, ind]
 
 
-def getWeights(bd: BallTreeDensity):
-    """Normalised point weights in original order (reference src/KDE01.jl:127-136)."""
+def getWeights(bd: BallTreeDensity, ind=None):
+    """Normalised point weights in original order (reference src/KDE01.jl:127-136); `ind` 0-based."""
     N = bd.bt.num_points
     out = np.zeros(N)
     out[bd.bt.permutation[N:] - 1] = bd.bt.weights[N:]
-    return out
+    return out if ind is None else out[ind]

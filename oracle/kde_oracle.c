@@ -14,7 +14,8 @@
  *   - Gibbs arithmetic (okde_gibbs1): PARITY UNPINNED by any golden vector -- the reference holds
  *     none for this path and Julia is not available here to run it.  It is constrained only by the
  *     reference's statistical acceptance tests (test/runtests.jl:167-201, test/testPartialProd.jl)
- *     and closed-form invariants, all replayed in tests/.
+ *     and closed-form invariants, all replayed in tests/.  oracle/julia_crosscheck.jl is the (un-run)
+ *     script that pins it against the real reference wherever Julia is available.
  *   - direct evaluation + LOOCV bandwidth (okde_eval_direct, okde_auto_bandwidth): PINNED by the
  *     reference's golden test1Dlcv100Result.txt (kde!(x) at the reference's 1e-4, UnitTest1Dlcv01).
  *

@@ -43,7 +43,32 @@ def make(name, D, M, N, Np, Niter):
     print(out, os.path.getsize(out), "bytes")
 
 
+def dump_text(name, D, M, N, Np, Niter, out_dir):
+    """Plain-text inputs + expected outputs of one case for oracle/julia_crosscheck.jl (the definitive parity check
+    against the real reference; needs a Julia installation, which this image does not have)."""
+    os.makedirs(out_dir, exist_ok=True)
+    pts, bws = inputs(D, M, N)
+    trees = [oracle.OracleDensity(p, b) for p, b in zip(pts, bws)]
+    K, R, nU, nN = oracle.rng_sizes(M, D, Np, Niter, [N] * M)
+    randU, randN = kat_streams(nU, nN)
+    p_e, i_e = oracle.gibbs1(trees, Np, Niter, randU, randN, addEntropy=True)
+    np.savetxt(os.path.join(out_dir, "meta.txt"), np.array([[D, M, N, Np, Niter]]), fmt="%d")
+    for j in range(M):
+        np.savetxt(os.path.join(out_dir, f"points_{j + 1}.txt"), pts[j], fmt="%.17g")
+        np.savetxt(os.path.join(out_dir, f"bw_{j + 1}.txt"), bws[j], fmt="%.17g")
+    np.savetxt(os.path.join(out_dir, "randU.txt"), randU, fmt="%.17g")
+    np.savetxt(os.path.join(out_dir, "randN.txt"), randN, fmt="%.17g")
+    np.savetxt(os.path.join(out_dir, "indices.txt"), i_e, fmt="%d")
+    np.savetxt(os.path.join(out_dir, "pGM.txt"), p_e, fmt="%.17g")
+    print("wrote", out_dir, f"({name})")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) == 3 and sys.argv[1] == "--dump-text":
+        dump_text("c1", 1, 2, 100, 100, 5, os.path.join(sys.argv[2], "c1"))
+        dump_text("c2", 2, 3, 200, 256, 5, os.path.join(sys.argv[2], "c2"))
+        dump_text("d6", 6, 4, 300, 64, 3, os.path.join(sys.argv[2], "d6"))
+        sys.exit(0)
     make("c1", 1, 2, 100, 100, 5)   # BASELINE config 1
     make("c2", 2, 3, 200, 256, 5)   # BASELINE config 2
     make("d6", 6, 4, 300, 64, 3)    # config-3 shape, reduced
