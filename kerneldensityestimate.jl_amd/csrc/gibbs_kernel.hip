@@ -515,6 +515,7 @@ template <typename T, int D, int MODE, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan, RunArgs a) {
   constexpr bool FAST = (MODE != kModeGeneric);      // product/rsqrt + uniform-bandwidth forms
   constexpr bool MASKED = (MODE == kModeFastMasked);  // ... with inactive dimensions
+  constexpr bool kAllDimsOn = (MODE == kModeFast);    // the plan checked it: no mask tests in this build
   // pass 1 prefetches the next row's fields while it evaluates the current one; the 16-wavefront fp64
   // builds have 128 VGPRs and would spill from D = 6 on
 #if defined(KDEHIP_NO_PREFETCH)
@@ -573,7 +574,7 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan,
     auto e = hdr + kTileHeader + (pos >> 6) * (ds.F * 64 + 1) + (pos & 63);
     const T mu = e[dl * 64];
     const T var = ds.uniform_bw ? hdr[dl] : e[(D + dl) * 64];
-    const bool on = (ds.mask_bits >> dl) & 1u;
+    const bool on = kAllDimsOn || ((ds.mask_bits >> dl) & 1u);
     const T l = on ? (FAST ? fast_rcp(var) : T(1) / var) : T(0);
     if (lane < D) {
       lam[j * D + dl] = l;
@@ -585,8 +586,14 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan,
   // Gaussian product of the selected kernels without density `skip` for this lane's dimension
   // (gaussianProductMeanCov!, :176-216): cov = 1/sum(lambda), mean = cov * sum(mu*lambda).
   auto product_dim = [&](int skip, uint32_t info_bits, T &mean, T &cov) {
-    // all LDS reads are issued before the first add (one LDS round trip instead of M); a skipped
-    // density contributes an exact +0, so the sums are the reference's sequential sums (:199-213)
+    // The density left out contributes an exact +0 to the reference's sequential sums (:199-213): its slot
+    // is zeroed instead of being masked out of every term (every caller with skip >= 0 adopts a new kernel
+    // for that density right after the draw, or never set the slot at all).  All LDS reads are issued
+    // before the first add (one LDS round trip instead of M).
+    if (skip >= 0) {
+      if (lane < D) { lam[skip * D + dl] = T(0); lmu[skip * D + dl] = T(0); }
+      wave_sync();
+    }
     T ls = T(0), ms = T(0);
     int k = 0;
     for (; k + 4 <= M; k += 4) {
@@ -594,17 +601,13 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan,
 #pragma unroll
       for (int i = 0; i < 4; ++i) { l4[i] = lam[(k + i) * D + dl]; m4[i] = lmu[(k + i) * D + dl]; }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        ls += (k + i != skip) ? l4[i] : T(0);
-        ms += (k + i != skip) ? m4[i] : T(0);
-      }
+      for (int i = 0; i < 4; ++i) { ls += l4[i]; ms += m4[i]; }
     }
     for (; k < M; ++k) {
-      const T l1 = lam[k * D + dl], m1 = lmu[k * D + dl];
-      ls += (k != skip) ? l1 : T(0);
-      ms += (k != skip) ? m1 : T(0);
+      ls += lam[k * D + dl];
+      ms += lmu[k * D + dl];
     }
-    const bool on = (info_bits >> dl) & 1u;
+    const bool on = kAllDimsOn || ((info_bits >> dl) & 1u);
     cov = on ? (FAST ? fast_rcp(ls) : T(1) / ls) : T(0);
     mean = on ? cov * ms : T(0);
   };
