@@ -406,7 +406,7 @@ __device__ __forceinline__ int select_from_scan(T incl, T S, P rows, const Level
 
   const T target = static_cast<T>(u) * total;
   const unsigned long long hit = __ballot(target <= incl);
-  const int last_lane = (n - 1) / B;
+  const int last_lane = ds.last_lane;
   int lstar = hit ? (__ffsll(hit) - 1) : last_lane;
   if (lstar > last_lane) lstar = last_lane;
   KSTAMP(tp2);
@@ -684,10 +684,7 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan,
   // workgroup-wide running chunk counter that selects the pool half; the chunk after this tile's last
   // one is the first chunk of `dn` (the next step's tile), if there is a next step.
   int gchunk = 0;
-  auto chunk_rows = [&](const LevelDesc &ds) -> int {
-    const int row_bytes = (ds.F * 64 + 1) * int(sizeof(T));
-    return ((kLdsPoolBytes / 2 - 1024) / row_bytes) & ~3;  // multiple of 4 rows: 16-byte aligned chunks
-  };
+  auto chunk_rows = [&](const LevelDesc &ds) -> int { return ds.chunk_rows; };
   auto stage_chunk = [&](const LevelDesc &ds, int r0, int half) {
     const int RS = ds.F * 64 + 1, rc = chunk_rows(ds);
     const int nrows = (ds.B - r0 < rc) ? (ds.B - r0) : rc;

@@ -50,7 +50,9 @@ struct LevelDesc {
   int32_t stage_mode;   // StageMode of this LEVEL (same for every density)
   int32_t lds_off;      // byte offset of the tile image in the LDS pool (resident mode)
   int32_t stage_bytes;  // bytes to copy (header + rows, rounded up to 1 KiB)
-  int32_t pad_[3];
+  int32_t last_lane;    // (n - 1) / B: the lane that owns the last entry (kept here: no integer division per step)
+  int32_t chunk_rows;   // rows per LDS chunk in chunked mode (multiple of 4: 16-byte aligned chunk starts)
+  int32_t pad_;
 };
 static_assert(sizeof(LevelDesc) == 64, "LevelDesc is read with scalar loads; keep it 64 bytes");
 

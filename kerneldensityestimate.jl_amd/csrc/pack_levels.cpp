@@ -152,6 +152,8 @@ int pack_levels(int Ndens, const kdehip_density *trees, int ndims, const uint8_t
       const int64_t bytes = (kTileHeader + B * RS) * esz;
       if (bytes > (int64_t(1) << 30)) return set_error(KDEHIP_ERR_UNSUPPORTED, "level tile too large");
       ds.stage_bytes = static_cast<int32_t>((bytes + 1023) / 1024 * 1024);
+      ds.last_lane = static_cast<int32_t>((n - 1) / B);
+      ds.chunk_rows = static_cast<int32_t>(((kLdsPoolBytes / 2 - 1024) / (RS * esz)) & ~int64_t(3));
       double *tile = out.data.data() + rows_off;
       int32_t *prow = out.perm.data() + ds.perm_off;
       for (int64_t i = 0; i < B; ++i)
