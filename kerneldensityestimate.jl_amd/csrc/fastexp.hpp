@@ -20,20 +20,31 @@ static __constant__ double kExp2Tab[32] = {
 
 // exp(x) for x <= 0 (NaN in -> NaN out).  x = (32k + j) * ln2/32 + r, |r| <= ln2/64:
 // exp(x) = 2^k * 2^(j/32) * (1 + r + r^2/2 + ... + r^6/720); the truncation error is < 4e-18.
-__device__ __forceinline__ double exp_nonpos(double x, const double *__restrict__ tab /* LDS */) {
+// Two halves, so that a caller can put independent work between the table lookup and its use.
+struct ExpSplit {
+  double r, t;  // reduced argument; 2^(j/32) from the table
+  int ki;       // 32k + j
+};
+__device__ __forceinline__ ExpSplit exp_nonpos_begin(double x, const double *__restrict__ tab /* LDS */) {
   x = fmax(x, -800.0);  // exp(-800) already underflows to 0; keeps the reduction finite
   const double kf = rint(x * 0x1.71547652b82fep+5);            // 32/ln2
   double r = fma(kf, -0x1.62e42fee00000p-6, x);                // ln2/32, high part (32 bits)
   r = fma(kf, -0x1.a39ef35793c76p-38, r);                      // low part
   const int ki = static_cast<int>(kf);
-  const double t = tab[ki & 31];
+  return {r, tab[ki & 31], ki};
+}
+__device__ __forceinline__ double exp_nonpos_end(const ExpSplit &s) {
+  const double r = s.r;
   double p = fma(r, 0x1.6c16c16c16c17p-10, 0x1.1111111111111p-7);  // 1/720, 1/120
   p = fma(p, r, 0x1.5555555555555p-5);                              // 1/24
   p = fma(p, r, 0x1.5555555555555p-3);                              // 1/6
   p = fma(p, r, 0.5);
   p = fma(p, r, 1.0);
   p = p * r;                                                        // exp(r) - 1
-  return ldexp(fma(t, p, t), ki >> 5);
+  return ldexp(fma(s.t, p, s.t), s.ki >> 5);
+}
+__device__ __forceinline__ double exp_nonpos(double x, const double *__restrict__ tab /* LDS */) {
+  return exp_nonpos_end(exp_nonpos_begin(x, tab));
 }
 
 }  // namespace kdehip

@@ -76,6 +76,9 @@ template <typename T> struct Num;
 template <> struct Num<double> {
   static __device__ __forceinline__ double exp(double x) { return ::exp(x); }
   static __device__ __forceinline__ double exp_fast(double x, const double *tab) { return exp_nonpos(x, tab); }
+  using ExpMid = ExpSplit;  // exp_fast in two halves (table lookup issued / result formed)
+  static __device__ __forceinline__ ExpMid exp_begin(double x, const double *tab) { return exp_nonpos_begin(x, tab); }
+  static __device__ __forceinline__ double exp_end(const ExpMid &m) { return exp_nonpos_end(m); }
   static __device__ __forceinline__ double log(double x) { return ::log(x); }
   static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
   static __device__ __forceinline__ double rsqrt(double x) { return ::rsqrt(x); }
@@ -85,6 +88,9 @@ template <> struct Num<double> {
 template <> struct Num<float> {
   static __device__ __forceinline__ float exp(float x) { return __expf(x); }
   static __device__ __forceinline__ float exp_fast(float x, const double *) { return __expf(x); }
+  struct ExpMid { float x; };
+  static __device__ __forceinline__ ExpMid exp_begin(float x, const double *) { return {x}; }
+  static __device__ __forceinline__ float exp_end(const ExpMid &m) { return __expf(m.x); }
   static __device__ __forceinline__ float log(float x) { return __logf(x); }
   static __device__ __forceinline__ float sqrt(float x) { return ::sqrtf(x); }
   static __device__ __forceinline__ float rsqrt(float x) { return ::rsqrtf(x); }
@@ -176,8 +182,9 @@ struct EvalUniform {
     r.w = e[D * 64];
     return r;
   }
+  // value = front * exp(exponent)
   template <typename V>
-  __device__ __forceinline__ V eval(const RowT<V> &r) const {
+  __device__ __forceinline__ V exponent(const RowT<V> &r, V &front) const {
     V acc = V(0);
 #pragma unroll
     for (int d = 0; d < D; ++d) {
@@ -186,8 +193,24 @@ struct EvalUniform {
     }
     // (no per-entry NaN test: on the fast paths every tile value is finite and positive, so a NaN can
     // only come from the wave-uniform centre/cov and then hits every entry -- handled on the total)
-    return (r.w * scale) * Num<V>::exp_fast(acc, tab);
+    front = r.w * scale;
+    return acc;
   }
+  template <typename V>
+  __device__ __forceinline__ V eval(const RowT<V> &r) const {
+    V front;
+    const V x = exponent<V>(r, front);
+    return front * Num<V>::exp_fast(x, tab);
+  }
+  // the same value in two halves: arg() ends by issuing the exp table lookup, fin() uses it
+  struct Mid { T front; typename Num<T>::ExpMid e; };
+  __device__ __forceinline__ Mid arg(const Row &r) const {
+    Mid m;
+    const T x = exponent<T>(r, m.front);
+    m.e = Num<T>::exp_begin(x, tab);
+    return m;
+  }
+  __device__ __forceinline__ T fin(const Mid &m) const { return m.front * Num<T>::exp_end(m.e); }
   __device__ __forceinline__ T operator()(const Row &r) const { return eval<T>(r); }
   template <typename P>
   __device__ __forceinline__ T operator()(P e) const { return (*this)(load(e)); }
@@ -219,7 +242,7 @@ struct EvalFast {
     return r;
   }
   template <typename V>
-  __device__ __forceinline__ V eval(const RowT<V> &row) const {
+  __device__ __forceinline__ V exponent(const RowT<V> &row, V &front) const {
     V c[D], d2[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) {
@@ -247,8 +270,23 @@ struct EvalFast {
     for (int d = 0; d < D; ++d) num = Num<V>::fma(d2[d], pre[d] * suf[d], num);
     const V r = Num<V>::rsqrt(prod);
     const V q = num * r * r;  // = sum_d delta_d^2 / c_d
-    return (w * r) * Num<V>::exp_fast(V(-0.5) * q, tab);
+    front = w * r;
+    return V(-0.5) * q;
   }
+  template <typename V>
+  __device__ __forceinline__ V eval(const RowT<V> &row) const {
+    V front;
+    const V x = exponent<V>(row, front);
+    return front * Num<V>::exp_fast(x, tab);
+  }
+  struct Mid { T front; typename Num<T>::ExpMid e; };
+  __device__ __forceinline__ Mid arg(const Row &row) const {
+    Mid m;
+    const T x = exponent<T>(row, m.front);
+    m.e = Num<T>::exp_begin(x, tab);
+    return m;
+  }
+  __device__ __forceinline__ T fin(const Mid &m) const { return m.front * Num<T>::exp_end(m.e); }
   __device__ __forceinline__ T operator()(const Row &row) const { return eval<T>(row); }
   template <typename P>
   __device__ __forceinline__ T operator()(P e) const { return (*this)(load(e)); }
@@ -299,6 +337,9 @@ struct EvalGeneric {
   }
   template <typename P>
   __device__ __forceinline__ T operator()(P e) const { return (*this)(load(e)); }
+  struct Mid { T p; };
+  __device__ __forceinline__ Mid arg(const Row &row) const { return {(*this)(row)}; }
+  __device__ __forceinline__ T fin(const Mid &m) const { return m.p; }
   static constexpr bool kPairs = false;
 };
 
@@ -348,11 +389,14 @@ __device__ __forceinline__ T lane_sum_rows(P rows, int nrows, int RS, int lane, 
   for (; i + 2 <= nrows; i += 2) {
     const typename Eval::Row rb = ev.load(e + RS);  // row i+1
     __builtin_amdgcn_sched_barrier(0);              // keep the requests above the arithmetic
-    S += ev(ra);
+    const typename Eval::Mid ma = ev.arg(ra);       // ... ends by issuing row i's exp table lookup
+    __builtin_amdgcn_sched_barrier(0);
+    const typename Eval::Mid mb = ev.arg(rb);       // hides the latency of row i's lookup
     e += (i + 2 < nrows) ? 2 * RS : RS;             // row i+2, or row i+1 again (never past the tile)
     ra = ev.load(e);
     __builtin_amdgcn_sched_barrier(0);
-    S += ev(rb);
+    S += ev.fin(ma);
+    S += ev.fin(mb);
   }
   if (i < nrows) S += ev(ra);
   return S;
@@ -500,15 +544,28 @@ struct TabTable {
 using LdsVoidPtr = __attribute__((address_space(3))) void *;
 using GlobalVoidPtr = const __attribute__((address_space(1))) void *;
 
-// Cooperative, asynchronous copy of one tile image (bytes is a multiple of 1 KiB) into the pool:
-// every wavefront issues global_load_lds_dwordx4 for its share of 1-KiB pieces.
+// Cooperative, asynchronous copy of one tile image (bytes is a multiple of 1 KiB) into the pool: every
+// wavefront issues direct-to-LDS loads for its share of 1-KiB pieces (16 bytes per lane).
+// The MUBUF form (buffer_load_dwordx4 ... lds) is used rather than global_load_lds: the compiler counts the
+// FLAT-encoded form against lgkmcnt as well and, while such a copy is in flight, turns EVERY LDS wait into
+// s_waitcnt lgkmcnt(0) -- which would serialise the row prefetches of the first pass behind each other.
+// Both forms are tracked by vmcnt in hardware.
 template <int WAVES>
 __device__ __forceinline__ void stage_tile(const unsigned char *__restrict__ src, unsigned char *dst,
                                            int bytes, int wave, int lane) {
+#ifdef KDEHIP_STAGE_GLOBAL_LOAD_LDS  // A/B builds
   const int pieces = bytes >> 10;
   for (int c = wave; c < pieces; c += WAVES)
     __builtin_amdgcn_global_load_lds((GlobalVoidPtr)(src + (c << 10) + (lane << 4)),
                                      (LdsVoidPtr)(dst + (c << 10)), 16, 0, 0);
+#else
+  // raw buffer over exactly this image: base = src, stride 0, num_records = bytes, gfx9 dword 3
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(src), 0, bytes, 0x00020000);
+  const int pieces = bytes >> 10;
+  for (int c = wave; c < pieces; c += WAVES)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LdsVoidPtr)(dst + (c << 10)), 16, lane << 4, c << 10, 0, 0);
+#endif
 }
 
 template <typename T, int D, int MODE, int WAVES>
