@@ -11,7 +11,7 @@
 //     8 chains (16 from 4096 chains on) share a workgroup, one workgroup per CU, and walk the
 //     data-independent (level, pass, density) schedule in lock step so that the tile every wavefront
 //     is about to read is staged ONCE per workgroup into LDS with direct-to-LDS loads
-//     (global_load_lds_dwordx4): levels whose tiles all fit the 120 KiB pool stay resident for the
+//     (buffer_load_dwordx4 ... lds): levels whose tiles all fit the 120 KiB pool stay resident for the
 //     whole level; larger ones are streamed one tile per step through a double buffer (the copy of
 //     step t+1 overlaps the evaluation of step t, one barrier per step); tiles beyond half the pool
 //     are streamed through the two halves a few rows at a time (one barrier per chunk);
