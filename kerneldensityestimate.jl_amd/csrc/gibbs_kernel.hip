@@ -360,11 +360,7 @@ template <typename T> constexpr bool kIsLdsPtr<const __attribute__((address_spac
 
 template <typename T, typename P, typename Eval, bool PREFETCH = true>
 __device__ __forceinline__ T lane_sum_rows(P rows, int nrows, int RS, int lane, const Eval &ev) {
-#ifdef KDEHIP_NO_PAIRS  // A/B builds (scripts/ab_build.sh)
-  constexpr bool kUsePairs = false;
-#else
   constexpr bool kUsePairs = sizeof(T) == 4 && Eval::kPairs;
-#endif
   if constexpr (kUsePairs) {
     // fp32: two rows per trip through the packed-math pipe (their 2F loads are in flight together)
     kdehip_f2 S2 = {0.0f, 0.0f};
@@ -548,7 +544,6 @@ struct TabTable {
 };
 
 using LdsVoidPtr = __attribute__((address_space(3))) void *;
-using GlobalVoidPtr = const __attribute__((address_space(1))) void *;
 
 // Cooperative, asynchronous copy of one tile image (bytes is a multiple of 1 KiB) into the pool: every
 // wavefront issues direct-to-LDS loads for its share of 1-KiB pieces (16 bytes per lane).
@@ -559,19 +554,12 @@ using GlobalVoidPtr = const __attribute__((address_space(1))) void *;
 template <int WAVES>
 __device__ __forceinline__ void stage_tile(const unsigned char *__restrict__ src, unsigned char *dst,
                                            int bytes, int wave, int lane) {
-#ifdef KDEHIP_STAGE_GLOBAL_LOAD_LDS  // A/B builds
-  const int pieces = bytes >> 10;
-  for (int c = wave; c < pieces; c += WAVES)
-    __builtin_amdgcn_global_load_lds((GlobalVoidPtr)(src + (c << 10) + (lane << 4)),
-                                     (LdsVoidPtr)(dst + (c << 10)), 16, 0, 0);
-#else
   // raw buffer over exactly this image: base = src, stride 0, num_records = bytes, gfx9 dword 3
   const __amdgpu_buffer_rsrc_t rsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(src), 0, bytes, 0x00020000);
   const int pieces = bytes >> 10;
   for (int c = wave; c < pieces; c += WAVES)
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LdsVoidPtr)(dst + (c << 10)), 16, lane << 4, c << 10, 0, 0);
-#endif
 }
 
 template <typename T, int D, int MODE, int WAVES>
@@ -581,13 +569,7 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan,
   constexpr bool kAllDimsOn = (MODE == kModeFast);    // the plan checked it: no mask tests in this build
   // pass 1 prefetches the next row's fields while it evaluates the current one; the 16-wavefront fp64
   // builds have 128 VGPRs and would spill from D = 6 on
-#if defined(KDEHIP_NO_PREFETCH)
-  constexpr bool kPrefetchRows = false;
-#elif defined(KDEHIP_PREFETCH_ALL)
-  constexpr bool kPrefetchRows = true;
-#else
-  constexpr bool kPrefetchRows = (WAVES == 8) || sizeof(T) == 4;
-#endif
+  constexpr bool kPrefetchRows = (WAVES == 8) || sizeof(T) == 4 || D <= 4;
   using Lay = LdsLayout<T, D, WAVES>;
   __shared__ __attribute__((aligned(1024))) unsigned char smem[Lay::kBytes];
 
