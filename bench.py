@@ -259,6 +259,12 @@ def cpu_baseline_and_parity(kdehip, plan, pts_all, bw_all, D, M, N, Nout, Niter,
     t_all = time.perf_counter() - t
     g_pts, g_ind = plan.sample(nall, Niter=Niter, seed=seed, sample_offset=0)
     mism = int((g_pts.shape != o_pts.shape) or (g_ind != o_ind).sum())
+
+    def ks_two_sample(a, b):  # sup |F_a - F_b| of two equal-size samples (identical samples give 1/n: ties)
+        both = np.concatenate([a, b])
+        order = np.argsort(both, kind="stable")
+        steps = np.where(order < a.size, 1.0, -1.0)
+        return float(np.abs(np.cumsum(steps)).max() / a.size)
     return {
         "cpu_baseline": {"value": nall / t_all, "unit": "samples/s", "cores": cores, "kind": "port",
                          "sample": f"first {nall} chains of the same workload and Philox stream (C oracle, OpenMP over samples, {cores} threads)",
@@ -266,7 +272,9 @@ def cpu_baseline_and_parity(kdehip, plan, pts_all, bw_all, D, M, N, Nout, Niter,
         "parity": {"samples_checked": nall, "label_mismatches": mism,
                    "max_abs_point_diff": float(np.abs(g_pts - o_pts).max()),
                    "moment_mean_diff": float(np.abs(g_pts.mean(axis=1) - o_pts.mean(axis=1)).max()),
-                   "moment_var_diff": float(np.abs(g_pts.var(axis=1) - o_pts.var(axis=1)).max())},
+                   "moment_var_diff": float(np.abs(g_pts.var(axis=1) - o_pts.var(axis=1)).max()),
+                   # two-sample Kolmogorov-Smirnov statistic per dimension, GPU pGM vs oracle pGM (north_star gate)
+                   "ks_max": max(ks_two_sample(g_pts[d], o_pts[d]) for d in range(g_pts.shape[0]))},
     }
 
 

@@ -33,6 +33,7 @@ def test_bench_single_gpu_json_contract():
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert d["parity"]["label_mismatches"] == 0 and d["parity"]["moment_mean_diff"] < 1e-6
+    assert d["parity"]["moment_var_diff"] < 1e-6 and d["parity"]["ks_max"] <= 2.0 / d["parity"]["samples_checked"]
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
 
 
