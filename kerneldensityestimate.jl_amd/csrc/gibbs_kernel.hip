@@ -8,7 +8,7 @@
 //
 // Mapping (MI355X-first, not a translation of the Julia loop nest):
 //   * one 64-lane wavefront owns one output sample (one Gibbs chain); chains never communicate.
-//     8 chains (16 from 4096 chains on) share a workgroup, one workgroup per CU, and walk the
+//     8 chains (16 once there are more than 8 chains per CU) share a workgroup, one workgroup per CU, and walk the
 //     data-independent (level, pass, density) schedule in lock step so that the tile every wavefront
 //     is about to read is staged ONCE per workgroup into LDS with direct-to-LDS loads
 //     (buffer_load_dwordx4 ... lds): levels whose tiles all fit the 120 KiB pool stay resident for the
@@ -990,7 +990,10 @@ static int launch_waves(const PlanDev &plan, const RunArgs &args, hipStream_t st
 template <typename T, int D, int MODE>
 static int launch_one(const PlanDev &plan, const RunArgs &args, hipStream_t stream) {
   if (args.Np <= 0) return KDEHIP_OK;
-  const bool wide = (args.variant % 1000 == 16) || (args.variant % 1000 != 8 && args.Np >= 16 * 256);
+  // 8 chains per workgroup while that still gives every CU at most one workgroup (one round over the chip);
+  // beyond that 16 chains per workgroup: 4 wavefronts per SIMD hide each other's latencies
+  const bool wide = (args.variant % 1000 == 16) ||
+                    (args.variant % 1000 != 8 && args.Np > static_cast<int64_t>(8) * device_cu_count());
   if (wide) launch_waves<T, D, MODE, 16>(plan, args, stream);
   else launch_waves<T, D, MODE, 8>(plan, args, stream);
   const hipError_t e = hipGetLastError();

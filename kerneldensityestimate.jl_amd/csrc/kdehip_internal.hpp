@@ -135,6 +135,9 @@ enum ArithMode : int {
   kModeFast = 1,       // product/rsqrt + uniform-bandwidth forms, every dimension active
   kModeFastMasked = 2  // the same with partialDimMask / uninformed dimensions
 };
+// Compute units of the current device (cached per device ordinal); 256 on MI355X.
+int device_cu_count();
+
 int launch_gibbs(int precision, int mode, const PlanDev &plan, const RunArgs &args, void *stream);
 
 }  // namespace kdehip
