@@ -569,7 +569,7 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan,
   constexpr bool kAllDimsOn = (MODE == kModeFast);    // the plan checked it: no mask tests in this build
   // pass 1 prefetches the next row's fields while it evaluates the current one; the 16-wavefront fp64
   // builds have 128 VGPRs and would spill from D = 6 on
-  constexpr bool kPrefetchRows = (WAVES == 8) || sizeof(T) == 4 || D <= 4;
+  constexpr bool kPrefetchRows = (WAVES <= 8) || sizeof(T) == 4 || D <= 4;
   using Lay = LdsLayout<T, D, WAVES>;
   __shared__ __attribute__((aligned(1024))) unsigned char smem[Lay::kBytes];
 
@@ -598,7 +598,7 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan,
   unsigned char *pool = smem + Lay::kPoolOff;
   const int dl = lane < D ? lane : D - 1;  // this lane's dimension in the "lanes = dimensions" phases
 
-  // variant: 0 default; 1 = read every tile from global memory (no LDS staging); 8 / 16 = workgroup width.
+  // variant: 0 default; 1 = read every tile from global memory (no LDS staging); 2 / 8 / 16 = 4 / 8 / 16 chains per workgroup.
   // Diagnostic builds (-DKDEHIP_EXPERIMENTS, scripts/) add level cut-offs and ablation flags.
   const int vlev = a.variant % 1000;
 #ifdef KDEHIP_EXPERIMENTS
@@ -992,18 +992,21 @@ static int launch_one(const PlanDev &plan, const RunArgs &args, hipStream_t stre
   if (args.Np <= 0) return KDEHIP_OK;
   // 8 chains per workgroup while that still gives every CU at most one workgroup (one round over the chip);
   // beyond that 16 chains per workgroup: 4 wavefronts per SIMD hide each other's latencies
-  const bool wide = (args.variant % 1000 == 16) ||
-                    (args.variant % 1000 != 8 && args.Np > static_cast<int64_t>(8) * device_cu_count());
-  if (wide) launch_waves<T, D, MODE, 16>(plan, args, stream);
-  else launch_waves<T, D, MODE, 8>(plan, args, stream);
+  // ... and only 4 while even that leaves CUs idle: one wavefront per SIMD runs a chain at its shortest latency
+  const int v = args.variant % 1000;
+  const int64_t cus = device_cu_count();
+  const int waves = (v == 8 || v == 16) ? v : (v == 2 ? 4 : (args.Np > 8 * cus ? 16 : (args.Np > 4 * cus ? 8 : 4)));
+  if (waves == 16) launch_waves<T, D, MODE, 16>(plan, args, stream);
+  else if (waves == 8) launch_waves<T, D, MODE, 8>(plan, args, stream);
+  else launch_waves<T, D, MODE, 4>(plan, args, stream);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess)
     return set_error(KDEHIP_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString(e));
   return KDEHIP_OK;
 }
 
-// This file is compiled once per dimension count (-DKDEHIP_DIM=1..8, see the Makefile) so the 12 kernel
-// variants of each dimension (2 precisions x 3 arithmetic modes x 2 workgroup widths) build in parallel.
+// This file is compiled once per dimension count (-DKDEHIP_DIM=1..8, see the Makefile) so the 18 kernel
+// variants of each dimension (2 precisions x 3 arithmetic modes x 3 workgroup widths) build in parallel.
 #ifndef KDEHIP_DIM
 #error "compile gibbs_kernel.hip with -DKDEHIP_DIM=<1..8>"
 #endif
