@@ -59,6 +59,10 @@ typedef struct kdehip_density {
 int kdehip_version(void);
 const char *kdehip_last_error(void);
 int kdehip_device_count(void); /* 0 when no device is usable */
+/* The library keeps freed device / pinned-host blocks (up to 1 GiB per device) for the next call instead of
+ * returning them to the driver: a one-shot product would otherwise spend most of its time in hipMalloc/hipFree.
+ * This hands everything back (no reference counterpart: Julia's GC owns the reference's scratch). */
+void kdehip_clear_cache(void);
 
 /* ---- (1) drop-in for gibbs1 (reference src/MSGibbs01.jl:527-537) ------------------------------
  * Host buffers in, host buffers out, blocking.  Arguments in the reference's order:
@@ -103,6 +107,7 @@ typedef struct kdehip_product_info_t {
 /* precision: 64 (reference arithmetic) or 32.  mask as in kdehip_gibbs1. */
 int kdehip_product_create(kdehip_product **out, int Ndens, const kdehip_density *trees, int ndims,
                           const uint8_t *partialDimMask, int precision, int device);
+/* (waits for the device first if runs were enqueued through the device-pointer entry points below) */
 void kdehip_product_destroy(kdehip_product *plan);
 int kdehip_product_info(const kdehip_product *plan, kdehip_product_info_t *info);
 /* Per-sample RNG consumption for a given Niter: K uniforms (first M slots never read), R normals. */

@@ -44,6 +44,7 @@ SIGNATURES = {
     "kdehip_version": (C.c_int, []),
     "kdehip_last_error": (C.c_char_p, []),
     "kdehip_device_count": (C.c_int, []),
+    "kdehip_clear_cache": (None, []),
     "kdehip_gibbs1": (C.c_int, [C.c_int, C.POINTER(CDensity), C.c_int64, C.c_int, f64p, i64p, f64p, C.c_int64,
                                 f64p, C.c_int64, C.c_int, C.c_int, u8p, C.c_int]),
     "kdehip_gibbs1_trace": (C.c_int, [C.c_int, C.POINTER(CDensity), C.c_int64, C.c_int, f64p, i64p, f64p, C.c_int64,

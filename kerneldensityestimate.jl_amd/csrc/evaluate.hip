@@ -36,10 +36,11 @@ constexpr int kEvalChunk = 128;    // source points per block
       return set_error(KDEHIP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
   } while (0)
 
-struct DevBuf {
+struct DevBuf {  // device scratch of one call, from the library's allocation cache (devmem.cpp)
   void *p = nullptr;
-  ~DevBuf() { if (p) (void)hipFree(p); }
-  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+  size_t n = 0;
+  ~DevBuf() { if (p) cached_free(p, n); }
+  hipError_t alloc(size_t bytes) { n = bytes ? bytes : 1; return cached_malloc(&p, n); }
   template <typename T> T *as() { return static_cast<T *>(p); }
 };
 
@@ -360,9 +361,11 @@ extern "C" int kdehip_auto_bandwidth(int64_t D64, int64_t N, const double *point
   // pinned host memory: no device buffer, no copy, one stream synchronisation per round
   struct Pinned {
     double *p = nullptr;
-    ~Pinned() { if (p) (void)hipHostFree(p); }
+    size_t n = 0;
+    ~Pinned() { if (p) cached_host_free(p, n); }
   } h_pin;
-  KDEHIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&h_pin.p), sizeof(double) * D * nfb, hipHostMallocDefault));
+  h_pin.n = sizeof(double) * D * nfb;
+  KDEHIP_CHECK(cached_host_malloc(reinterpret_cast<void **>(&h_pin.p), h_pin.n));
   KDEHIP_CHECK(hipMemcpy(d_x.p, xo.data(), sizeof(double) * D * N, hipMemcpyHostToDevice));
   KDEHIP_CHECK(hipMemcpy(d_w.p, wts.data(), sizeof(double) * D * N, hipMemcpyHostToDevice));
 

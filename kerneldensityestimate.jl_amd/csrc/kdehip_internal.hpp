@@ -1,6 +1,9 @@
 // kdehip_internal.hpp -- shared declarations of libkdehip.so (host side + PODs passed to kernels).
 #pragma once
 
+#include <hip/hip_runtime_api.h>
+
+#include <cstddef>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -135,6 +138,13 @@ enum ArithMode : int {
   kModeFast = 1,       // product/rsqrt + uniform-bandwidth forms, every dimension active
   kModeFastMasked = 2  // the same with partialDimMask / uninformed dimensions
 };
+// Device / pinned-host allocations through the library's cache (devmem.cpp).  `bytes` of the free must be the
+// `bytes` of the allocation.  Only free a block once the work using it has completed.
+hipError_t cached_malloc(void **out, size_t bytes);
+void cached_free(void *p, size_t bytes);
+hipError_t cached_host_malloc(void **out, size_t bytes);
+void cached_host_free(void *p, size_t bytes);
+
 // Compute units of the current device (cached per device ordinal); 256 on MI355X.
 int device_cu_count();
 

@@ -22,6 +22,8 @@ struct kdehip_product {
   int variant = 0;
   PackedProduct host;  // descriptors (payload vectors are released after upload)
   void *d_blob = nullptr;   // the one device allocation of the plan; the pointers below point into it
+  size_t blob_bytes = 0;
+  bool async_pending = false;  // a run was enqueued through a device-pointer entry point and not waited for here
   void *d_data = nullptr;
   int32_t *d_perm = nullptr;
   LevelDesc *d_levels = nullptr;
@@ -95,9 +97,9 @@ int maybe_build_tables(kdehip_product *plan, int64_t Np, RunArgs &a, void *strea
 // hipMalloc / hipFree once it is large enough).  Callers hold plan->work_mutex.
 int reserve_work(kdehip_product *plan, size_t bytes) {
   if (bytes <= plan->work_cap) return KDEHIP_OK;
-  if (plan->d_work) { (void)hipFree(plan->d_work); plan->d_work = nullptr; plan->work_cap = 0; }
-  const size_t cap = (bytes + (bytes >> 2) + 4095) & ~static_cast<size_t>(4095);
-  KDEHIP_CHECK(hipMalloc(&plan->d_work, cap));
+  if (plan->d_work) { cached_free(plan->d_work, plan->work_cap); plan->d_work = nullptr; plan->work_cap = 0; }
+  const size_t cap = (bytes + 4095) & ~static_cast<size_t>(4095);
+  KDEHIP_CHECK(cached_malloc(&plan->d_work, cap));
   plan->work_cap = cap;
   return KDEHIP_OK;
 }
@@ -157,7 +159,8 @@ int kdehip_product_create(kdehip_product **out, int Ndens, const kdehip_density 
     float *f = reinterpret_cast<float *>(blob.data() + off_data);
     for (size_t i = 0; i < nelem; ++i) f[i] = static_cast<float>(p->host.data[i]);
   }
-  hipError_t e = hipMalloc(&p->d_blob, total);
+  hipError_t e = cached_malloc(&p->d_blob, total);
+  if (e == hipSuccess) p->blob_bytes = total;
   if (e == hipSuccess) e = hipMemcpy(p->d_blob, blob.data(), off_tables, hipMemcpyHostToDevice);
   if (e != hipSuccess) {
     const std::string m = std::string("plan upload: ") + hipGetErrorString(e);
@@ -191,8 +194,11 @@ int kdehip_product_create(kdehip_product **out, int Ndens, const kdehip_density 
 void kdehip_product_destroy(kdehip_product *plan) {
   if (!plan) return;
   if (hipSetDevice(plan->device) == hipSuccess) {
-    if (plan->d_blob) (void)hipFree(plan->d_blob);
-    if (plan->d_work) (void)hipFree(plan->d_work);
+    // the blocks go back to the allocation cache and may be handed out again at once: work enqueued on the
+    // caller's streams must be over (hipFree used to imply this)
+    if (plan->async_pending) (void)hipDeviceSynchronize();
+    if (plan->d_blob) cached_free(plan->d_blob, plan->blob_bytes);
+    if (plan->d_work) cached_free(plan->d_work, plan->work_cap);
   }
   delete plan;
 }
@@ -250,6 +256,7 @@ int kdehip_product_sample_streams(kdehip_product *plan, int64_t Np, int Niter, c
   a.points = d_points; a.indices = d_indices; a.labels = d_labels;
   rc = maybe_build_tables(plan, Np, a, stream);
   if (rc != KDEHIP_OK) return rc;
+  plan->async_pending = true;
   return launch_gibbs(plan->precision, plan->mode, plan->dev, a, stream);
 }
 
@@ -271,6 +278,7 @@ int kdehip_product_sample_philox(kdehip_product *plan, int64_t Np, int Niter, ui
   a.points = d_points; a.indices = d_indices; a.labels = d_labels;
   rc = maybe_build_tables(plan, Np, a, stream);
   if (rc != KDEHIP_OK) return rc;
+  plan->async_pending = true;
   return launch_gibbs(plan->precision, plan->mode, plan->dev, a, stream);
 }
 
@@ -291,12 +299,14 @@ int kdehip_product_sample_philox_host(kdehip_product *plan, int64_t Np, int Nite
   double *dp = reinterpret_cast<double *>(w);
   int64_t *di = reinterpret_cast<int64_t *>(w + off_i);
   int32_t *dl = labels ? reinterpret_cast<int32_t *>(w + off_l) : nullptr;
+  const bool was_pending = plan->async_pending;  // an earlier run on a caller stream may still be in flight
   rc = kdehip_product_sample_philox(plan, Np, Niter, seed, sample_offset, addEntropy, dp, di, dl, nullptr);
   if (rc != KDEHIP_OK) return rc;
   // (the blocking copies on the null stream wait for the kernel)
   KDEHIP_CHECK(hipMemcpy(points, dp, sizeof(double) * D * Np, hipMemcpyDeviceToHost));
   KDEHIP_CHECK(hipMemcpy(indices, di, sizeof(int64_t) * M * Np, hipMemcpyDeviceToHost));
   if (labels) KDEHIP_CHECK(hipMemcpy(labels, dl, sizeof(int32_t) * M * L * Np, hipMemcpyDeviceToHost));
+  plan->async_pending = was_pending;  // (the blocking copies waited for this call's run)
   return KDEHIP_OK;
 }
 
@@ -348,6 +358,7 @@ int kdehip_gibbs1_trace(int Ndens, const kdehip_density *trees, int64_t Np, int 
   KDEHIP_CHECK(hipMemcpy(pts, dp, sizeof(double) * D * Np, hipMemcpyDeviceToHost));
   KDEHIP_CHECK(hipMemcpy(ind, di, sizeof(int64_t) * M * Np, hipMemcpyDeviceToHost));
   if (trace) KDEHIP_CHECK(hipMemcpy(labels, dl, lab_bytes, hipMemcpyDeviceToHost));
+  plan->async_pending = false;  // the blocking copies waited for the run (the plan is private to this call)
   return KDEHIP_OK;
 }
 

@@ -4,7 +4,7 @@ set -e
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 cd $REPO/kerneldensityestimate.jl_amd/csrc
 mkdir -p $REPO/gpurun_out/stamps
-for f in balltree.cpp pack_levels.cpp gibbs_dispatch.cpp; do /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off -x hip --offload-arch=gfx950 -c $f -o $REPO/gpurun_out/stamps/$f.o & done
+for f in balltree.cpp pack_levels.cpp gibbs_dispatch.cpp devmem.cpp; do /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off -x hip --offload-arch=gfx950 -c $f -o $REPO/gpurun_out/stamps/$f.o & done
 for f in product.hip evaluate.hip; do /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -c $f -o $REPO/gpurun_out/stamps/$f.o & done
 for d in 1 2 3 4 5 6 7 8; do /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -DKDEHIP_STAMPS -DKDEHIP_EXPERIMENTS -mllvm -disable-vector-combine -DKDEHIP_DIM=$d -c gibbs_kernel.hip -o $REPO/gpurun_out/stamps/gibbs_kernel_d$d.o & done
 wait

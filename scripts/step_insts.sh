@@ -6,7 +6,7 @@ OUT=$REPO/gpurun_out/sinst
 mkdir -p $OUT
 cd $REPO/kerneldensityestimate.jl_amd/csrc
 CXX="/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950"
-for f in balltree.cpp pack_levels.cpp gibbs_dispatch.cpp; do $CXX -x hip -c $f -o $OUT/$f.o & done
+for f in balltree.cpp pack_levels.cpp gibbs_dispatch.cpp devmem.cpp; do $CXX -x hip -c $f -o $OUT/$f.o & done
 for f in product.hip evaluate.hip; do $CXX -c $f -o $OUT/$f.o & done
 for d in 1 2 3 4 5 6 7 8; do $CXX -DKDEHIP_EXPERIMENTS -mllvm -disable-vector-combine -DKDEHIP_DIM=$d -c gibbs_kernel.hip -o $OUT/gibbs_kernel_d$d.o & done
 wait

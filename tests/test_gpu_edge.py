@@ -178,3 +178,23 @@ def test_very_large_ragged_densities():
     randU, randN = rng.random(nU), rng.standard_normal(nN)
     g = kdehip.prodAppxMSGibbsS(None, gp, None, None, Niter=Niter, Np=Np, randU=randU, randN=randN)
     _compare(g, oracle.gibbs1(op, Np, Niter, randU, randN, nthreads=8))
+
+
+def test_allocation_cache_reuse_and_clear():
+    """One-shot calls recycle device blocks through the library's cache; results are unaffected, interleaved
+    sizes do not alias, and kdehip_clear_cache() is harmless between calls."""
+    from kdehip import _lib
+    rng = np.random.default_rng(21)
+    cases = []
+    for D, M, N, Np in [(2, 2, 50, 40), (3, 3, 300, 500), (2, 2, 50, 40), (4, 2, 1000, 100)]:
+        gp, op = _make_inputs(200 + N, D, M, N)
+        K, R, nU, nN = oracle.rng_sizes(M, D, Np, 2, [N] * M)
+        cases.append((gp, op, Np, rng.random(nU), rng.standard_normal(nN)))
+    for rep in range(3):
+        for gp, op, Np, randU, randN in cases:
+            g = kdehip.prodAppxMSGibbsS(None, gp, None, None, Niter=2, Np=Np, randU=randU, randN=randN)
+            _compare(g, oracle.gibbs1(op, Np, 2, randU, randN))
+            p = kdehip.evaluateDualTree(gp[0], kdehip.getPoints(gp[1])[:, :17])
+            assert np.allclose(p, oracle.eval_direct(op[0], kdehip.getPoints(gp[1])[:, :17]), rtol=1e-11)
+        if rep == 1:
+            _lib.lib.kdehip_clear_cache()
