@@ -134,7 +134,7 @@ int kdehip_product_sample_philox_host(kdehip_product *plan, int64_t Np, int Nite
                                       int64_t *indices, int32_t *labels);
 /* Scheduling knob for experiments/benchmarks; results never depend on it.  0 = library default,
  * 1 = read every tile from global memory (no LDS staging), 4 = no conditional tables,
- * 2 / 8 / 16 = 4 / 8 / 16 chains per workgroup (default: by chains per compute unit). */
+ * 2 / 8 / 12 / 16 = 4 / 8 / 12 / 16 chains per workgroup (default: chosen from the number of chains). */
 int kdehip_product_set_variant(kdehip_product *plan, int variant);
 
 /* ---- (3) host twin of the device RNG ----------------------------------------------------------

@@ -569,7 +569,7 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan,
   constexpr bool kAllDimsOn = (MODE == kModeFast);    // the plan checked it: no mask tests in this build
   // pass 1 prefetches the next row's fields while it evaluates the current one; the 16-wavefront fp64
   // builds have 128 VGPRs and would spill from D = 6 on
-  constexpr bool kPrefetchRows = (WAVES <= 8) || sizeof(T) == 4 || D <= 4;
+  constexpr bool kPrefetchRows = (WAVES <= 12) || sizeof(T) == 4 || D <= 4;
   using Lay = LdsLayout<T, D, WAVES>;
   __shared__ __attribute__((aligned(1024))) unsigned char smem[Lay::kBytes];
 
@@ -598,7 +598,7 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan,
   unsigned char *pool = smem + Lay::kPoolOff;
   const int dl = lane < D ? lane : D - 1;  // this lane's dimension in the "lanes = dimensions" phases
 
-  // variant: 0 default; 1 = read every tile from global memory (no LDS staging); 2 / 8 / 16 = 4 / 8 / 16 chains per workgroup.
+  // variant: 0 default; 1 = read every tile from global memory (no LDS staging); 2 / 8 / 12 / 16 = 4 / 8 / 12 / 16 chains per workgroup.
   // Diagnostic builds (-DKDEHIP_EXPERIMENTS, scripts/) add level cut-offs and ablation flags.
   const int vlev = a.variant % 1000;
 #ifdef KDEHIP_EXPERIMENTS
@@ -990,13 +990,27 @@ static int launch_waves(const PlanDev &plan, const RunArgs &args, hipStream_t st
 template <typename T, int D, int MODE>
 static int launch_one(const PlanDev &plan, const RunArgs &args, hipStream_t stream) {
   if (args.Np <= 0) return KDEHIP_OK;
-  // 8 chains per workgroup while that still gives every CU at most one workgroup (one round over the chip);
-  // beyond that 16 chains per workgroup: 4 wavefronts per SIMD hide each other's latencies
-  // ... and only 4 while even that leaves CUs idle: one wavefront per SIMD runs a chain at its shortest latency
+  // Chains per workgroup (= wavefronts per CU, one workgroup per CU at a time): fewer wavefronts per SIMD run
+  // each chain faster, more hide each other's latencies.  Pick the width with the smallest estimated time
+  // rounds(width) * cost(width); the relative costs of one round are measured ones (config 3: 0.68, 0.89,
+  // 1.19, 1.40 ms for 4, 8, 12, 16 chains per workgroup) and differ little between shapes.
   const int v = args.variant % 1000;
   const int64_t cus = device_cu_count();
-  const int waves = (v == 8 || v == 16) ? v : (v == 2 ? 4 : (args.Np > 8 * cus ? 16 : (args.Np > 4 * cus ? 8 : 4)));
+  int waves = 16;
+  if (v == 8 || v == 12 || v == 16) waves = v;
+  else if (v == 2) waves = 4;
+  else {
+    static const int kWidth[4] = {4, 8, 12, 16};
+    static const double kCost[4] = {1.0, 1.31, 1.75, 2.06};
+    double best = 0.0;
+    for (int i = 0; i < 4; ++i) {
+      const int64_t wgs = (args.Np + kWidth[i] - 1) / kWidth[i];
+      const double t = static_cast<double>((wgs + cus - 1) / cus) * kCost[i];
+      if (i == 0 || t < best) { best = t; waves = kWidth[i]; }
+    }
+  }
   if (waves == 16) launch_waves<T, D, MODE, 16>(plan, args, stream);
+  else if (waves == 12) launch_waves<T, D, MODE, 12>(plan, args, stream);
   else if (waves == 8) launch_waves<T, D, MODE, 8>(plan, args, stream);
   else launch_waves<T, D, MODE, 4>(plan, args, stream);
   const hipError_t e = hipGetLastError();
@@ -1005,8 +1019,8 @@ static int launch_one(const PlanDev &plan, const RunArgs &args, hipStream_t stre
   return KDEHIP_OK;
 }
 
-// This file is compiled once per dimension count (-DKDEHIP_DIM=1..8, see the Makefile) so the 18 kernel
-// variants of each dimension (2 precisions x 3 arithmetic modes x 3 workgroup widths) build in parallel.
+// This file is compiled once per dimension count (-DKDEHIP_DIM=1..8, see the Makefile) so the 24 kernel
+// variants of each dimension (2 precisions x 3 arithmetic modes x 4 workgroup widths) build in parallel.
 #ifndef KDEHIP_DIM
 #error "compile gibbs_kernel.hip with -DKDEHIP_DIM=<1..8>"
 #endif
