@@ -1,5 +1,5 @@
-// fastexp.hpp -- fp64 exp for non-positive arguments on gfx950: 32-entry table (held in LDS: exactly one
-// bank row, so the per-lane lookup is conflict free) + degree-6 polynomial, ~1 ulp, ~17 instructions
+// fastexp.hpp -- fp64 exp for non-positive arguments on gfx950: 32-entry table (held in LDS, 256 bytes;
+// lanes that pick the same entry are served by a broadcast) + degree-6 polynomial, ~1 ulp, ~17 instructions
 // (the library exp is ~30).  Shared by the sampler (gibbs_kernel.hip) and the evaluation kernels
 // (evaluate.hip).
 #pragma once

@@ -8,8 +8,8 @@
 //
 // Mapping (MI355X-first, not a translation of the Julia loop nest):
 //   * one 64-lane wavefront owns one output sample (one Gibbs chain); chains never communicate.
-//     8 chains (16 once there are more than 8 chains per CU) share a workgroup, one workgroup per CU, and walk the
-//     data-independent (level, pass, density) schedule in lock step so that the tile every wavefront
+//     4, 8, 12 or 16 chains (picked per launch, see launch_one) share a workgroup, one workgroup per CU,
+//     and walk the data-independent (level, pass, density) schedule in lock step so that the tile every wavefront
 //     is about to read is staged ONCE per workgroup into LDS with direct-to-LDS loads
 //     (buffer_load_dwordx4 ... lds): levels whose tiles all fit the 120 KiB pool stay resident for the
 //     whole level; larger ones are streamed one tile per step through a double buffer (the copy of
@@ -17,7 +17,8 @@
 //     are streamed through the two halves a few rows at a time (one barrier per chunk);
 //   * inside a (level, density) step the lanes are the frontier nodes: lane `ln` owns the
 //     contiguous entries ln*B .. ln*B+B-1 (B = ceil(n/64)), reads them row by row with coalesced
-//     loads (one address per row, fields at constant offsets), keeps a private running sum, and
+//     loads (one address per row, fields at constant offsets; the next row is requested while the
+//     current one is evaluated, two rows interleaved per trip), keeps a private running sum, and
 //     ONE DPP wavefront prefix scan turns the 64 lane sums into the cumulative weights the
 //     categorical draw needs; the winning lane's block is then re-evaluated by the whole wavefront
 //     (one more pass over <= 64 nodes) and scanned again to find the node.  No p[] array is ever
@@ -41,7 +42,7 @@
 //            inputs whose variance products could leave the range of T or are not finite/positive.
 // partialDimMask products (and one-density "products") run UNIFORM/FAST with the inactive dimensions
 // contributing c = 1, delta = 0 (MODE = fast-masked).
-// fp64 exp on the fast forms is a 32-entry-table (LDS, one bank row, conflict free) + degree-6
+// fp64 exp on the fast forms is a 32-entry-table (256 bytes of LDS) + degree-6
 // polynomial, ~1 ulp; the GENERIC form calls the library exp/log.
 //
 // Compiled with -ffp-contract=off; fused multiply-adds are written explicitly where wanted.
