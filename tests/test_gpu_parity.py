@@ -405,3 +405,27 @@ def test_record_choosen_label_trace_like_the_reference_example():
     want = np.sort([np.mean([kdehip.getPoints(X[j])[0, g1.labelsChoosen[s][j + 1][L] - 1] for j in range(3)])
                     for s in (1, 2, 3)])
     assert np.allclose(got, want, atol=1e-12)
+
+
+@pytest.mark.parametrize("D,Ns,Np,Niter,mask", [
+    (1, [3, 3], 4, 1, None), (1, [1, 6], 5, 2, None), (2, [9, 14, 5], 6, 2, None), (3, [20, 33], 5, 3, None),
+    (2, [12, 12, 12], 8, 2, [[1, 0], [1, 1], [0, 1]]), (2, [10], 4, 1, None), (2, [70, 130], 6, 2, None),
+])
+def test_gpu_against_the_pure_python_restatement(D, Ns, Np, Niter, mask):
+    """The HIP path directly against tests/pymodel.py -- the second, independently written reading of the
+    reference (1-based indexing, the reference's own loop structure), without the C oracle in between."""
+    from tests import pymodel
+    rng = np.random.default_rng(13 * D + len(Ns) + Np)
+    raw = [rng.standard_normal((D, n)) for n in Ns]
+    kss = [list(rng.uniform(0.2, 0.6, D)) for _ in Ns]
+    ws = [list(rng.uniform(0.3, 1.0, n)) for n in Ns]
+    gt = [kdehip.kde(p, k, np.array(w)) for p, k, w in zip(raw, kss, ws)]
+    mt = [pymodel.kde([list(p[:, i]) for i in range(p.shape[1])], k, w) for p, k, w in zip(raw, kss, ws)]
+    K, R, nU, nN = oracle.rng_sizes(len(Ns), D, Np, Niter, Ns)
+    randU, randN = rng.random(nU), rng.standard_normal(nN)
+    for addEntropy in (True, False):
+        gp, gi = kdehip.prodAppxMSGibbsS(None, gt, None, None, Niter=Niter, Np=Np, randU=randU, randN=randN,
+                                         addEntropy=addEntropy, partialDimMask=mask)
+        mp, mi = pymodel.prodAppxMSGibbsS(mt, Np, Niter, list(randU), list(randN), addEntropy, mask)
+        assert np.array_equal(gi, np.array(mi, dtype=np.int64))
+        assert np.allclose(gp, np.array(mp, dtype=float), rtol=1e-12, atol=1e-13)
