@@ -198,8 +198,8 @@ def gibbs1(Ndens, trees, Np, Niter, pts, ind, randU, randN, *, addEntropy=True, 
     return None
 
 
-def prodAppxMSGibbsS(npd0, trees, anFcns=None, anParams=None, *, Niter=3, addEntropy=True, ndims=None,
-                     Ndens=None, Np=None, randU=None, randN=None, partialDimMask=None,
+def prodAppxMSGibbsS(npd0, trees, anFcns=None, anParams=None, *deprecated_niter, Niter=3, addEntropy=True, ndims=None,
+                     Ndens=None, Np=None, maxNp=None, Nlevels=None, randU=None, randN=None, partialDimMask=None,
                      addop=None, diffop=None, getMu=None, getLambda=None, glbs=None,
                      seed=None, device=0, precision=64):
     """`prodAppxMSGibbsS` (reference src/MSGibbs01.jl:645-703).
@@ -209,7 +209,16 @@ def prodAppxMSGibbsS(npd0, trees, anFcns=None, anParams=None, *, Niter=3, addEnt
     them; otherwise (the reference would call rand/randn) the on-device Philox stream keyed by
     `seed` is used.  Returns (points[ndims, Np], indices[Ndens, Np]).
     Non-Euclidean addop/diffop/getMu/getLambda cannot cross the C ABI and are rejected.
+    `maxNp` / `Nlevels` only size the reference's default random arrays (:659-662; `gibbs1` recomputes the level
+    count from the trees, :568) and are accepted and ignored; a fifth positional argument is the deprecated
+    positional `Niter` (:632-643).
     """
+    if deprecated_niter:
+        if len(deprecated_niter) > 1:
+            raise TypeError("prodAppxMSGibbsS takes at most 5 positional arguments")
+        import warnings
+        warnings.warn("prodApproxMSGibbs has new keyword interface, use (..; Niter::Int=5 ) instead", DeprecationWarning)
+        Niter = int(deprecated_niter[0])
     for name, v in (("addop", addop), ("diffop", diffop), ("getMu", getMu), ("getLambda", getLambda)):
         if v is not None:
             raise NotImplementedError(f"{name}: only the Euclidean defaults exist behind the HIP path")

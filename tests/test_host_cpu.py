@@ -170,3 +170,20 @@ def test_no_device_fails_loudly_instead_of_falling_back():
 def test_nlevels_formula():
     for n, L in [(1, 1), (2, 2), (3, 2), (4, 3), (100, 7), (200, 8), (1000, 10), (1024, 11), (5000, 13), (10000, 14)]:
         assert kdehip.nlevels(n) == L == oracle.nlevels(n)
+
+
+def test_prod_front_end_keyword_surface():
+    """The reference's keyword list (src/MSGibbs01.jl:645-664) is accepted; argument errors are raised before any
+    device work (so this runs without a GPU)."""
+    import inspect
+    names = set(inspect.signature(kdehip.prodAppxMSGibbsS).parameters)
+    for kw in ("Niter", "addop", "diffop", "getMu", "getLambda", "glbs", "addEntropy", "ndims", "Ndens", "Np", "maxNp",
+               "Nlevels", "randU", "randN", "partialDimMask"):
+        assert kw in names, kw
+    p = kdehip.kde(np.array([[0.0, 1.0, 2.0]]), [0.5])
+    with pytest.raises(NotImplementedError):
+        kdehip.prodAppxMSGibbsS(p, [p, p], None, None, addop=(lambda a, b: a + b,))
+    with pytest.raises(ValueError):
+        kdehip.prodAppxMSGibbsS(p, [p, p], None, None, randU=np.zeros(10))
+    with pytest.raises(TypeError):
+        kdehip.prodAppxMSGibbsS(p, [p, p], None, None, 3, 4)
