@@ -171,8 +171,22 @@ static __device__ unsigned long long g_stamp_acc[16];
 #define KSTAMP_ADD(slot, t0, t1) do {} while (0)
 #endif
 
+template <typename P> constexpr bool kIsLdsPointer = false;
+template <typename T> constexpr bool kIsLdsPointer<const __attribute__((address_space(3))) T *> = true;
+
 // ---- kernel evaluation of one frontier entry -----------------------------------------------------
 // `e` points at (row, field 0, lane) of the entry (LDS or global pointer); field f is at e[f*64].
+
+// A load the compiler may not merge with its neighbours: the two halves of a packed fp32 pair come from two
+// rows; merged ds_read2 loads of two FIELDS of one row would land in the wrong register pairing and cost a
+// v_mov per value to untangle.
+template <typename P>
+__device__ __forceinline__ float load_single(P p) {
+  using E = std::remove_pointer_t<P>;
+  using VP = std::conditional_t<kIsLdsPointer<P>, volatile __attribute__((address_space(3))) const float *, volatile const float *>;
+  (void)sizeof(E);
+  return *(VP)(p);
+}
 
 // UNIFORM: the level has one bandwidth vector; ninv[d] = -1/(2 c_d), scale = rsqrt(prod_d c_d).
 template <typename T, int D>
@@ -226,8 +240,8 @@ struct EvalUniform {
   __device__ __forceinline__ kdehip_f2 pair(P e, int RS) const {  // entries at e and e + RS
     RowT<kdehip_f2> r;
 #pragma unroll
-    for (int d = 0; d < D; ++d) r.m[d] = kdehip_f2{e[d * 64], e[RS + d * 64]};
-    r.w = kdehip_f2{e[D * 64], e[RS + D * 64]};
+    for (int d = 0; d < D; ++d) r.m[d] = kdehip_f2{load_single(e + d * 64), load_single(e + RS + d * 64)};
+    r.w = kdehip_f2{load_single(e + D * 64), load_single(e + RS + D * 64)};
     return eval<kdehip_f2>(r);
   }
 };
@@ -303,10 +317,10 @@ struct EvalFast {
     RowT<kdehip_f2> r;
 #pragma unroll
     for (int d = 0; d < D; ++d) {
-      r.m[d] = kdehip_f2{e[d * 64], e[RS + d * 64]};
-      r.v[d] = kdehip_f2{e[(D + d) * 64], e[RS + (D + d) * 64]};
+      r.m[d] = kdehip_f2{load_single(e + d * 64), load_single(e + RS + d * 64)};
+      r.v[d] = kdehip_f2{load_single(e + (D + d) * 64), load_single(e + RS + (D + d) * 64)};
     }
-    r.w = kdehip_f2{e[2 * D * 64], e[RS + 2 * D * 64]};
+    r.w = kdehip_f2{load_single(e + 2 * D * 64), load_single(e + RS + 2 * D * 64)};
     return eval<kdehip_f2>(r);
   }
 };
