@@ -76,6 +76,9 @@ __device__ __forceinline__ float fast_rcp(float x) {
 template <typename T> struct Num;
 template <> struct Num<double> {
   static __device__ __forceinline__ double exp(double x) { return ::exp(x); }
+  // the fast forms hand exp_fast an exponent already multiplied by kExpArg (fp32: log2 e, so that the
+  // hardware's base-2 exponential needs no extra multiply; fp64: 1)
+  static constexpr double kExpArg = 1.0;
   static __device__ __forceinline__ double exp_fast(double x, const double *tab) { return exp_nonpos(x, tab); }
   using ExpMid = ExpSplit;  // exp_fast in two halves (table lookup issued / result formed)
   static __device__ __forceinline__ ExpMid exp_begin(double x, const double *tab) { return exp_nonpos_begin(x, tab); }
@@ -94,10 +97,11 @@ template <> struct Num<double> {
 };
 template <> struct Num<float> {
   static __device__ __forceinline__ float exp(float x) { return __expf(x); }
-  static __device__ __forceinline__ float exp_fast(float x, const double *) { return __expf(x); }
+  static constexpr float kExpArg = 1.44269504088896340736f;
+  static __device__ __forceinline__ float exp_fast(float x, const double *) { return __builtin_amdgcn_exp2f(x); }
   struct ExpMid { float x; };
   static __device__ __forceinline__ ExpMid exp_begin(float x, const double *) { return {x}; }
-  static __device__ __forceinline__ float exp_end(const ExpMid &m) { return __expf(m.x); }
+  static __device__ __forceinline__ float exp_end(const ExpMid &m) { return __builtin_amdgcn_exp2f(m.x); }
   static __device__ __forceinline__ float log(float x) { return __logf(x); }
   static __device__ __forceinline__ float sqrt(float x) { return ::sqrtf(x); }
   static __device__ __forceinline__ float rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }  // normal x: no denormal scaling
@@ -109,7 +113,9 @@ template <> struct Num<float> {
 // the rate of one scalar fp32 instruction, so the fp32 first pass evaluates the rows two at a time.
 typedef float kdehip_f2 __attribute__((ext_vector_type(2)));
 template <> struct Num<kdehip_f2> {
-  static __device__ __forceinline__ kdehip_f2 exp_fast(kdehip_f2 x, const double *) { return {__expf(x.x), __expf(x.y)}; }
+  static __device__ __forceinline__ kdehip_f2 exp_fast(kdehip_f2 x, const double *) {
+    return {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
+  }
   static __device__ __forceinline__ kdehip_f2 rsqrt(kdehip_f2 x) { return {__builtin_amdgcn_rsqf(x.x), __builtin_amdgcn_rsqf(x.y)}; }
   static __device__ __forceinline__ kdehip_f2 fma(kdehip_f2 a, kdehip_f2 b, kdehip_f2 c) {
     return __builtin_elementwise_fma(a, b, c);
@@ -292,7 +298,7 @@ struct EvalFast {
     const V r = Num<V>::rsqrt(prod);
     const V q = num * r * r;  // = sum_d delta_d^2 / c_d
     front = w * r;
-    return V(-0.5) * q;
+    return V(T(-0.5) * T(Num<T>::kExpArg)) * q;
   }
   template <typename V>
   __device__ __forceinline__ V eval(const RowT<V> &row) const {
@@ -682,7 +688,7 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan,
         EvalUniform<T, D> ev;
         ev.tab = sExpTab;
         T c = hdr[dl] + cov;
-        T ni = T(-0.5) * fast_rcp(c);
+        T ni = (T(-0.5) * T(Num<T>::kExpArg)) * fast_rcp(c);
         if constexpr (MASKED) {  // an inactive dimension contributes nothing: c = 1, weight 0
           const bool on = (act >> dl) & 1u;
           c = on ? c : T(1);
