@@ -513,12 +513,88 @@ __device__ __forceinline__ int select_from_scan(T incl, T S, P rows, const Level
 }
 
 // whole tile readable through one pointer (resident / streamed LDS image, or global memory)
-template <typename T, typename P, bool PREFETCH, typename Eval>
+// Frontiers of 2 .. BMAX rows per lane whose tile is in LDS, in builds with registers to spare: the lane keeps
+// the BMAX values of its block from the first pass, so the second pass needs no re-evaluation, no LDS gather
+// and no second wavefront scan -- every lane forms the running sums of its own block (the same sequential
+// sums the first pass accumulates), finds the first row that reaches the target, and the answer is read from
+// the winning lane.  (Rows beyond B are padding of weight 0 in the tile; they are not even evaluated.)
+template <typename T, typename P, typename Eval, int BMAX>
+__device__ __forceinline__ int draw_label_kept(P rows, const LevelDesc &ds, int lane, const Eval &ev, double u) {
+  const int n = ds.n, B = ds.B, F = ds.F;
+  const int RS = F * 64 + 1;
+  T v[BMAX];
+  P e = rows + lane;
+  // first pass: the two-rows-per-trip schedule of lane_sum_rows (next row requested early, the two rows
+  // interleaved around their exp table lookups), fully unrolled so that the values stay in registers
+  typename Eval::Row ra = ev.load(e);
+#pragma unroll
+  for (int i = 0; i < BMAX; i += 2) {
+    if (i + 2 <= B) {  // wave-uniform
+      const typename Eval::Row rb = ev.load(e + (i + 1) * RS);
+      __builtin_amdgcn_sched_barrier(0);
+      const typename Eval::Mid ma = ev.arg(ra);
+      if (i + 2 < B) ra = ev.load(e + (i + 2) * RS);
+      __builtin_amdgcn_sched_barrier(0);
+      const typename Eval::Mid mb = ev.arg(rb);
+      __builtin_amdgcn_sched_barrier(0);
+      v[i] = ev.fin(ma);
+      v[i + 1] = ev.fin(mb);
+    } else if (i < B) {
+      v[i] = ev(ra);
+      v[i + 1] = T(0);
+    } else {
+      v[i] = T(0);
+      v[i + 1] = T(0);
+    }
+  }
+  T S = T(0);
+#pragma unroll
+  for (int i = 0; i < BMAX; ++i) S += v[i];  // (+0 for the rows beyond B: the first pass's sequential sum)
+  const T incl = wave_inclusive_scan(S);
+  const T total = lane_read(incl, 63);
+  if (!(total >= Num<T>::tiny_total())) {  // uniform fallback (:311-315), as in select_from_scan
+    const int zl = n - 1;
+    const T wl = rows[(zl % B) * RS + (F - 1) * 64 + zl / B];
+    int z = n - 1;
+    if (wl > T(0)) {
+      z = static_cast<int>(ceil(u * static_cast<double>(n))) - 1;
+      z = z < 0 ? 0 : (z > n - 1 ? n - 1 : z);
+    }
+    return (z % B) * 64 + z / B;
+  }
+  const T target = static_cast<T>(u) * total;
+  const unsigned long long hit = __ballot(target <= incl);
+  const int last_lane = ds.last_lane;
+  int lstar = hit ? (__ffsll(hit) - 1) : last_lane;
+  if (lstar > last_lane) lstar = last_lane;
+  // second pass, in every lane on its own block: first row r with target <= exclusive prefix + v[0..r]
+  T run = incl - S;
+  int first = BMAX;
+  T c[BMAX];
+#pragma unroll
+  for (int r = 0; r < BMAX; ++r) { run += v[r]; c[r] = run; }
+#pragma unroll
+  for (int r = BMAX - 1; r >= 0; --r) first = (target <= c[r]) ? r : first;
+  int len = n - lstar * B;
+  if (len > B) len = B;
+  int istar = __builtin_amdgcn_readlane(first, lstar);
+  if (istar > len - 1) istar = len - 1;  // no row reached the target (rounding), or only padding rows did
+  return istar * 64 + lstar;
+}
+
+template <typename T, typename P, bool PREFETCH, bool kKeptRows, typename Eval>
 __device__ __forceinline__ int draw_label(P rows, const LevelDesc &ds, int lane, const Eval &ev, double u
 #ifdef KDEHIP_STAMPS
                                           , unsigned long long *stamp_acc, bool stamp_on
 #endif
 ) {
+#if !defined(KDEHIP_STAMPS) && !defined(KDEHIP_NO_KEPT)
+  // PREFETCH marks the builds with registers to spare (see kPrefetchRows); fp32 has its packed-pair first pass
+  if constexpr (PREFETCH && kIsLdsPtr<P> && sizeof(T) == 8 && kKeptRows) {
+    if (ds.B > 1 && ds.B <= 4) return draw_label_kept<T, P, Eval, 4>(rows, ds, lane, ev, u);
+    if (ds.B > 4 && ds.B <= 8) return draw_label_kept<T, P, Eval, 8>(rows, ds, lane, ev, u);
+  }
+#endif
   KSTAMP(tp0);
   const T S = lane_sum_rows<T, P, Eval, PREFETCH>(rows, ds.B, ds.F * 64 + 1, lane, ev);
   KSTAMP(tp1);
@@ -733,7 +809,7 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan,
     auto rows = hdr + kTileHeader;
     using P = decltype(rows);
     const int pos = (vflags & 8) ? 0 : draw(ds, hdr, mean, cov, [&](const auto &ev) {
-      return draw_label<T, P, kPrefetchRows>(rows, ds, lane, ev, u KSTAMP_ARGS);
+      return draw_label<T, P, kPrefetchRows, (WAVES <= 8)>(rows, ds, lane, ev, u KSTAMP_ARGS);
     });
     wave_sync();
     KSTAMP(ts1);
