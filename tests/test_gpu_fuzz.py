@@ -13,7 +13,8 @@ pytestmark = pytest.mark.gpu
 def _random_case(rng):
     D = int(rng.integers(1, 9))
     M = int(rng.integers(1, 7))
-    Ns = [int(rng.choice([1, 2, 3, 5, 8, 16, 31, 32, 33, 64, 65, 100, 128, 200, 257])) for _ in range(M)]
+    Ns = [int(rng.choice([1, 2, 3, 5, 8, 16, 31, 32, 33, 64, 65, 100, 128, 200, 257, 300, 448, 512, 513, 600]))
+          for _ in range(M)]  # up to 10 rows per lane: both second-pass forms and their boundaries
     Np = int(rng.choice([1, 7, 8, 9, 15, 16, 17, 40, 64, 130]))
     Niter = int(rng.integers(0, 4))
     weighted = bool(rng.integers(0, 2))
@@ -27,7 +28,7 @@ def _random_case(rng):
     return D, M, Ns, Np, Niter, weighted, mask
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(60))
 def test_random_products_match_oracle(seed):
     rng = np.random.default_rng(1000 + seed)
     D, M, Ns, Np, Niter, weighted, mask = _random_case(rng)
