@@ -568,13 +568,14 @@ __device__ __forceinline__ int draw_label_kept(P rows, const LevelDesc &ds, int 
   int lstar = hit ? (__ffsll(hit) - 1) : last_lane;
   if (lstar > last_lane) lstar = last_lane;
   // second pass, in every lane on its own block: first row r with target <= exclusive prefix + v[0..r]
+  // (the running sums never decrease, so the first row that reaches the target = the number of rows below it)
   T run = incl - S;
-  int first = BMAX;
-  T c[BMAX];
+  int first = 0;
 #pragma unroll
-  for (int r = 0; r < BMAX; ++r) { run += v[r]; c[r] = run; }
-#pragma unroll
-  for (int r = BMAX - 1; r >= 0; --r) first = (target <= c[r]) ? r : first;
+  for (int r = 0; r < BMAX; ++r) {
+    run += v[r];
+    first += (target <= run) ? 0 : 1;
+  }
   int len = n - lstar * B;
   if (len > B) len = B;
   int istar = __builtin_amdgcn_readlane(first, lstar);
