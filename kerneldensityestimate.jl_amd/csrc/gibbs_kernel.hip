@@ -976,45 +976,13 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan,
     }
 
     int j = 0;
-    uint32_t word = 0;  // packed labels (tabulated levels)
     LevelDesc ds_next = levels[l];  // descriptor of step 0; each step fetches its successor's early
-    for (int t = 0; t < nsteps; ++t) {
+    const bool tabulated = (l <= Lt);
+    const int t_general = tabulated ? M : nsteps;  // tabulated levels: only the sampleIndices! pass runs here
+    for (int t = 0; t < t_general; ++t) {
       const LevelDesc ds = ds_next;
       const int jn = (j + 1 == M) ? 0 : j + 1;
       ds_next = levels[jn * (L + 1) + l];
-      if (l <= Lt && t >= M) {
-        // tabulated sweep step.  The labels of all densities are kept packed in one scalar word
-        // (density k in bits [shift_k, shift_k + bits_k): frontier sizes are powers of two here); the
-        // row of density j is addressed by the word with j's digit squeezed out.  The row holds the
-        // inclusive scan the regular path would compute (lanes >= n read the total, which is what
-        // they would hold after the scan), so the selection code below is the unchanged one.
-        const TabDesc td = tabs[j * (L + 1) + l];
-        if (t == M) {  // first sweep step of the level: pack the labels the sampleIndices! pass chose
-          word = 0;
-          for (int k = 0; k < M; ++k)
-            word |= static_cast<uint32_t>(psel[k]) << tabs[k * (L + 1) + l].shift;
-          word = __builtin_amdgcn_readfirstlane(word);
-        }
-        const uint32_t cfg = (word & ((1u << td.shift) - 1u)) | ((word >> (td.shift + td.bits)) << td.shift);
-        const T *row = tables + td.off + static_cast<int64_t>(cfg) * (td.n + 1);
-        const T incl = row[lane < td.n ? lane : td.n];
-        const double u = next_uniform();
-        const LdsPtr<T> rows = (LdsPtr<T>)(pool + ds.lds_off) + kTileHeader;
-        EvalGeneric<T, D> unused{};  // single-row frontiers never reach the second pass
-        const int pos = select_from_scan<T, LdsPtr<T>>(incl, T(0), rows, ds, lane, unused, u KSTAMP_ARGS);
-        word = (word & ~(((1u << td.bits) - 1u) << td.shift)) | (static_cast<uint32_t>(pos) << td.shift);
-        if (lane == 0) psel[j] = pos;
-        if (t + 1 == nsteps) {  // the level's last step: adopt the selected kernels for what follows
-          wave_sync();
-          for (int k = 0; k < M; ++k) {
-            const LevelDesc dk = levels[k * (L + 1) + l];
-            set_particle(k, dk, (LdsPtr<T>)(pool + dk.lds_off), psel[k]);
-          }
-          wave_sync();
-        }
-        j = jn;
-        continue;
-      }
       T mean = x, cov = T(0);      // sampleIndices! (:364-385): against the point just drawn
 #ifdef KDEHIP_STAMPS
       stamp_on = (l == (vflags >> 8)) ;  // stamp only the level selected by the experiment
@@ -1043,6 +1011,54 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan,
         step(j, ds, (LdsPtr<T>)(pool + (t & 1) * (kLdsPoolBytes / 2)), mean, cov, u);
       }
       j = jn;
+    }
+    if (tabulated) {
+      // ---- tabulated sweeps: a loop of their own (short live ranges, nothing of the general step in it) ----
+      // The labels of all densities are kept packed in one scalar word (density k in bits [shift_k,
+      // shift_k + bits_k): frontier sizes are powers of two here); the row of density j is addressed by the
+      // word with j's digit squeezed out.  The row holds the inclusive scan the regular path would compute
+      // (lanes >= n read the total), so the selection is select_from_scan's for a single-row frontier.
+      uint32_t word = 0;
+      for (int k = 0; k < M; ++k) word |= static_cast<uint32_t>(psel[k]) << tabs[k * (L + 1) + l].shift;
+      word = __builtin_amdgcn_readfirstlane(word);
+      int jt = 0;
+      for (int t = M; t < nsteps; ++t) {
+        const TabDesc td = tabs[jt * (L + 1) + l];
+        const uint32_t cfg = (word & ((1u << td.shift) - 1u)) | ((word >> (td.shift + td.bits)) << td.shift);
+        const T *row = tables + td.off + static_cast<int64_t>(cfg) * (td.n + 1);
+        const T incl = row[lane < td.n ? lane : td.n];
+        const double u = next_uniform();
+        const int n = td.n;
+        const T total = lane_read(incl, n < 64 ? n : 63);  // (a 64-node row: its last scan value IS the total)
+        int pos;
+        if (!(total >= Num<T>::tiny_total())) {  // uniform fallback (:311-315), rare: fetch the descriptor here
+          const LevelDesc dk = levels[jt * (L + 1) + l];
+          const T wl = ((LdsPtr<T>)(pool + dk.lds_off) + kTileHeader)[(dk.F - 1) * 64 + (n - 1)];
+          int z = n - 1;
+          if (wl > T(0)) {
+            z = static_cast<int>(ceil(u * static_cast<double>(n))) - 1;
+            z = z < 0 ? 0 : (z > n - 1 ? n - 1 : z);
+          }
+          pos = z;
+        } else {
+          const T target = static_cast<T>(u) * total;
+          unsigned long long hit = __ballot(target <= incl);
+          if (n < 64) hit &= (1ull << n) - 1ull;
+          pos = hit ? (__ffsll(hit) - 1) : (n - 1);
+        }
+        word = (word & ~(((1u << td.bits) - 1u) << td.shift)) | (static_cast<uint32_t>(pos) << td.shift);
+        jt = (jt + 1 == M) ? 0 : jt + 1;
+      }
+      // the level's sweeps are over: unpack the labels and adopt the selected kernels for what follows
+      wave_sync();
+      for (int k = 0; k < M; ++k) {
+        const TabDesc tk = tabs[k * (L + 1) + l];
+        const LevelDesc dk = levels[k * (L + 1) + l];
+        const int pk = static_cast<int>((word >> tk.shift) & ((1u << tk.bits) - 1u));
+        if (lane == 0) psel[k] = pk;
+        set_particle(k, dk, (LdsPtr<T>)(pool + dk.lds_off), pk);
+      }
+      wave_sync();
     }
     if (a.labels && live && lane == 0) {
       for (int k = 0; k < M; ++k) {
