@@ -975,43 +975,52 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan,
       stage_chunk(levels[l], 0, gchunk & 1);
     }
 
-    int j = 0;
-    LevelDesc ds_next = levels[l];  // descriptor of step 0; each step fetches its successor's early
     const bool tabulated = (l <= Lt);
     const int t_general = tabulated ? M : nsteps;  // tabulated levels: only the sampleIndices! pass runs here
-    for (int t = 0; t < t_general; ++t) {
-      const LevelDesc ds = ds_next;
-      const int jn = (j + 1 == M) ? 0 : j + 1;
-      ds_next = levels[jn * (L + 1) + l];
-      T mean = x, cov = T(0);      // sampleIndices! (:364-385): against the point just drawn
+    // The step loop exists once per staging mode (a compile-time tag): every copy holds only its own mode's
+    // code, which keeps live ranges -- and with them the scalar-register spills of every step -- short.
+    auto run_steps = [&](auto mode_tag) {
+      constexpr int kMode = decltype(mode_tag)::value;
+      int j = 0;
+      LevelDesc ds_next = levels[l];  // descriptor of step 0; each step fetches its successor's early
+      for (int t = 0; t < t_general; ++t) {
+        const LevelDesc ds = ds_next;
+        const int jn = (j + 1 == M) ? 0 : j + 1;
+        ds_next = levels[jn * (L + 1) + l];
+        T mean = x, cov = T(0);      // sampleIndices! (:364-385): against the point just drawn
 #ifdef KDEHIP_STAMPS
-      stamp_on = (l == (vflags >> 8)) ;  // stamp only the level selected by the experiment
+        stamp_on = (l == (vflags >> 8)) ;  // stamp only the level selected by the experiment
 #endif
-      KSTAMP(tq0);
-      if (t >= M && !(vflags & 4)) product_dim(j, ds.others_bits, mean, cov);  // sampleIndex (:404-429): leave j out
-      const double u = next_uniform();
-      KSTAMP(tq1);
-      KSTAMP_ADD(0, tq0, tq1);
-      if (mode == kStageGlobal) {
-        step(j, ds, data + ds.hdr_off, mean, cov, u);
-      } else if (mode == kStageResident) {
-        step(j, ds, (LdsPtr<T>)(pool + ds.lds_off), mean, cov, u);
-      } else if (mode == kStageChunked) {
-        step_chunked(j, ds, ds_next, t + 1 < nsteps, mean, cov, u);
-      } else {
-        // tile t has been copied by all wavefronts once everyone passes this barrier; buffer
-        // (t+1)&1 was last read in step t-1, which everyone has left -> start the next copy
-        KSTAMP(tb0);
-        __syncthreads();
-        KSTAMP(tb1);
-        KSTAMP_ADD(6, tb0, tb1);
-        if (t + 1 < nsteps)
-          stage_tile<WAVES>(reinterpret_cast<const unsigned char *>(data + ds_next.hdr_off),
-                     pool + ((t + 1) & 1) * (kLdsPoolBytes / 2), ds_next.stage_bytes, wave, lane);
-        step(j, ds, (LdsPtr<T>)(pool + (t & 1) * (kLdsPoolBytes / 2)), mean, cov, u);
+        KSTAMP(tq0);
+        if (t >= M && !(vflags & 4)) product_dim(j, ds.others_bits, mean, cov);  // sampleIndex (:404-429): leave j out
+        const double u = next_uniform();
+        KSTAMP(tq1);
+        KSTAMP_ADD(0, tq0, tq1);
+        if constexpr (kMode == kStageGlobal) {
+          step(j, ds, data + ds.hdr_off, mean, cov, u);
+        } else if constexpr (kMode == kStageResident) {
+          step(j, ds, (LdsPtr<T>)(pool + ds.lds_off), mean, cov, u);
+        } else if constexpr (kMode == kStageChunked) {
+          step_chunked(j, ds, ds_next, t + 1 < nsteps, mean, cov, u);
+        } else {
+          // tile t has been copied by all wavefronts once everyone passes this barrier; buffer
+          // (t+1)&1 was last read in step t-1, which everyone has left -> start the next copy
+          KSTAMP(tb0);
+          __syncthreads();
+          KSTAMP(tb1);
+          KSTAMP_ADD(6, tb0, tb1);
+          if (t + 1 < nsteps)
+            stage_tile<WAVES>(reinterpret_cast<const unsigned char *>(data + ds_next.hdr_off),
+                       pool + ((t + 1) & 1) * (kLdsPoolBytes / 2), ds_next.stage_bytes, wave, lane);
+          step(j, ds, (LdsPtr<T>)(pool + (t & 1) * (kLdsPoolBytes / 2)), mean, cov, u);
+        }
+        j = jn;
       }
-      j = jn;
-    }
+    };
+    if (mode == kStageGlobal) run_steps(std::integral_constant<int, kStageGlobal>{});
+    else if (mode == kStageResident) run_steps(std::integral_constant<int, kStageResident>{});
+    else if (mode == kStageChunked) run_steps(std::integral_constant<int, kStageChunked>{});
+    else run_steps(std::integral_constant<int, kStageStream>{});
     if (tabulated) {
       // ---- tabulated sweeps: a loop of their own (short live ranges, nothing of the general step in it) ----
       // The labels of all densities are kept packed in one scalar word (density k in bits [shift_k,
