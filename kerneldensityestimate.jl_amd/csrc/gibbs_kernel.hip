@@ -982,11 +982,14 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan,
     auto run_steps = [&](auto mode_tag) {
       constexpr int kMode = decltype(mode_tag)::value;
       int j = 0;
-      LevelDesc ds_next = levels[l];  // descriptor of step 0; each step fetches its successor's early
+      LevelDesc ds_next = levels[l];  // descriptor of step 0 (streamed modes: each step fetches its successor's early)
       for (int t = 0; t < t_general; ++t) {
-        const LevelDesc ds = ds_next;
         const int jn = (j + 1 == M) ? 0 : j + 1;
-        ds_next = levels[jn * (L + 1) + l];
+        // the streamed modes need the successor's descriptor anyway (they copy its tile during this step);
+        // the others load their own at the top of the step: 16 fewer scalar registers live across it
+        constexpr bool kNeedsNext = (kMode == kStageStream || kMode == kStageChunked);
+        const LevelDesc ds = kNeedsNext ? ds_next : levels[j * (L + 1) + l];
+        if constexpr (kNeedsNext) ds_next = levels[jn * (L + 1) + l];
         T mean = x, cov = T(0);      // sampleIndices! (:364-385): against the point just drawn
 #ifdef KDEHIP_STAMPS
         stamp_on = (l == (vflags >> 8)) ;  // stamp only the level selected by the experiment
