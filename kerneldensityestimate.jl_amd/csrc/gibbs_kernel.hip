@@ -1118,8 +1118,8 @@ static int launch_one(const PlanDev &plan, const RunArgs &args, hipStream_t stre
   if (args.Np <= 0) return KDEHIP_OK;
   // Chains per workgroup (= wavefronts per CU, one workgroup per CU at a time): fewer wavefronts per SIMD run
   // each chain faster, more hide each other's latencies.  Pick the width with the smallest estimated time
-  // rounds(width) * cost(width); the relative costs of one round are measured ones (config 3: 0.64, 0.86,
-  // 1.19, 1.40 ms for 4, 8, 12, 16 chains per workgroup) and differ little between shapes.
+  // rounds(width) * cost(width); the relative costs of one round are measured ones (config 3: 0.59, 0.79,
+  // 1.10, 1.37 ms for 4, 8, 12, 16 chains per workgroup) and differ little between shapes.
   const int v = args.variant % 1000;
   const int64_t cus = device_cu_count();
   int waves = 16;
@@ -1127,7 +1127,7 @@ static int launch_one(const PlanDev &plan, const RunArgs &args, hipStream_t stre
   else if (v == 2) waves = 4;
   else {
     static const int kWidth[4] = {4, 8, 12, 16};
-    static const double kCost[4] = {1.0, 1.34, 1.86, 2.19};
+    static const double kCost[4] = {1.0, 1.34, 1.86, 2.31};
     double best = 0.0;
     for (int i = 0; i < 4; ++i) {
       const int64_t wgs = (args.Np + kWidth[i] - 1) / kWidth[i];
