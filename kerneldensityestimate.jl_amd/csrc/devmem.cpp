@@ -10,6 +10,7 @@
 
 #include <cstddef>
 #include <mutex>
+#include <string>
 #include <vector>
 
 #include "kdehip_internal.hpp"
@@ -56,6 +57,27 @@ bool give(Cache &c, int cls, void *p) {
 }
 
 }  // namespace
+
+DeviceGuard::~DeviceGuard() {
+  if (switched_) (void)hipSetDevice(prev_);
+}
+
+int DeviceGuard::enter(int device) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return set_error(KDEHIP_ERR_NO_DEVICE, "no HIP device available (libkdehip has no CPU fallback by design)");
+  if (device < 0 || device >= n) return set_error(KDEHIP_ERR_ARG, "device ordinal out of range");
+  int cur = -1;
+  e = hipGetDevice(&cur);
+  if (e != hipSuccess) return set_error(KDEHIP_ERR_NO_DEVICE, std::string("hipGetDevice: ") + hipGetErrorString(e));
+  if (cur == device) return KDEHIP_OK;
+  e = hipSetDevice(device);
+  if (e != hipSuccess) return set_error(KDEHIP_ERR_NO_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e));
+  prev_ = cur;
+  switched_ = true;
+  return KDEHIP_OK;
+}
 
 hipError_t cached_malloc(void **out, size_t bytes) {
   *out = nullptr;

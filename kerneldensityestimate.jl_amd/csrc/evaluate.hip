@@ -27,7 +27,24 @@ namespace kdehip {
 namespace {
 
 constexpr int kEvalThreads = 256;  // queries per block
-constexpr int kEvalChunk = 128;    // source points per block
+constexpr int kEvalChunk = 128;    // source points per staged chunk
+constexpr int kEvalMaxGroups = 64; // at most this many partial sums per query (scratch = 64 * Nq doubles)
+
+// Source chunks are dealt to groups of consecutive chunks: as many groups as it takes to give every CU a few
+// blocks (small problems: one chunk per group, the most parallel split), never more than kEvalMaxGroups.
+struct GroupSplit { int64_t chunks_per_group; int ngroups; };
+inline GroupSplit split_chunks(int64_t N, int64_t Nq, int nprob) {
+  const int64_t nchunks = (N + kEvalChunk - 1) / kEvalChunk;
+  const int64_t qblocks = ((Nq + kEvalThreads - 1) / kEvalThreads) * (nprob > 0 ? nprob : 1);
+  int64_t want = (int64_t(8) * device_cu_count() + qblocks - 1) / qblocks;  // groups for ~8 blocks per CU
+  if (want < 1) want = 1;
+  if (want > kEvalMaxGroups) want = kEvalMaxGroups;
+  if (want > nchunks) want = nchunks;
+  GroupSplit g;
+  g.chunks_per_group = (nchunks + want - 1) / want;
+  g.ngroups = static_cast<int>((nchunks + g.chunks_per_group - 1) / g.chunks_per_group);
+  return g;
+}
 
 #define KDEHIP_CHECK(expr)                                                                  \
   do {                                                                                      \
@@ -49,54 +66,73 @@ struct EvalProblem {
   const double *src;   // [N][D]
   const double *w;     // [N]
   const double *qry;   // [Nq][D]
-  double *partial;     // [nchunks][Nq]
+  double *partial;     // [ngroups][Nq]
   double nhib[KDEHIP_MAX_DIMS];  // -1/(2 bw_k)
   int64_t N, Nq;
+  int64_t chunks_per_group;  // consecutive 128-point source chunks summed by one block
 };
 
 // A launch handles up to KDEHIP_MAX_DIMS independent problems (the D one-dimensional searches of
 // kde!(points) in one round); their descriptors travel as kernel arguments, not through memory.
 struct EvalBatch { EvalProblem p[KDEHIP_MAX_DIMS]; };
 
-// partial[c][q] = sum_{i in chunk c, (i != q if loo)} w_i exp(-1/2 sum_k (x_qk - c_ik)^2 / bw_k)
-// (the kernel value of distGauss!, src/DualTree01.jl:14-47, with leaf ranges 0 and uniform bandwidth)
+// partial[g][q] = sum over the source chunks c of group g, in chunk order, of
+//   sum_{i in chunk c, (i != q if loo)} w_i exp(-1/2 sum_k (x_qk - c_ik)^2 / bw_k)
+// (the kernel value of distGauss!, src/DualTree01.jl:14-47, with leaf ranges 0 and uniform bandwidth).
+// A block owns kEvalThreads queries and ONE group of consecutive 128-point source chunks, which it walks in
+// order with the running sum in a register: the scratch is [ngroups][Nq] with ngroups <= kEvalMaxGroups
+// whatever N is (grid.y stays far below the 65535 limit), and the summation order is fixed by (N, ngroups).
 template <int D>
 __global__ __launch_bounds__(kEvalThreads) void eval_partial_kernel(const EvalBatch batch, int loo) {
-  __shared__ double sSrc[kEvalChunk * (D + 1)];
+  __shared__ double sSrc[2][kEvalChunk * (D + 1)];
   __shared__ double sExpTab[32];
   if (threadIdx.x < 32) sExpTab[threadIdx.x] = kExp2Tab[threadIdx.x];
   const EvalProblem &pb = batch.p[blockIdx.z];
   const int64_t q = static_cast<int64_t>(blockIdx.x) * kEvalThreads + threadIdx.x;
-  const int64_t i0 = static_cast<int64_t>(blockIdx.y) * kEvalChunk;
-  if (i0 >= pb.N || static_cast<int64_t>(blockIdx.x) * kEvalThreads >= pb.Nq) return;  // block-uniform
-  const int cnt = static_cast<int>((pb.N - i0 < kEvalChunk) ? (pb.N - i0) : kEvalChunk);
-  for (int t = threadIdx.x; t < cnt * (D + 1); t += kEvalThreads) {
-    const int i = t / (D + 1), f = t % (D + 1);
-    sSrc[t] = (f < D) ? pb.src[(i0 + i) * D + f] : pb.w[i0 + i];
-  }
-  __syncthreads();
-  if (q >= pb.Nq) return;
+  const int64_t c_begin = static_cast<int64_t>(blockIdx.y) * pb.chunks_per_group;
+  int64_t c_end = c_begin + pb.chunks_per_group;
+  const int64_t nchunks = (pb.N + kEvalChunk - 1) / kEvalChunk;
+  if (c_end > nchunks) c_end = nchunks;
+  if (c_begin >= c_end || static_cast<int64_t>(blockIdx.x) * kEvalThreads >= pb.Nq) return;  // block-uniform
   double x[D];
 #pragma unroll
-  for (int k = 0; k < D; ++k) x[k] = pb.qry[q * D + k];
-  double sum = 0.0;
-  for (int i = 0; i < cnt; ++i) {
-    const double *s = sSrc + i * (D + 1);
-    double acc = 0.0;
-#pragma unroll
-    for (int k = 0; k < D; ++k) {
-      const double d = x[k] - s[k];
-      acc = fma(d * d, pb.nhib[k], acc);
+  for (int k = 0; k < D; ++k) x[k] = (q < pb.Nq) ? pb.qry[q * D + k] : 0.0;
+  auto stage = [&](int64_t c, int buf) {
+    const int64_t i0 = c * kEvalChunk;
+    const int cnt = static_cast<int>((pb.N - i0 < kEvalChunk) ? (pb.N - i0) : kEvalChunk);
+    for (int t = threadIdx.x; t < cnt * (D + 1); t += kEvalThreads) {
+      const int i = t / (D + 1), f = t % (D + 1);
+      sSrc[buf][t] = (f < D) ? pb.src[(i0 + i) * D + f] : pb.w[i0 + i];
     }
-    double v = s[D] * exp_nonpos(acc, sExpTab);  // acc <= 0
-    if (loo && i0 + i == q) v = 0.0;  // leave-one-out: skip the self term (:141)
-    sum += v;
+  };
+  stage(c_begin, 0);
+  double total = 0.0;
+  for (int64_t c = c_begin; c < c_end; ++c) {
+    const int buf = static_cast<int>((c - c_begin) & 1);
+    __syncthreads();  // chunk c is staged; the other buffer is free again
+    if (c + 1 < c_end) stage(c + 1, buf ^ 1);
+    const int64_t i0 = c * kEvalChunk;
+    const int cnt = static_cast<int>((pb.N - i0 < kEvalChunk) ? (pb.N - i0) : kEvalChunk);
+    double sum = 0.0;
+    for (int i = 0; i < cnt; ++i) {
+      const double *s = sSrc[buf] + i * (D + 1);
+      double acc = 0.0;
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        const double d = x[k] - s[k];
+        acc = fma(d * d, pb.nhib[k], acc);
+      }
+      double v = s[D] * exp_nonpos(acc, sExpTab);  // acc <= 0
+      if (loo && i0 + i == q) v = 0.0;  // leave-one-out: skip the self term (:141)
+      sum += v;
+    }
+    total += sum;
   }
-  pb.partial[static_cast<int64_t>(blockIdx.y) * pb.Nq + q] = sum;
+  if (q < pb.Nq) pb.partial[static_cast<int64_t>(blockIdx.y) * pb.Nq + q] = total;
 }
 
 struct FinishProblem {
-  const double *partial;   // [nchunks][Nq]
+  const double *partial;   // [nchunks][Nq] (nchunks = groups of source chunks, see split_chunks)
   const double *w;         // [N] (loo: 1 - w_q)
   const int64_t *out_idx;  // optional: output position of query q (loo: permutation - 1), or null
   double *out;
@@ -147,37 +183,28 @@ __global__ __launch_bounds__(kFinishThreads) void loo_entropy_kernel(const Finis
 }
 
 template <int D>
-void launch_partial(const EvalBatch &d_problems, int nprob, int64_t maxNq, int64_t maxN, int loo,
+void launch_partial(const EvalBatch &d_problems, int nprob, int64_t maxNq, int ngroups, int loo,
                     hipStream_t st) {
   dim3 grid(static_cast<unsigned>((maxNq + kEvalThreads - 1) / kEvalThreads),
-            static_cast<unsigned>((maxN + kEvalChunk - 1) / kEvalChunk), static_cast<unsigned>(nprob));
+            static_cast<unsigned>(ngroups), static_cast<unsigned>(nprob));
   hipLaunchKernelGGL((eval_partial_kernel<D>), grid, dim3(kEvalThreads), 0, st, d_problems, loo);
 }
 
-int launch_partial_dims(int D, const EvalBatch &d_problems, int nprob, int64_t maxNq, int64_t maxN, int loo,
+int launch_partial_dims(int D, const EvalBatch &d_problems, int nprob, int64_t maxNq, int ngroups, int loo,
                         hipStream_t st) {
   switch (D) {
-    case 1: launch_partial<1>(d_problems, nprob, maxNq, maxN, loo, st); break;
-    case 2: launch_partial<2>(d_problems, nprob, maxNq, maxN, loo, st); break;
-    case 3: launch_partial<3>(d_problems, nprob, maxNq, maxN, loo, st); break;
-    case 4: launch_partial<4>(d_problems, nprob, maxNq, maxN, loo, st); break;
-    case 5: launch_partial<5>(d_problems, nprob, maxNq, maxN, loo, st); break;
-    case 6: launch_partial<6>(d_problems, nprob, maxNq, maxN, loo, st); break;
-    case 7: launch_partial<7>(d_problems, nprob, maxNq, maxN, loo, st); break;
-    case 8: launch_partial<8>(d_problems, nprob, maxNq, maxN, loo, st); break;
+    case 1: launch_partial<1>(d_problems, nprob, maxNq, ngroups, loo, st); break;
+    case 2: launch_partial<2>(d_problems, nprob, maxNq, ngroups, loo, st); break;
+    case 3: launch_partial<3>(d_problems, nprob, maxNq, ngroups, loo, st); break;
+    case 4: launch_partial<4>(d_problems, nprob, maxNq, ngroups, loo, st); break;
+    case 5: launch_partial<5>(d_problems, nprob, maxNq, ngroups, loo, st); break;
+    case 6: launch_partial<6>(d_problems, nprob, maxNq, ngroups, loo, st); break;
+    case 7: launch_partial<7>(d_problems, nprob, maxNq, ngroups, loo, st); break;
+    case 8: launch_partial<8>(d_problems, nprob, maxNq, ngroups, loo, st); break;
     default: return set_error(KDEHIP_ERR_UNSUPPORTED, "ndims outside 1..KDEHIP_MAX_DIMS");
   }
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_error(KDEHIP_ERR_HIP, std::string("eval launch failed: ") + hipGetErrorString(e));
-  return KDEHIP_OK;
-}
-
-int use_device(int device) {
-  int n = 0;
-  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
-    return set_error(KDEHIP_ERR_NO_DEVICE, "no HIP device available (libkdehip has no CPU fallback by design)");
-  if (device < 0 || device >= n) return set_error(KDEHIP_ERR_ARG, "device ordinal out of range");
-  if (hipSetDevice(device) != hipSuccess) return set_error(KDEHIP_ERR_NO_DEVICE, "hipSetDevice failed");
   return KDEHIP_OK;
 }
 
@@ -211,10 +238,12 @@ extern "C" int kdehip_evaluate(const kdehip_density *bd, const double *pos, int6
     for (int k = 0; k < D; ++k)
       if (bd->bandwidth[(N + i) * D + k] != bw[k])
         return set_error(KDEHIP_ERR_UNSUPPORTED, "per-point bandwidths are not supported (the reference's kde! never builds them)");
-  int rc = use_device(device);
+  DeviceGuard guard;
+  int rc = guard.enter(device);
   if (rc != KDEHIP_OK) return rc;
 
-  const int nchunks = static_cast<int>((N + kEvalChunk - 1) / kEvalChunk);
+  const GroupSplit gs = split_chunks(N, Nq, 1);
+  const int nchunks = gs.ngroups;  // partial sums per query
   DevBuf d_src, d_w, d_q, d_part, d_out, d_idx;
   KDEHIP_CHECK(d_src.alloc(sizeof(double) * N * D));
   KDEHIP_CHECK(d_w.alloc(sizeof(double) * N));
@@ -237,13 +266,13 @@ extern "C" int kdehip_evaluate(const kdehip_density *bd, const double *pos, int6
   EvalProblem &pb = eb.p[0];
   pb.src = d_src.as<double>(); pb.w = d_w.as<double>();
   pb.qry = leave_one_out ? d_src.as<double>() : d_q.as<double>();
-  pb.partial = d_part.as<double>(); pb.N = N; pb.Nq = Nq;
+  pb.partial = d_part.as<double>(); pb.N = N; pb.Nq = Nq; pb.chunks_per_group = gs.chunks_per_group;
   for (int k = 0; k < D; ++k) pb.nhib[k] = -0.5 / bw[k];
   FinishProblem &fp = fb.p[0];
   fp.partial = d_part.as<double>(); fp.w = d_w.as<double>();
   fp.out_idx = leave_one_out ? d_idx.as<int64_t>() : nullptr;
   fp.out = d_out.as<double>(); fp.inv_norm = 1.0 / gauss_norm(bw, D); fp.Nq = Nq; fp.nchunks = nchunks;
-  rc = launch_partial_dims(D, eb, 1, Nq, N, leave_one_out ? 1 : 0, nullptr);
+  rc = launch_partial_dims(D, eb, 1, Nq, gs.ngroups, leave_one_out ? 1 : 0, nullptr);
   if (rc != KDEHIP_OK) return rc;
   hipLaunchKernelGGL(eval_finish_kernel, dim3(static_cast<unsigned>((Nq + 255) / 256), 1), dim3(256), 0, nullptr,
                      fb, leave_one_out ? 1 : 0);
@@ -298,7 +327,8 @@ extern "C" int kdehip_auto_bandwidth(int64_t D64, int64_t N, const double *point
   if (D64 < 1 || D64 > KDEHIP_MAX_DIMS) return set_error(KDEHIP_ERR_UNSUPPORTED, "ndims outside 1..KDEHIP_MAX_DIMS");
   if (N < 2) return set_error(KDEHIP_ERR_ARG, "kde!(points) needs at least two points");
   const int D = static_cast<int>(D64);
-  int rc = use_device(device);
+  DeviceGuard guard;
+  int rc = guard.enter(device);
   if (rc != KDEHIP_OK) return rc;
   const bool timing = std::getenv("KDEHIP_TIMING") != nullptr;
   auto tnow = [] { return std::chrono::steady_clock::now(); };
@@ -351,7 +381,8 @@ extern "C" int kdehip_auto_bandwidth(int64_t D64, int64_t N, const double *point
   }
 
   auto t_host = tnow();
-  const int nchunks = static_cast<int>((N + kEvalChunk - 1) / kEvalChunk);
+  const GroupSplit gs = split_chunks(N, N, D);
+  const int nchunks = gs.ngroups;  // partial sums per query
   const int nfb = static_cast<int>((N + kFinishThreads - 1) / kFinishThreads);
   DevBuf d_x, d_w, d_part;
   KDEHIP_CHECK(d_x.alloc(sizeof(double) * D * N));
@@ -411,14 +442,14 @@ extern "C" int kdehip_auto_bandwidth(int64_t D64, int64_t N, const double *point
       pb.w = d_w.as<double>() + static_cast<size_t>(d) * N;
       pb.partial = d_part.as<double>() + static_cast<size_t>(d) * nchunks * N;
       pb.nhib[0] = -0.5 / bw_eval[a];
-      pb.N = N; pb.Nq = N;
+      pb.N = N; pb.Nq = N; pb.chunks_per_group = gs.chunks_per_group;
       FinishProblem &fp = fb.p[a];
       std::memset(&fp, 0, sizeof(fp));
       fp.partial = pb.partial; fp.w = pb.w;
       fp.inv_norm = 1.0 / gauss_norm(&bw_eval[a], 1);
       fp.Nq = N; fp.nchunks = nchunks;
     }
-    rc = launch_partial_dims(1, eb, na, N, N, 1, nullptr);
+    rc = launch_partial_dims(1, eb, na, N, gs.ngroups, 1, nullptr);
     if (rc != KDEHIP_OK) return rc;
     hipLaunchKernelGGL(loo_entropy_kernel, dim3(static_cast<unsigned>(nfb), static_cast<unsigned>(na)),
                        dim3(kFinishThreads), 0, nullptr, fb, h_pin.p, nfb);

@@ -145,6 +145,21 @@ void cached_free(void *p, size_t bytes);
 hipError_t cached_host_malloc(void **out, size_t bytes);
 void cached_host_free(void *p, size_t bytes);
 
+// Makes `device` the thread's current HIP device for the lifetime of the guard and restores the caller's
+// device on every exit path: no entry point of the library (including kdehip_product_destroy, which a
+// garbage collector may call at any time) leaves the thread on another device than it found.
+class DeviceGuard {
+ public:
+  DeviceGuard() = default;
+  DeviceGuard(const DeviceGuard &) = delete;
+  DeviceGuard &operator=(const DeviceGuard &) = delete;
+  ~DeviceGuard();
+  int enter(int device);  // KDEHIP_OK, KDEHIP_ERR_NO_DEVICE or KDEHIP_ERR_ARG (ordinal out of range)
+ private:
+  int prev_ = -1;
+  bool switched_ = false;
+};
+
 // Compute units of the current device (cached per device ordinal); 256 on MI355X.
 int device_cu_count();
 

@@ -3,6 +3,7 @@
 // re-layout: pack_levels.cpp; density construction: balltree.cpp.)
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -23,7 +24,7 @@ struct kdehip_product {
   PackedProduct host;  // descriptors (payload vectors are released after upload)
   void *d_blob = nullptr;   // the one device allocation of the plan; the pointers below point into it
   size_t blob_bytes = 0;
-  bool async_pending = false;  // a run was enqueued through a device-pointer entry point and not waited for here
+  std::atomic<bool> async_pending{false};  // set (never cleared) by the device-pointer entry points: a run may be in flight on a caller stream
   void *d_data = nullptr;
   int32_t *d_perm = nullptr;
   LevelDesc *d_levels = nullptr;
@@ -46,19 +47,6 @@ namespace {
     if (e_ != hipSuccess)                                                                   \
       return set_error(KDEHIP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
   } while (0)
-
-int use_device(int device) {
-  int n = 0;
-  hipError_t e = hipGetDeviceCount(&n);
-  if (e != hipSuccess || n <= 0)
-    return set_error(KDEHIP_ERR_NO_DEVICE,
-                     "no HIP device available (libkdehip has no CPU fallback by design)");
-  if (device < 0 || device >= n) return set_error(KDEHIP_ERR_ARG, "device ordinal out of range");
-  e = hipSetDevice(device);
-  if (e != hipSuccess)
-    return set_error(KDEHIP_ERR_NO_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e));
-  return KDEHIP_OK;
-}
 
 int check_run(const kdehip_product *plan, int64_t Np, int Niter, const void *d_points,
               const void *d_indices) {
@@ -105,6 +93,56 @@ int reserve_work(kdehip_product *plan, size_t bytes) {
 }
 inline size_t align256(size_t x) { return (x + 255) & ~static_cast<size_t>(255); }
 
+// The two run forms, enqueue only (no bookkeeping of who waits for the work: see the callers).
+int enqueue_streams(kdehip_product *plan, int64_t Np, int Niter, const double *d_randU, int64_t nU,
+                    const double *d_randN, int64_t nN, int addEntropy, double *d_points, int64_t *d_indices,
+                    int32_t *d_labels, void *stream) {
+  int rc = check_run(plan, Np, Niter, d_points, d_indices);
+  if (rc != KDEHIP_OK) return rc;
+  if (Np == 0) return KDEHIP_OK;
+  const int64_t K = kdehip_product_randu_per_sample(plan, Niter);
+  const int64_t R = kdehip_product_randn_per_sample(plan);
+  // last uniform read is 0-based element Np*K - 2; the reference raises BoundsError when short
+  if (!d_randU || nU < Np * K - 1)
+    return set_error(KDEHIP_ERR_RAND_SHORT, "randU shorter than Np*K-1 values (Julia: BoundsError)");
+  if (!d_randN || nN < Np * R)
+    return set_error(KDEHIP_ERR_RAND_SHORT, "randN shorter than Np*R values (Julia: BoundsError)");
+  DeviceGuard guard;
+  rc = guard.enter(plan->device);
+  if (rc != KDEHIP_OK) return rc;
+  RunArgs a{};
+  a.Np = Np; a.Niter = Niter; a.addEntropy = addEntropy ? 1 : 0; a.rng_philox = 0;
+  a.variant = plan->variant;
+  a.randU = d_randU; a.randN = d_randN; a.K = K; a.R = R; a.nU = nU; a.nN = nN;
+  a.seed = 0; a.sample_offset = 0;
+  a.points = d_points; a.indices = d_indices; a.labels = d_labels;
+  rc = maybe_build_tables(plan, Np, a, stream);
+  if (rc != KDEHIP_OK) return rc;
+  return launch_gibbs(plan->precision, plan->mode, plan->dev, a, stream);
+}
+
+int enqueue_philox(kdehip_product *plan, int64_t Np, int Niter, uint64_t seed, int64_t sample_offset,
+                   int addEntropy, double *d_points, int64_t *d_indices, int32_t *d_labels, void *stream) {
+  int rc = check_run(plan, Np, Niter, d_points, d_indices);
+  if (rc != KDEHIP_OK) return rc;
+  if (Np == 0) return KDEHIP_OK;
+  if (sample_offset < 0) return set_error(KDEHIP_ERR_ARG, "sample_offset must be >= 0");
+  DeviceGuard guard;
+  rc = guard.enter(plan->device);
+  if (rc != KDEHIP_OK) return rc;
+  RunArgs a{};
+  a.Np = Np; a.Niter = Niter; a.addEntropy = addEntropy ? 1 : 0; a.rng_philox = 1;
+  a.variant = plan->variant;
+  a.randU = nullptr; a.randN = nullptr;
+  a.K = kdehip_product_randu_per_sample(plan, Niter);
+  a.R = kdehip_product_randn_per_sample(plan);
+  a.seed = seed; a.sample_offset = sample_offset;
+  a.points = d_points; a.indices = d_indices; a.labels = d_labels;
+  rc = maybe_build_tables(plan, Np, a, stream);
+  if (rc != KDEHIP_OK) return rc;
+  return launch_gibbs(plan->precision, plan->mode, plan->dev, a, stream);
+}
+
 }  // namespace
 
 extern "C" {
@@ -125,8 +163,9 @@ int kdehip_product_create(kdehip_product **out, int Ndens, const kdehip_density 
   if (precision != 64 && precision != 32) return set_error(KDEHIP_ERR_ARG, "precision must be 64 or 32");
   kdehip_product *p = new (std::nothrow) kdehip_product();
   if (!p) return set_error(KDEHIP_ERR_ALLOC, "out of host memory");
+  DeviceGuard guard;
   int rc = pack_levels(Ndens, trees, ndims, partialDimMask, precision, p->host);
-  if (rc == KDEHIP_OK) rc = use_device(device);
+  if (rc == KDEHIP_OK) rc = guard.enter(device);
   if (rc != KDEHIP_OK) { delete p; return rc; }
   p->device = device;
   p->precision = precision;
@@ -193,10 +232,11 @@ int kdehip_product_create(kdehip_product **out, int Ndens, const kdehip_density 
 
 void kdehip_product_destroy(kdehip_product *plan) {
   if (!plan) return;
-  if (hipSetDevice(plan->device) == hipSuccess) {
+  DeviceGuard guard;  // (reached from garbage collectors: the caller's current device must survive this call)
+  if (guard.enter(plan->device) == KDEHIP_OK) {
     // the blocks go back to the allocation cache and may be handed out again at once: work enqueued on the
     // caller's streams must be over (hipFree used to imply this)
-    if (plan->async_pending) (void)hipDeviceSynchronize();
+    if (plan->async_pending.load()) (void)hipDeviceSynchronize();
     if (plan->d_blob) cached_free(plan->d_blob, plan->blob_bytes);
     if (plan->d_work) cached_free(plan->d_work, plan->work_cap);
   }
@@ -237,49 +277,19 @@ int kdehip_product_sample_streams(kdehip_product *plan, int64_t Np, int Niter, c
                                   int64_t nU, const double *d_randN, int64_t nN, int addEntropy,
                                   double *d_points, int64_t *d_indices, int32_t *d_labels,
                                   void *stream) {
-  int rc = check_run(plan, Np, Niter, d_points, d_indices);
-  if (rc != KDEHIP_OK) return rc;
-  if (Np == 0) return KDEHIP_OK;
-  const int64_t K = kdehip_product_randu_per_sample(plan, Niter);
-  const int64_t R = kdehip_product_randn_per_sample(plan);
-  // last uniform read is 0-based element Np*K - 2; the reference raises BoundsError when short
-  if (!d_randU || nU < Np * K - 1)
-    return set_error(KDEHIP_ERR_RAND_SHORT, "randU shorter than Np*K-1 values (Julia: BoundsError)");
-  if (!d_randN || nN < Np * R)
-    return set_error(KDEHIP_ERR_RAND_SHORT, "randN shorter than Np*R values (Julia: BoundsError)");
-  KDEHIP_CHECK(hipSetDevice(plan->device));
-  RunArgs a{};
-  a.Np = Np; a.Niter = Niter; a.addEntropy = addEntropy ? 1 : 0; a.rng_philox = 0;
-  a.variant = plan->variant;
-  a.randU = d_randU; a.randN = d_randN; a.K = K; a.R = R; a.nU = nU; a.nN = nN;
-  a.seed = 0; a.sample_offset = 0;
-  a.points = d_points; a.indices = d_indices; a.labels = d_labels;
-  rc = maybe_build_tables(plan, Np, a, stream);
-  if (rc != KDEHIP_OK) return rc;
-  plan->async_pending = true;
-  return launch_gibbs(plan->precision, plan->mode, plan->dev, a, stream);
+  const int rc = enqueue_streams(plan, Np, Niter, d_randU, nU, d_randN, nN, addEntropy, d_points, d_indices,
+                                 d_labels, stream);
+  if (rc == KDEHIP_OK && Np > 0) plan->async_pending.store(true);  // the caller's stream may still be running it
+  return rc;
 }
 
 int kdehip_product_sample_philox(kdehip_product *plan, int64_t Np, int Niter, uint64_t seed,
                                  int64_t sample_offset, int addEntropy, double *d_points,
                                  int64_t *d_indices, int32_t *d_labels, void *stream) {
-  int rc = check_run(plan, Np, Niter, d_points, d_indices);
-  if (rc != KDEHIP_OK) return rc;
-  if (Np == 0) return KDEHIP_OK;
-  if (sample_offset < 0) return set_error(KDEHIP_ERR_ARG, "sample_offset must be >= 0");
-  KDEHIP_CHECK(hipSetDevice(plan->device));
-  RunArgs a{};
-  a.Np = Np; a.Niter = Niter; a.addEntropy = addEntropy ? 1 : 0; a.rng_philox = 1;
-  a.variant = plan->variant;
-  a.randU = nullptr; a.randN = nullptr;
-  a.K = kdehip_product_randu_per_sample(plan, Niter);
-  a.R = kdehip_product_randn_per_sample(plan);
-  a.seed = seed; a.sample_offset = sample_offset;
-  a.points = d_points; a.indices = d_indices; a.labels = d_labels;
-  rc = maybe_build_tables(plan, Np, a, stream);
-  if (rc != KDEHIP_OK) return rc;
-  plan->async_pending = true;
-  return launch_gibbs(plan->precision, plan->mode, plan->dev, a, stream);
+  const int rc = enqueue_philox(plan, Np, Niter, seed, sample_offset, addEntropy, d_points, d_indices, d_labels,
+                                stream);
+  if (rc == KDEHIP_OK && Np > 0) plan->async_pending.store(true);
+  return rc;
 }
 
 int kdehip_product_sample_philox_host(kdehip_product *plan, int64_t Np, int Niter, uint64_t seed,
@@ -288,7 +298,9 @@ int kdehip_product_sample_philox_host(kdehip_product *plan, int64_t Np, int Nite
   int rc = check_run(plan, Np, Niter, points, indices);
   if (rc != KDEHIP_OK) return rc;
   if (Np == 0) return KDEHIP_OK;
-  KDEHIP_CHECK(hipSetDevice(plan->device));
+  DeviceGuard guard;
+  rc = guard.enter(plan->device);
+  if (rc != KDEHIP_OK) return rc;
   const size_t D = plan->host.D, M = plan->host.M, L = plan->host.L;
   std::lock_guard<std::mutex> lock(plan->work_mutex);
   const size_t off_i = align256(sizeof(double) * D * Np);
@@ -299,14 +311,13 @@ int kdehip_product_sample_philox_host(kdehip_product *plan, int64_t Np, int Nite
   double *dp = reinterpret_cast<double *>(w);
   int64_t *di = reinterpret_cast<int64_t *>(w + off_i);
   int32_t *dl = labels ? reinterpret_cast<int32_t *>(w + off_l) : nullptr;
-  const bool was_pending = plan->async_pending;  // an earlier run on a caller stream may still be in flight
-  rc = kdehip_product_sample_philox(plan, Np, Niter, seed, sample_offset, addEntropy, dp, di, dl, nullptr);
+  // (this call's run is waited for by the blocking copies below, so it never marks the plan "async pending";
+  // the flag is only ever set, by the device-pointer entry points, and read by kdehip_product_destroy)
+  rc = enqueue_philox(plan, Np, Niter, seed, sample_offset, addEntropy, dp, di, dl, nullptr);
   if (rc != KDEHIP_OK) return rc;
-  // (the blocking copies on the null stream wait for the kernel)
   KDEHIP_CHECK(hipMemcpy(points, dp, sizeof(double) * D * Np, hipMemcpyDeviceToHost));
   KDEHIP_CHECK(hipMemcpy(indices, di, sizeof(int64_t) * M * Np, hipMemcpyDeviceToHost));
   if (labels) KDEHIP_CHECK(hipMemcpy(labels, dl, sizeof(int32_t) * M * L * Np, hipMemcpyDeviceToHost));
-  plan->async_pending = was_pending;  // (the blocking copies waited for this call's run)
   return KDEHIP_OK;
 }
 
@@ -336,6 +347,9 @@ int kdehip_gibbs1_trace(int Ndens, const kdehip_density *trees, int64_t Np, int 
     return set_error(KDEHIP_ERR_RAND_SHORT, "randN shorter than Np*R values (Julia: BoundsError)");
   const size_t D = ndims, M = Ndens;
   const int64_t useU = (nU < Np * K) ? nU : Np * K, useN = Np * R;
+  DeviceGuard dguard;
+  rc = dguard.enter(device);
+  if (rc != KDEHIP_OK) return rc;
   std::lock_guard<std::mutex> lock(plan->work_mutex);
   const size_t off_n = align256(sizeof(double) * useU);
   const size_t off_p = align256(off_n + sizeof(double) * useN);
@@ -353,12 +367,11 @@ int kdehip_gibbs1_trace(int Ndens, const kdehip_density *trees, int64_t Np, int 
   int32_t *dl = trace ? reinterpret_cast<int32_t *>(w + off_l) : nullptr;
   KDEHIP_CHECK(hipMemcpy(du, randU, sizeof(double) * useU, hipMemcpyHostToDevice));
   KDEHIP_CHECK(hipMemcpy(dn, randN, sizeof(double) * useN, hipMemcpyHostToDevice));
-  rc = kdehip_product_sample_streams(plan, Np, Niter, du, useU, dn, useN, addEntropy, dp, di, dl, nullptr);
+  rc = enqueue_streams(plan, Np, Niter, du, useU, dn, useN, addEntropy, dp, di, dl, nullptr);
   if (rc != KDEHIP_OK) return rc;
   KDEHIP_CHECK(hipMemcpy(pts, dp, sizeof(double) * D * Np, hipMemcpyDeviceToHost));
   KDEHIP_CHECK(hipMemcpy(ind, di, sizeof(int64_t) * M * Np, hipMemcpyDeviceToHost));
   if (trace) KDEHIP_CHECK(hipMemcpy(labels, dl, lab_bytes, hipMemcpyDeviceToHost));
-  plan->async_pending = false;  // the blocking copies waited for the run (the plan is private to this call)
   return KDEHIP_OK;
 }
 

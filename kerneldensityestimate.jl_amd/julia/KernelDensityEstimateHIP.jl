@@ -39,12 +39,20 @@ CDensity(bd::BallTreeDensity) = CDensity(bd.bt.num_points, bd.bt.dims, pointer(b
 lasterror() = unsafe_string(ccall((:kdehip_last_error, libkdehip), Cstring, ()))
 devicecount() = Int(ccall((:kdehip_device_count, libkdehip), Cint, ()))
 
+const KDEHIP_ERR_UNSUPPORTED = -7        # ndims > 8, Ndens > 16, ... (include/kdehip.h)
+
 function check(rc::Integer)
   rc == 0 && return nothing
   msg = lasterror()
   rc == -3 && throw(BoundsError(msg))   # randU / randN too short
   error("libkdehip ($rc): $msg")         # incl. "kdes must have same dimension"
 end
+
+# The reference's own gibbs1: `KDE.gibbs1` until enable!() has overwritten that method, the saved original
+# afterwards (calling KDE.gibbs1 from the fallback paths would then recurse into this module).
+const ORIGINAL_GIBBS1 = Ref{Any}(nothing)
+reference_gibbs1(args...; kw...) =
+  ORIGINAL_GIBBS1[] === nothing ? KDE.gibbs1(args...; kw...) : ORIGINAL_GIBBS1[](args...; kw...)
 
 isEuclid(addop, diffop, getMu, getLambda) =
   all(f -> f === +, addop) && all(f -> f === -, diffop) &&
@@ -66,11 +74,10 @@ function gibbs1(Ndens::Int, trees::Array{BallTreeDensity,1}, Np::Int, Niter::Int
                 ndims::Int=maximum(Ndim.(trees)),
                 partialDimMask::AbstractVector{<:BitVector}=[ones(Int, ndims) .== 1 for i in 1:Ndens],
                 device::Int=0)
-  if !isEuclid(addop, diffop, getMu, getLambda)
-    return KDE.gibbs1(Ndens, trees, Np, Niter, pts, ind, randU, randN; addop=addop, diffop=diffop, getMu=getMu,
-                      getLambda=getLambda, glbs=glbs, addEntropy=addEntropy, ndims=ndims,
-                      partialDimMask=partialDimMask)
-  end
+  fallback() = reference_gibbs1(Ndens, trees, Np, Niter, pts, ind, randU, randN; addop=addop, diffop=diffop,
+                                getMu=getMu, getLambda=getLambda, glbs=glbs, addEntropy=addEntropy, ndims=ndims,
+                                partialDimMask=partialDimMask)
+  isEuclid(addop, diffop, getMu, getLambda) || return fallback()
   cds = CDensity[CDensity(t) for t in trees]
   mask = maskbytes(partialDimMask, Ndens, ndims)
   # glbs.recordChoosen (src/MSGibbs01.jl:29-31): the label trace comes back as labels[level, density, sample]
@@ -83,6 +90,9 @@ function gibbs1(Ndens::Int, trees::Array{BallTreeDensity,1}, Np::Int, Niter::Int
                Ndens, cds, Np, Niter, pts, ind, randU, length(randU), randN, length(randN),
                addEntropy ? 1 : 0, ndims, mask, device, glbs.recordChoosen ? pointer(labels) : C_NULL)
   end
+  # shapes beyond the compiled limits (ndims > 8, Ndens > 16) stay on the reference path: the caller sees the
+  # same behaviour as without this package, only slower (nothing has been written to pts / ind yet)
+  rc == KDEHIP_ERR_UNSUPPORTED && return fallback()
   check(rc)
   if glbs.recordChoosen   # same nesting and 1-based keys as :471-472, :575-583, :109-112
     glbs.labelsChoosen = Dict{Int,Dict{Int,Dict{Int,Int}}}()
@@ -136,10 +146,15 @@ function prodAppxMSGibbsS(npd0::BallTreeDensity, trees::Array{BallTreeDensity,1}
   mask = maskbytes(partialDimMask, Ndens, ndims)
   plan = Ref{Ptr{Cvoid}}(C_NULL)
   GC.@preserve trees cds mask begin
-    check(ccall((:kdehip_product_create, libkdehip), Cint,
-                (Ref{Ptr{Cvoid}}, Cint, Ptr{CDensity}, Cint, Ptr{UInt8}, Cint, Cint),
-                plan, Ndens, cds, ndims, mask, 64, device))
+    rc = ccall((:kdehip_product_create, libkdehip), Cint,
+               (Ref{Ptr{Cvoid}}, Cint, Ptr{CDensity}, Cint, Ptr{UInt8}, Cint, Cint),
+               plan, Ndens, cds, ndims, mask, 64, device)
   end
+  if rc == KDEHIP_ERR_UNSUPPORTED   # beyond the compiled limits: the reference's own front end and engine
+    return KDE.prodAppxMSGibbsS(npd0, trees, anFcns, anParams; Niter=Niter, glbs=glbs, addEntropy=addEntropy,
+                                ndims=ndims, Ndens=Ndens, Np=Np, partialDimMask=partialDimMask)
+  end
+  check(rc)
   try
     s = seed === nothing ? rand(UInt64) : seed
     check(ccall((:kdehip_product_sample_philox_host, libkdehip), Cint,
@@ -198,6 +213,7 @@ function enable!()
   orig = KDE.gibbs1
   m = first(methods(orig))
   invoke_original(args...; kw...) = Base.invoke_in_world(m.primary_world, orig, args...; kw...)
+  ORIGINAL_GIBBS1[] = invoke_original
   @eval KDE function gibbs1(Ndens::Int, trees::Array{BallTreeDensity,1}, Np::Int, Niter::Int,
                             pts::Array{Float64,1}, ind::Array{Int}, randU::Array{Float64,1},
                             randN::Array{Float64,1}; addop=(+,), diffop=(-,), getMu=(getEuclidMu,),
