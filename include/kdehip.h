@@ -132,6 +132,10 @@ int kdehip_product_sample_philox(kdehip_product *plan, int64_t Np, int Niter, ui
 int kdehip_product_sample_philox_host(kdehip_product *plan, int64_t Np, int Niter, uint64_t seed,
                                       int64_t sample_offset, int addEntropy, double *points,
                                       int64_t *indices, int32_t *labels);
+/* Diagnostic: how many label draws of this plan's runs so far took the reference's underflow branch
+ * (`pT < 1e-99` -> uniform draw over the frontier, src/MSGibbs01.jl:311-315).  Waits for the device.
+ * Negative = error code. */
+int64_t kdehip_product_fallback_count(kdehip_product *plan);
 /* Scheduling knob for experiments/benchmarks; results never depend on it.  0 = library default,
  * 1 = read every tile from global memory (no LDS staging), 4 = no conditional tables,
  * 2 / 8 / 12 / 16 = 4 / 8 / 12 / 16 chains per workgroup (default: chosen from the number of chains). */

@@ -55,6 +55,7 @@ SIGNATURES = {
     "kdehip_product_info": (C.c_int, [C.c_void_p, C.POINTER(CProductInfo)]),
     "kdehip_product_randu_per_sample": (C.c_int64, [C.c_void_p, C.c_int]),
     "kdehip_product_randn_per_sample": (C.c_int64, [C.c_void_p]),
+    "kdehip_product_fallback_count": (C.c_int64, [C.c_void_p]),
     "kdehip_product_sample_streams": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64,
                                                 C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p,
                                                 C.c_void_p, C.c_void_p]),

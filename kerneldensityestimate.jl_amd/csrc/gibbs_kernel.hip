@@ -94,6 +94,9 @@ template <> struct Num<double> {
   }
   static __device__ __forceinline__ double fma(double a, double b, double c) { return ::fma(a, b, c); }
   static __device__ __forceinline__ double tiny_total() { return 1e-99; }  // :311
+  static constexpr int kOffsetSteps = 0;   // fp64 holds pT < 1e-99 directly: one attempt
+  static constexpr double kOffsetStep = 0.0;
+  static __device__ __forceinline__ double final_total() { return 1e-99; }
 };
 template <> struct Num<float> {
   static __device__ __forceinline__ float exp(float x) { return __expf(x); }
@@ -106,7 +109,15 @@ template <> struct Num<float> {
   static __device__ __forceinline__ float sqrt(float x) { return ::sqrtf(x); }
   static __device__ __forceinline__ float rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }  // normal x: no denormal scaling
   static __device__ __forceinline__ float fma(float a, float b, float c) { return ::fmaf(a, b, c); }
-  static __device__ __forceinline__ float tiny_total() { return 1e-37f; }  // 1e-99 is not a float
+  // The reference's "pT < 1e-99 -> uniform draw" (:311-315) in a type whose exp underflows at 2^-126: the sum is
+  // formed with every exponent raised by a wave-uniform offset o = 0, 110, 220, 330 binades (first o whose sum
+  // reaches 2^-100, so that every term within 2^-26 of the largest one is still a normal number); the selection
+  // only needs relative values, and at o = 330 the reference's threshold 1e-99 * 2^330 = 2.19 is representable:
+  // the fallback fires exactly where the fp64 sum would be below 1e-99 (up to fp32 rounding of the sum).
+  static __device__ __forceinline__ float tiny_total() { return 0x1p-100f; }
+  static constexpr int kOffsetSteps = 3;
+  static constexpr float kOffsetStep = 110.0f;
+  static __device__ __forceinline__ float final_total() { return static_cast<float>(1e-99 * 0x1p330); }
 };
 
 // Two fp32 entries per lane in one register pair: gfx950 executes v_pk_add/mul/fma_f32 on both halves at
@@ -121,6 +132,13 @@ template <> struct Num<kdehip_f2> {
     return __builtin_elementwise_fma(a, b, c);
   }
 };
+
+// min(x, hi) that keeps a NaN a NaN (the fast forms detect a NaN centre/cov on the total)
+__device__ __forceinline__ float clamp_hi(float x, float hi) { return x > hi ? hi : x; }
+__device__ __forceinline__ double clamp_hi(double x, double hi) { return x > hi ? hi : x; }
+__device__ __forceinline__ kdehip_f2 clamp_hi(kdehip_f2 x, kdehip_f2 hi) {
+  return {x.x > hi.x ? hi.x : x.x, x.y > hi.y ? hi.y : x.y};
+}
 
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_fetch(double v) {
@@ -195,10 +213,20 @@ __device__ __forceinline__ float load_single(P p) {
 }
 
 // UNIFORM: the level has one bandwidth vector; ninv[d] = -1/(2 c_d), scale = rsqrt(prod_d c_d).
-template <typename T, int D>
+// OFF (fp32 retries only): every exponent is raised by `xoff` (base-2 units) and clamped below the overflow
+// of exp2 -- see Num<float>::tiny_total.
+template <typename T, int D, bool OFF = false>
 struct EvalUniform {
   T center[D], ninv[D], scale;
+  T xoff;
   const double *tab;
+  __device__ __forceinline__ EvalUniform<T, D, true> with_offset(T o) const {
+    EvalUniform<T, D, true> e;
+#pragma unroll
+    for (int d = 0; d < D; ++d) { e.center[d] = center[d]; e.ninv[d] = ninv[d]; }
+    e.scale = scale; e.tab = tab; e.xoff = o;
+    return e;
+  }
   template <typename V> struct RowT { V m[D], w; };  // the fields of one entry (V = T) or of two (packed pair)
   using Row = RowT<T>;
   template <typename P>
@@ -212,12 +240,13 @@ struct EvalUniform {
   // value = front * exp(exponent)
   template <typename V>
   __device__ __forceinline__ V exponent(const RowT<V> &r, V &front) const {
-    V acc = V(0);
+    V acc = OFF ? V(xoff) : V(0);
 #pragma unroll
     for (int d = 0; d < D; ++d) {
       const V dl = r.m[d] - center[d];
       acc = Num<V>::fma(dl * dl, V(ninv[d]), acc);
     }
+    if constexpr (OFF) acc = clamp_hi(acc, V(T(126)));
     // (no per-entry NaN test: on the fast paths every tile value is finite and positive, so a NaN can
     // only come from the wave-uniform centre/cov and then hits every entry -- handled on the total)
     front = r.w * scale;
@@ -253,11 +282,19 @@ struct EvalUniform {
 };
 
 // FAST: per-node bandwidths; one rsqrt instead of D divides and D logs.
-template <typename T, int D, bool MASKED>
+template <typename T, int D, bool MASKED, bool OFF = false>
 struct EvalFast {
   T center[D], cov[D];
+  T xoff;
   const double *tab;
   uint32_t act;  // MASKED: dimensions that take part (:282); an inactive one contributes c = 1, delta = 0
+  __device__ __forceinline__ EvalFast<T, D, MASKED, true> with_offset(T o) const {
+    EvalFast<T, D, MASKED, true> e;
+#pragma unroll
+    for (int d = 0; d < D; ++d) { e.center[d] = center[d]; e.cov[d] = cov[d]; }
+    e.tab = tab; e.act = act; e.xoff = o;
+    return e;
+  }
   template <typename V> struct RowT { V m[D], v[D], w; };
   using Row = RowT<T>;
   template <typename P>
@@ -298,7 +335,10 @@ struct EvalFast {
     const V r = Num<V>::rsqrt(prod);
     const V q = num * r * r;  // = sum_d delta_d^2 / c_d
     front = w * r;
-    return V(T(-0.5) * T(Num<T>::kExpArg)) * q;
+    if constexpr (OFF)
+      return clamp_hi(Num<V>::fma(q, V(T(-0.5) * T(Num<T>::kExpArg)), V(xoff)), V(T(126)));
+    else
+      return V(T(-0.5) * T(Num<T>::kExpArg)) * q;
   }
   template <typename V>
   __device__ __forceinline__ V eval(const RowT<V> &row) const {
@@ -332,10 +372,18 @@ struct EvalFast {
 };
 
 // GENERIC: literally the reference's accumulation (:280-303) incl. inactive dimensions.
-template <typename T, int D>
+template <typename T, int D, bool OFF = false>
 struct EvalGeneric {
   T center[D], cov[D];
+  T xoff;
   uint32_t act;
+  __device__ __forceinline__ EvalGeneric<T, D, true> with_offset(T o) const {
+    EvalGeneric<T, D, true> e;
+#pragma unroll
+    for (int d = 0; d < D; ++d) { e.center[d] = center[d]; e.cov[d] = cov[d]; }
+    e.act = act; e.xoff = o;
+    return e;
+  }
   struct Row { T m[D], v[D], w; };
   template <typename P>
   __device__ __forceinline__ Row load(P e) const {
@@ -359,7 +407,12 @@ struct EvalGeneric {
         }
       }
     }
-    const T p = Num<T>::exp(T(-0.5) * acc) * row.w;
+    T arg = T(-0.5) * acc;
+    if constexpr (OFF) {  // xoff binades = xoff * ln 2 in the natural exponent; stay below exp's overflow
+      arg = arg + xoff * T(0.6931471805599453);
+      arg = clamp_hi(arg, T(87));
+    }
+    const T p = Num<T>::exp(arg) * row.w;
     return (p != p) ? T(0) : p;
   }
   template <typename P>
@@ -425,9 +478,15 @@ __device__ __forceinline__ T lane_sum_rows(P rows, int nrows, int RS, int lane, 
   return S;
 }
 
+// Uniform draws over the frontier that replaced an underflowed conditional (:311-315) are counted when the run
+// carries a counter (RunArgs.fallbacks): how tests compare the fp32 path's fallback behaviour with fp64's.
+__device__ __forceinline__ void count_fallback(unsigned long long *counter, int lane) {
+  if (counter && lane == 0) atomicAdd(counter, 1ull);
+}
+
 template <typename T, typename P, typename Eval>
 __device__ __forceinline__ int select_from_scan(T incl, T S, P rows, const LevelDesc &ds, int lane, const Eval &ev,
-                                                double u
+                                                double u, T thr, bool final, unsigned long long *fb
 #ifdef KDEHIP_STAMPS
                                                 , unsigned long long *stamp_acc, bool stamp_on
 #endif
@@ -436,19 +495,22 @@ __device__ __forceinline__ int select_from_scan(T incl, T S, P rows, const Level
 // Selection from the lane sums S: wavefront scan, winning lane, then pass 2 over the winning lane's
 // block read through `rows` (row 0, field 0, lane 0 of the whole tile; LDS or global).
 template <typename T, typename P, typename Eval>
-__device__ __forceinline__ int select_label(T S, P rows, const LevelDesc &ds, int lane, const Eval &ev, double u
+__device__ __forceinline__ int select_label(T S, P rows, const LevelDesc &ds, int lane, const Eval &ev, double u,
+                                            T thr, bool final, unsigned long long *fb
 #ifdef KDEHIP_STAMPS
                                             , unsigned long long *stamp_acc, bool stamp_on
 #endif
 ) {
-  return select_from_scan<T, P>(wave_inclusive_scan(S), S, rows, ds, lane, ev, u KSTAMP_ARGS);
+  return select_from_scan<T, P>(wave_inclusive_scan(S), S, rows, ds, lane, ev, u, thr, final, fb KSTAMP_ARGS);
 }
 
 // The selection proper, from the inclusive wavefront scan `incl` of the lane sums S.  Also entered
 // directly with a scan that was computed ahead of time (conditional tables, single-row frontiers).
+// A total below `thr` (or NaN) is the reference's underflow case: with `final` the uniform fallback is taken,
+// otherwise -1 is returned and the caller repeats the evaluation with raised exponents (fp32 only).
 template <typename T, typename P, typename Eval>
 __device__ __forceinline__ int select_from_scan(T incl, T S, P rows, const LevelDesc &ds, int lane, const Eval &ev,
-                                                double u
+                                                double u, T thr, bool final, unsigned long long *fb
 #ifdef KDEHIP_STAMPS
                                                 , unsigned long long *stamp_acc, bool stamp_on
 #endif
@@ -458,7 +520,9 @@ __device__ __forceinline__ int select_from_scan(T incl, T S, P rows, const Level
   KSTAMP(tp1);
   const T total = lane_read(incl, 63);
 
-  if (!(total >= Num<T>::tiny_total())) {  // also taken when every weight is NaN (:302 zeroes them all)
+  if (!(total >= thr)) {  // also taken when every weight is NaN (:302 zeroes them all)
+    if (!final) return -1;
+    count_fallback(fb, lane);
     // "stick with selection of others": uniform over the frontier (:311-315); with a zero/NaN
     // last weight the reference's CDF is all-NaN and the last entry is taken.
     const int zl = n - 1;
@@ -519,7 +583,8 @@ __device__ __forceinline__ int select_from_scan(T incl, T S, P rows, const Level
 // sums the first pass accumulates), finds the first row that reaches the target, and the answer is read from
 // the winning lane.  (Rows beyond B are padding of weight 0 in the tile; they are not even evaluated.)
 template <typename T, typename P, typename Eval, int BMAX>
-__device__ __forceinline__ int draw_label_kept(P rows, const LevelDesc &ds, int lane, const Eval &ev, double u) {
+__device__ __forceinline__ int draw_label_kept(P rows, const LevelDesc &ds, int lane, const Eval &ev, double u,
+                                               unsigned long long *fb) {
   const int n = ds.n, B = ds.B, F = ds.F;
   const int RS = F * 64 + 1;
   T v[BMAX];
@@ -553,6 +618,7 @@ __device__ __forceinline__ int draw_label_kept(P rows, const LevelDesc &ds, int 
   const T incl = wave_inclusive_scan(S);
   const T total = lane_read(incl, 63);
   if (!(total >= Num<T>::tiny_total())) {  // uniform fallback (:311-315), as in select_from_scan
+    count_fallback(fb, lane);
     const int zl = n - 1;
     const T wl = rows[(zl % B) * RS + (F - 1) * 64 + zl / B];
     int z = n - 1;
@@ -583,8 +649,47 @@ __device__ __forceinline__ int draw_label_kept(P rows, const LevelDesc &ds, int 
   return istar * 64 + lstar;
 }
 
+// fp32: the evaluation is repeated with every exponent raised by 110, 220, 330 binades while the sum stays below
+// 2^-100 (Num<float>::tiny_total); the last attempt applies the reference's threshold.  Rare (densities far
+// apart), so these passes are the plain ones: no prefetch, any readable pointer (LDS image or global memory).
+template <typename T, typename P, typename Eval>
+__device__ __noinline__ int draw_label_raised(P rows, const LevelDesc &ds, int lane, const Eval &ev, double u,
+                                              unsigned long long *fb) {
+  int pos = -1;
+  for (int k = 1; k <= Num<T>::kOffsetSteps && pos < 0; ++k) {
+    const auto evo = ev.with_offset(T(Num<T>::kOffsetStep) * T(k));
+    const T S = lane_sum_rows<T, P, std::decay_t<decltype(evo)>, false>(rows, ds.B, ds.F * 64 + 1, lane, evo);
+    const bool final = (k == Num<T>::kOffsetSteps);
+    pos = select_from_scan<T, P>(wave_inclusive_scan(S), S, rows, ds, lane, evo, u,
+                                 final ? Num<T>::final_total() : Num<T>::tiny_total(), final, fb
+#ifdef KDEHIP_STAMPS
+                                 , nullptr, false
+#endif
+    );
+  }
+  return pos;
+}
+
+// selection from first-pass lane sums S formed at offset 0, then the raised attempts if the sum underflowed
+template <typename T, typename P, typename Eval>
+__device__ __forceinline__ int select_or_raise(T S, P rows, const LevelDesc &ds, int lane, const Eval &ev, double u,
+                                               unsigned long long *fb
+#ifdef KDEHIP_STAMPS
+                                               , unsigned long long *stamp_acc, bool stamp_on
+#endif
+) {
+  constexpr bool kOneAttempt = (Num<T>::kOffsetSteps == 0);
+  const int pos = select_label<T, P>(S, rows, ds, lane, ev, u, Num<T>::tiny_total(), kOneAttempt, fb KSTAMP_ARGS);
+  if constexpr (kOneAttempt) return pos;
+  else {
+    if (__builtin_expect(pos >= 0, 1)) return pos;
+    return draw_label_raised<T, P>(rows, ds, lane, ev, u, fb);
+  }
+}
+
 template <typename T, typename P, bool PREFETCH, bool kKeptRows, typename Eval>
-__device__ __forceinline__ int draw_label(P rows, const LevelDesc &ds, int lane, const Eval &ev, double u
+__device__ __forceinline__ int draw_label(P rows, const LevelDesc &ds, int lane, const Eval &ev, double u,
+                                          unsigned long long *fb
 #ifdef KDEHIP_STAMPS
                                           , unsigned long long *stamp_acc, bool stamp_on
 #endif
@@ -592,15 +697,15 @@ __device__ __forceinline__ int draw_label(P rows, const LevelDesc &ds, int lane,
 #if !defined(KDEHIP_STAMPS) && !defined(KDEHIP_NO_KEPT)
   // PREFETCH marks the builds with registers to spare (see kPrefetchRows); fp32 has its packed-pair first pass
   if constexpr (PREFETCH && kIsLdsPtr<P> && sizeof(T) == 8 && kKeptRows) {
-    if (ds.B > 1 && ds.B <= 4) return draw_label_kept<T, P, Eval, 4>(rows, ds, lane, ev, u);
-    if (ds.B > 4 && ds.B <= 8) return draw_label_kept<T, P, Eval, 8>(rows, ds, lane, ev, u);
+    if (ds.B > 1 && ds.B <= 4) return draw_label_kept<T, P, Eval, 4>(rows, ds, lane, ev, u, fb);
+    if (ds.B > 4 && ds.B <= 8) return draw_label_kept<T, P, Eval, 8>(rows, ds, lane, ev, u, fb);
   }
 #endif
   KSTAMP(tp0);
   const T S = lane_sum_rows<T, P, Eval, PREFETCH>(rows, ds.B, ds.F * 64 + 1, lane, ev);
   KSTAMP(tp1);
   KSTAMP_ADD(2, tp0, tp1);
-  return select_label<T, P>(S, rows, ds, lane, ev, u KSTAMP_ARGS);
+  return select_or_raise<T, P>(S, rows, ds, lane, ev, u, fb KSTAMP_ARGS);
 }
 
 // ---- the sampler ----------------------------------------------------------------------------------
@@ -810,7 +915,7 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan,
     auto rows = hdr + kTileHeader;
     using P = decltype(rows);
     const int pos = (vflags & 8) ? 0 : draw(ds, hdr, mean, cov, [&](const auto &ev) {
-      return draw_label<T, P, kPrefetchRows, (WAVES <= 8)>(rows, ds, lane, ev, u KSTAMP_ARGS);
+      return draw_label<T, P, kPrefetchRows, (WAVES <= 8)>(rows, ds, lane, ev, u, a.fallbacks KSTAMP_ARGS);
     });
     wave_sync();
     KSTAMP(ts1);
@@ -848,7 +953,8 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan,
         S += lane_sum_rows<T, LdsPtr<T>, std::decay_t<decltype(ev)>, kPrefetchRows>(
             (LdsPtr<T>)(pool + (gchunk & 1) * (kLdsPoolBytes / 2)), nrows, RS, lane, ev);
       }
-      return select_label<T, const T *>(S, hdr + kTileHeader, ds, lane, ev, u KSTAMP_ARGS);
+      // (a raised repeat of the evaluation reads the tile from global memory: no staging, no barriers)
+      return select_or_raise<T, const T *>(S, hdr + kTileHeader, ds, lane, ev, u, a.fallbacks KSTAMP_ARGS);
     });
     wave_sync();
     set_particle(j, ds, hdr, pos);
@@ -892,8 +998,21 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan,
     const T *hdr = data + ds.hdr_off;
     T *row = tables + td.off + static_cast<int64_t>(cfg) * (td.n + 1);
     draw(ds, hdr, mean, cov, [&](const auto &ev) {
-      const T S = lane_sum_rows<T, const T *, std::decay_t<decltype(ev)>, false>(hdr + kTileHeader, 1, ds.F * 64 + 1, lane, ev);
-      const T incl = wave_inclusive_scan(S);
+      T incl = wave_inclusive_scan(lane_sum_rows<T, const T *, std::decay_t<decltype(ev)>, false>(
+          hdr + kTileHeader, 1, ds.F * 64 + 1, lane, ev));
+      // fp32: the scan of the first exponent offset at which the sum is large enough (see Num<float>::tiny_total);
+      // an underflow in the reference's sense is stored as an all-zero row, which the sweep step takes as the
+      // uniform fallback
+      if constexpr (Num<T>::kOffsetSteps > 0) {
+        bool ok = lane_read(incl, 63) >= Num<T>::tiny_total();
+        for (int k = 1; k <= Num<T>::kOffsetSteps && !ok; ++k) {
+          const auto evo = ev.with_offset(T(Num<T>::kOffsetStep) * T(k));
+          incl = wave_inclusive_scan(lane_sum_rows<T, const T *, std::decay_t<decltype(evo)>, false>(
+              hdr + kTileHeader, 1, ds.F * 64 + 1, lane, evo));
+          ok = lane_read(incl, 63) >= (k == Num<T>::kOffsetSteps ? Num<T>::final_total() : Num<T>::tiny_total());
+        }
+        if (!ok) incl = T(0);
+      }
       if (lane < td.n) row[lane] = incl;
       if (lane == 63) row[td.n] = incl;  // the total the selection reads from lane 63
       return 0;
@@ -1044,6 +1163,7 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan,
         const T total = lane_read(incl, n < 64 ? n : 63);  // (a 64-node row: its last scan value IS the total)
         int pos;
         if (!(total >= Num<T>::tiny_total())) {  // uniform fallback (:311-315), rare: fetch the descriptor here
+          count_fallback(a.fallbacks, lane);
           const LevelDesc dk = levels[jt * (L + 1) + l];
           const T wl = ((LdsPtr<T>)(pool + dk.lds_off) + kTileHeader)[(dk.F - 1) * 64 + (n - 1)];
           int z = n - 1;

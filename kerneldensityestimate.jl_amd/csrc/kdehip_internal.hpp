@@ -104,6 +104,7 @@ struct RunArgs {
   double *points;
   int64_t *indices;
   int32_t *labels;
+  unsigned long long *fallbacks;  // optional device counter of uniform-fallback draws (:311-315), or null
 };
 
 // Host result of packing one product (precision-independent description + fp64 payload; the fp32

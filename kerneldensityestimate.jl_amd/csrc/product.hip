@@ -32,6 +32,7 @@ struct kdehip_product {
   TabDesc *d_tabdesc = nullptr;
   bool tables_built = false;
   std::mutex tables_mutex;  // concurrent first runs on one plan build the tables once
+  unsigned long long *d_fallbacks = nullptr;  // device counter of uniform-fallback draws (:311-315), in the blob
   void *d_work = nullptr;   // scratch of the host-buffer entry points (outputs / uploaded streams), grown on demand
   size_t work_cap = 0;
   std::mutex work_mutex;    // host-buffer calls on one plan are serialised
@@ -116,6 +117,7 @@ int enqueue_streams(kdehip_product *plan, int64_t Np, int Niter, const double *d
   a.randU = d_randU; a.randN = d_randN; a.K = K; a.R = R; a.nU = nU; a.nN = nN;
   a.seed = 0; a.sample_offset = 0;
   a.points = d_points; a.indices = d_indices; a.labels = d_labels;
+  a.fallbacks = plan->d_fallbacks;
   rc = maybe_build_tables(plan, Np, a, stream);
   if (rc != KDEHIP_OK) return rc;
   return launch_gibbs(plan->precision, plan->mode, plan->dev, a, stream);
@@ -138,6 +140,7 @@ int enqueue_philox(kdehip_product *plan, int64_t Np, int Niter, uint64_t seed, i
   a.R = kdehip_product_randn_per_sample(plan);
   a.seed = seed; a.sample_offset = sample_offset;
   a.points = d_points; a.indices = d_indices; a.labels = d_labels;
+  a.fallbacks = plan->d_fallbacks;
   rc = maybe_build_tables(plan, Np, a, stream);
   if (rc != KDEHIP_OK) return rc;
   return launch_gibbs(plan->precision, plan->mode, plan->dev, a, stream);
@@ -186,7 +189,8 @@ int kdehip_product_create(kdehip_product **out, int Ndens, const kdehip_density 
   const size_t off_tab = align(off_lev + nlev * sizeof(LevelDesc));
   const size_t off_perm = align(off_tab + ntab * sizeof(TabDesc));
   const size_t off_data = align(off_perm + nperm * sizeof(int32_t));
-  const size_t off_tables = align(off_data + nelem * esz);
+  const size_t off_count = align(off_data + nelem * esz);   // (zeroed with the rest of the upload)
+  const size_t off_tables = align(off_count + sizeof(unsigned long long));
   const size_t total = off_tables + tab_bytes;
   std::vector<unsigned char> blob(off_tables, 0);
   std::memcpy(blob.data() + off_lev, p->host.levels.data(), nlev * sizeof(LevelDesc));
@@ -211,6 +215,7 @@ int kdehip_product_create(kdehip_product **out, int Ndens, const kdehip_density 
   p->d_tabdesc = reinterpret_cast<TabDesc *>(base + off_tab);
   p->d_perm = reinterpret_cast<int32_t *>(base + off_perm);
   p->d_data = base + off_data;
+  p->d_fallbacks = reinterpret_cast<unsigned long long *>(base + off_count);
   p->d_tables = tab_bytes ? base + off_tables : nullptr;
   p->packed_bytes = static_cast<int64_t>(total);
   std::vector<double>().swap(p->host.data);
@@ -265,6 +270,17 @@ int64_t kdehip_product_randu_per_sample(const kdehip_product *plan, int Niter) {
 int64_t kdehip_product_randn_per_sample(const kdehip_product *plan) {
   if (!plan) return -1;
   return static_cast<int64_t>(plan->host.D) * (plan->host.L + 1);
+}
+
+int64_t kdehip_product_fallback_count(kdehip_product *plan) {
+  if (!plan) return set_error(KDEHIP_ERR_ARG, "null plan");
+  DeviceGuard guard;
+  int rc = guard.enter(plan->device);
+  if (rc != KDEHIP_OK) return rc;
+  unsigned long long v = 0;
+  KDEHIP_CHECK(hipDeviceSynchronize());
+  KDEHIP_CHECK(hipMemcpy(&v, plan->d_fallbacks, sizeof(v), hipMemcpyDeviceToHost));
+  return static_cast<int64_t>(v);
 }
 
 int kdehip_product_set_variant(kdehip_product *plan, int variant) {

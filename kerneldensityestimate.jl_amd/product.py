@@ -87,6 +87,13 @@ class ProductPlan:
         """E = (Niter+1) * sum_j sum_l n_{j,l} Gaussian-kernel evaluations per output sample."""
         return (int(Niter) + 1) * int(self.nodes_per_sweep)
 
+    def fallback_count(self) -> int:
+        """Label draws of this plan's runs that took the reference's `pT < 1e-99` uniform fallback (:311-315)."""
+        n = int(_lib.lib.kdehip_product_fallback_count(self._h))
+        if n < 0:
+            _lib.check(n)
+        return n
+
     def set_variant(self, v: int):
         _lib.check(_lib.lib.kdehip_product_set_variant(self._h, int(v)))
 

@@ -293,6 +293,15 @@ static void gaussian_product(okde_glb *g, int dim, double *destMu, double *destC
   *destMu = cov * lambdamu;
 }
 
+/* How often the underflow branch of makeFasterSampleIndex! (:311-315) was taken since the last reset: lets the
+ * tests compare the fallback behaviour of the GPU path's precisions with the reference arithmetic. */
+static int64_t g_fallbacks = 0;
+int64_t okde_fallback_count(int reset) {
+  int64_t v = __atomic_load_n(&g_fallbacks, __ATOMIC_RELAXED);
+  if (reset) __atomic_store_n(&g_fallbacks, 0, __ATOMIC_RELAXED);
+  return v;
+}
+
 /* makeFasterSampleIndex! :250-328.  muValue has Ndim entries (caller applies the offset). */
 static void make_sample_index(okde_glb *g, int j, const double *muValue, const double *covValue,
                               int doCalmost) {
@@ -327,6 +336,7 @@ static void make_sample_index(okde_glb *g, int j, const double *muValue, const d
     if (z + 1 < n) zz = list[z + 1];
   }
   if (pT < 1e-99) { /* :311-315, zz is the last node of the level */
+    __atomic_fetch_add(&g_fallbacks, 1, __ATOMIC_RELAXED); /* test instrumentation, not in the reference */
     double w = t->weights[zz - 1];
     pT = 0.0;
     for (int64_t z = 0; z < n; ++z) { g->p[z] = w; pT += w; }

@@ -59,6 +59,10 @@ int okde_gibbs1_omp(int Ndens, const okde_tree *trees, int64_t Np, int Niter, do
                     int64_t *ind, const double *randU, int64_t nU, const double *randN, int64_t nN,
                     int addEntropy, int ndims, const uint8_t *partialDimMask, int nthreads);
 
+/* Number of times makeFasterSampleIndex! took its underflow branch (pT < 1e-99, :311-315) since the last reset
+ * (process-wide; reset != 0 clears it). */
+int64_t okde_fallback_count(int reset);
+
 /* Direct evaluation (evalDirect, FORCE_EVAL_DIRECT = true): p[q] for pos (D x Nq, column-major); with
  * loo != 0 the density's own points in original order, leave-one-out (pos ignored). */
 int okde_eval_direct(const okde_tree *bd, const double *pos, int64_t Nq, int loo, double *p);

@@ -62,6 +62,8 @@ def lib():
         L.okde_gibbs1_omp.restype = C.c_int
         L.okde_gibbs1_omp.argtypes = [C.c_int, C.POINTER(_Tree), C.c_int64, C.c_int, _f64p, _i64p, _f64p,
                                       C.c_int64, _f64p, C.c_int64, C.c_int, C.c_int, _u8p, C.c_int]
+        L.okde_fallback_count.restype = C.c_int64
+        L.okde_fallback_count.argtypes = [C.c_int]
         L.okde_eval_direct.restype = C.c_int
         L.okde_eval_direct.argtypes = [C.POINTER(_Tree), _f64p, C.c_int64, C.c_int, _f64p]
         L.okde_auto_bandwidth.restype = C.c_int
@@ -178,6 +180,11 @@ def gibbs1(trees, Np, Niter, randU, randN, addEntropy=True, partialDimMask=None,
         raise IndexError(f"okde_gibbs1 failed rc={rc} (randU/randN too short = Julia BoundsError)")
     out = (pts.reshape(Np, D).T.copy(), ind.reshape(Np, M).T.copy())
     return out + (labels,) if want_labels else out
+
+
+def fallback_count(reset=False):
+    """How often makeFasterSampleIndex! took its `pT < 1e-99` branch (src/MSGibbs01.jl:311-315) since the last reset."""
+    return int(lib().okde_fallback_count(int(bool(reset))))
 
 
 def eval_direct(tree, pos=None, loo=False):
