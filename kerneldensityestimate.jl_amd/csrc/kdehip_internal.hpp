@@ -80,7 +80,7 @@ constexpr int64_t kTabMinChains = 16;           // tables are built at the first
 struct PlanDev {
   const void *data;          // T[...]
   const int32_t *perm;       // int32[...]
-  const LevelDesc *levels;   // [M][L+1], level 0 = root
+  const LevelDesc *levels;   // [M][L+1], level 0 = root; the 8 bytes in front of it: counter of uniform-fallback draws
   const void *tables;        // T[...] conditional tables (may be unbuilt: RunArgs.use_tables)
   const TabDesc *tabdesc;    // [M][L+1]
   int64_t tab_rows_total;
@@ -104,7 +104,6 @@ struct RunArgs {
   double *points;
   int64_t *indices;
   int32_t *labels;
-  unsigned long long *fallbacks;  // optional device counter of uniform-fallback draws (:311-315), or null
 };
 
 // Host result of packing one product (precision-independent description + fp64 payload; the fp32

@@ -117,7 +117,6 @@ int enqueue_streams(kdehip_product *plan, int64_t Np, int Niter, const double *d
   a.randU = d_randU; a.randN = d_randN; a.K = K; a.R = R; a.nU = nU; a.nN = nN;
   a.seed = 0; a.sample_offset = 0;
   a.points = d_points; a.indices = d_indices; a.labels = d_labels;
-  a.fallbacks = plan->d_fallbacks;
   rc = maybe_build_tables(plan, Np, a, stream);
   if (rc != KDEHIP_OK) return rc;
   return launch_gibbs(plan->precision, plan->mode, plan->dev, a, stream);
@@ -140,7 +139,6 @@ int enqueue_philox(kdehip_product *plan, int64_t Np, int Niter, uint64_t seed, i
   a.R = kdehip_product_randn_per_sample(plan);
   a.seed = seed; a.sample_offset = sample_offset;
   a.points = d_points; a.indices = d_indices; a.labels = d_labels;
-  a.fallbacks = plan->d_fallbacks;
   rc = maybe_build_tables(plan, Np, a, stream);
   if (rc != KDEHIP_OK) return rc;
   return launch_gibbs(plan->precision, plan->mode, plan->dev, a, stream);
@@ -185,12 +183,12 @@ int kdehip_product_create(kdehip_product **out, int Ndens, const kdehip_density 
   const size_t ntab = p->host.tabdesc.size();
   const size_t tab_bytes = static_cast<size_t>(p->host.tab_entries) * esz;
   auto align = [](size_t x) { return (x + 255) & ~static_cast<size_t>(255); };
-  const size_t off_lev = 0;
+  const size_t off_lev = 256;                                  // the fallback counter sits in the 8 bytes before it
+  const size_t off_count = off_lev - sizeof(unsigned long long); // (zeroed with the rest of the upload)
   const size_t off_tab = align(off_lev + nlev * sizeof(LevelDesc));
   const size_t off_perm = align(off_tab + ntab * sizeof(TabDesc));
   const size_t off_data = align(off_perm + nperm * sizeof(int32_t));
-  const size_t off_count = align(off_data + nelem * esz);   // (zeroed with the rest of the upload)
-  const size_t off_tables = align(off_count + sizeof(unsigned long long));
+  const size_t off_tables = align(off_data + nelem * esz);
   const size_t total = off_tables + tab_bytes;
   std::vector<unsigned char> blob(off_tables, 0);
   std::memcpy(blob.data() + off_lev, p->host.levels.data(), nlev * sizeof(LevelDesc));
