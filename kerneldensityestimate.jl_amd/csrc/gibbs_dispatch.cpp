@@ -20,11 +20,52 @@ int device_cu_count() {
   return n;
 }
 
-#define KDEHIP_DECL(d) int launch_gibbs_d##d(int, int, const PlanDev &, const RunArgs &, void *);
+int chains_per_workgroup(int64_t Np, int variant) {
+  // fewer wavefronts per SIMD run each chain faster, more hide each other's latencies; the relative costs of one
+  // round are measured ones (config 3: 0.59, 0.79, 1.10, 1.37 ms for 4, 8, 12, 16 chains per workgroup) and
+  // differ little between shapes
+  const int v = variant % 1000;
+  if (v == 8 || v == 12 || v == 16) return v;
+  if (v == 2) return 4;
+  static const int kWidth[4] = {4, 8, 12, 16};
+  static const double kCost[4] = {1.0, 1.34, 1.86, 2.31};
+  const int64_t cus = device_cu_count();
+  int waves = 16;
+  double best = 0.0;
+  for (int i = 0; i < 4; ++i) {
+    const int64_t wgs = (Np + kWidth[i] - 1) / kWidth[i];
+    const double t = static_cast<double>((wgs + cus - 1) / cus) * kCost[i];
+    if (i == 0 || t < best) { best = t; waves = kWidth[i]; }
+  }
+  return waves;
+}
+
+#define KDEHIP_DECL(d)                                                                  \
+  int launch_gibbs_d##d(int, int, const PlanDev &, const RunArgs &, void *);           \
+  int launch_lean_d##d(int, int, const PlanDev &, const RunArgs &, void *);
 KDEHIP_DECL(1) KDEHIP_DECL(2) KDEHIP_DECL(3) KDEHIP_DECL(4) KDEHIP_DECL(5) KDEHIP_DECL(6) KDEHIP_DECL(7) KDEHIP_DECL(8)
 #undef KDEHIP_DECL
 
-int launch_gibbs(int precision, int mode, const PlanDev &plan, const RunArgs &args, void *stream) {
+int launch_gibbs(int precision, int mode, const PlanDev &plan, const RunArgs &args_in, void *stream) {
+  RunArgs args = args_in;
+  const int v = args.variant % 1000;
+  const bool generic_only = (v >= kVariantGenericBase && v < kVariantGenericBase + 20);
+  if (generic_only) args.variant -= kVariantGenericBase;
+  if (!generic_only) {  // products of 2..4 densities, all dimensions active: the register-resident kernel
+    int rc = kLeanNotCovered;
+    switch (plan.D) {
+      case 1: rc = launch_lean_d1(precision, mode, plan, args, stream); break;
+      case 2: rc = launch_lean_d2(precision, mode, plan, args, stream); break;
+      case 3: rc = launch_lean_d3(precision, mode, plan, args, stream); break;
+      case 4: rc = launch_lean_d4(precision, mode, plan, args, stream); break;
+      case 5: rc = launch_lean_d5(precision, mode, plan, args, stream); break;
+      case 6: rc = launch_lean_d6(precision, mode, plan, args, stream); break;
+      case 7: rc = launch_lean_d7(precision, mode, plan, args, stream); break;
+      case 8: rc = launch_lean_d8(precision, mode, plan, args, stream); break;
+      default: break;
+    }
+    if (rc != kLeanNotCovered) return rc;
+  }
   switch (plan.D) {
     case 1: return launch_gibbs_d1(precision, mode, plan, args, stream);
     case 2: return launch_gibbs_d2(precision, mode, plan, args, stream);

@@ -46,726 +46,9 @@
 // polynomial, ~1 ulp; the GENERIC form calls the library exp/log.
 //
 // Compiled with -ffp-contract=off; fused multiply-adds are written explicitly where wanted.
-#include <hip/hip_runtime.h>
-
-#include <cstdint>
-#include <type_traits>
-
-#include "fastexp.hpp"
-#include "kdehip_internal.hpp"
-#include "philox.hpp"
+#include "gibbs_device.hpp"
 
 namespace kdehip {
-
-// ---- small device helpers ------------------------------------------------------------------------
-
-// 1/x for positive, finite, normal x (the fast paths guarantee that at pack time): hardware
-// reciprocal + two Newton steps, ~half the dependent latency of the IEEE division sequence.
-__device__ __forceinline__ double fast_rcp(double x) {
-  double r = __builtin_amdgcn_rcp(x);
-  double e = fma(-x, r, 1.0);
-  r = fma(r, e, r);
-  e = fma(-x, r, 1.0);
-  return fma(r, e, r);
-}
-__device__ __forceinline__ float fast_rcp(float x) {
-  float r = __builtin_amdgcn_rcpf(x);
-  return fmaf(r, fmaf(-x, r, 1.0f), r);
-}
-
-template <typename T> struct Num;
-template <> struct Num<double> {
-  static __device__ __forceinline__ double exp(double x) { return ::exp(x); }
-  // the fast forms hand exp_fast an exponent already multiplied by kExpArg (fp32: log2 e, so that the
-  // hardware's base-2 exponential needs no extra multiply; fp64: 1)
-  static constexpr double kExpArg = 1.0;
-  static __device__ __forceinline__ double exp_fast(double x, const double *tab) { return exp_nonpos(x, tab); }
-  using ExpMid = ExpSplit;  // exp_fast in two halves (table lookup issued / result formed)
-  static __device__ __forceinline__ ExpMid exp_begin(double x, const double *tab) { return exp_nonpos_begin(x, tab); }
-  static __device__ __forceinline__ double exp_end(const ExpMid &m) { return exp_nonpos_end(m); }
-  static __device__ __forceinline__ double log(double x) { return ::log(x); }
-  static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
-  // 1/sqrt(x) for positive, finite, normal x (guaranteed on the fast forms at pack time): the library's
-  // refinement of v_rsq_f64 without its zero/infinity handling -- same result, three instructions fewer
-  static __device__ __forceinline__ double rsqrt(double x) {
-    const double y = __builtin_amdgcn_rsq(x);
-    const double e = fma(-x * y, y, 1.0);
-    return fma(y * e, fma(e, 0.375, 0.5), y);
-  }
-  static __device__ __forceinline__ double fma(double a, double b, double c) { return ::fma(a, b, c); }
-  static __device__ __forceinline__ double tiny_total() { return 1e-99; }  // :311
-  static constexpr int kOffsetSteps = 0;   // fp64 holds pT < 1e-99 directly: one attempt
-  static constexpr double kOffsetStep = 0.0;
-  static __device__ __forceinline__ double final_total() { return 1e-99; }
-};
-template <> struct Num<float> {
-  static __device__ __forceinline__ float exp(float x) { return __expf(x); }
-  static constexpr float kExpArg = 1.44269504088896340736f;
-  static __device__ __forceinline__ float exp_fast(float x, const double *) { return __builtin_amdgcn_exp2f(x); }
-  struct ExpMid { float x; };
-  static __device__ __forceinline__ ExpMid exp_begin(float x, const double *) { return {x}; }
-  static __device__ __forceinline__ float exp_end(const ExpMid &m) { return __builtin_amdgcn_exp2f(m.x); }
-  static __device__ __forceinline__ float log(float x) { return __logf(x); }
-  static __device__ __forceinline__ float sqrt(float x) { return ::sqrtf(x); }
-  static __device__ __forceinline__ float rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }  // normal x: no denormal scaling
-  static __device__ __forceinline__ float fma(float a, float b, float c) { return ::fmaf(a, b, c); }
-  // The reference's "pT < 1e-99 -> uniform draw" (:311-315) in a type whose exp underflows at 2^-126: the sum is
-  // formed with every exponent raised by a wave-uniform offset o = 0, 110, 220, 330 binades (first o whose sum
-  // reaches 2^-100, so that every term within 2^-26 of the largest one is still a normal number); the selection
-  // only needs relative values, and at o = 330 the reference's threshold 1e-99 * 2^330 = 2.19 is representable:
-  // the fallback fires exactly where the fp64 sum would be below 1e-99 (up to fp32 rounding of the sum).
-  static __device__ __forceinline__ float tiny_total() { return 0x1p-100f; }
-  static constexpr int kOffsetSteps = 3;
-  static constexpr float kOffsetStep = 110.0f;
-  static __device__ __forceinline__ float final_total() { return static_cast<float>(1e-99 * 0x1p330); }
-};
-
-// Two fp32 entries per lane in one register pair: gfx950 executes v_pk_add/mul/fma_f32 on both halves at
-// the rate of one scalar fp32 instruction, so the fp32 first pass evaluates the rows two at a time.
-typedef float kdehip_f2 __attribute__((ext_vector_type(2)));
-template <> struct Num<kdehip_f2> {
-  static __device__ __forceinline__ kdehip_f2 exp_fast(kdehip_f2 x, const double *) {
-    return {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
-  }
-  static __device__ __forceinline__ kdehip_f2 rsqrt(kdehip_f2 x) { return {__builtin_amdgcn_rsqf(x.x), __builtin_amdgcn_rsqf(x.y)}; }
-  static __device__ __forceinline__ kdehip_f2 fma(kdehip_f2 a, kdehip_f2 b, kdehip_f2 c) {
-    return __builtin_elementwise_fma(a, b, c);
-  }
-};
-
-// min(x, hi) that keeps a NaN a NaN (the fast forms detect a NaN centre/cov on the total)
-__device__ __forceinline__ float clamp_hi(float x, float hi) { return x > hi ? hi : x; }
-__device__ __forceinline__ double clamp_hi(double x, double hi) { return x > hi ? hi : x; }
-__device__ __forceinline__ kdehip_f2 clamp_hi(kdehip_f2 x, kdehip_f2 hi) {
-  return {x.x > hi.x ? hi.x : x.x, x.y > hi.y ? hi.y : x.y};
-}
-
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_fetch(double v) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  constexpr bool kBound = (ROW_MASK == 0xF);  // full row mask: bound_ctrl supplies the zeros
-  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, kBound);
-  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, kBound);
-  return __hiloint2double(hi, lo);
-}
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_fetch(float v) {
-  constexpr bool kBound = (ROW_MASK == 0xF);
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, kBound));
-}
-
-// Inclusive prefix sum over the 64 lanes of a wavefront with DPP row shifts / row broadcasts
-// (lanes without a source read 0).
-template <typename T>
-__device__ __forceinline__ T wave_inclusive_scan(T v) {
-  v += dpp_fetch<0x111, 0xF>(v);  // row_shr:1
-  v += dpp_fetch<0x112, 0xF>(v);  // row_shr:2
-  v += dpp_fetch<0x114, 0xF>(v);  // row_shr:4
-  v += dpp_fetch<0x118, 0xF>(v);  // row_shr:8
-  v += dpp_fetch<0x142, 0xA>(v);  // row_bcast:15 -> rows 1 and 3
-  v += dpp_fetch<0x143, 0xC>(v);  // row_bcast:31 -> rows 2 and 3
-  return v;
-}
-
-// Orders this wavefront's LDS traffic (written by some lanes, read by others) in the compiler;
-// the hardware executes one wavefront's LDS instructions in order.
-__device__ __forceinline__ void wave_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-}
-
-__device__ __forceinline__ double lane_read(double v, int src) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
-  return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ float lane_read(float v, int src) {
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
-}
-
-// ---- phase stamps (diagnostic build only, -DKDEHIP_STAMPS; never part of the product library) ----
-#ifdef KDEHIP_STAMPS
-static __device__ unsigned long long g_stamp_acc[16];
-#define KSTAMP(var) unsigned long long var = __builtin_amdgcn_s_memtime()
-#define KSTAMP_ARGS , stamp_acc, stamp_on
-#define KSTAMP_ADD(slot, t0, t1) do { if (stamp_on) stamp_acc[slot] += (t1) - (t0); } while (0)
-#else
-#define KSTAMP(var) do {} while (0)
-#define KSTAMP_ARGS
-#define KSTAMP_ADD(slot, t0, t1) do {} while (0)
-#endif
-
-template <typename P> constexpr bool kIsLdsPointer = false;
-template <typename T> constexpr bool kIsLdsPointer<const __attribute__((address_space(3))) T *> = true;
-
-// ---- kernel evaluation of one frontier entry -----------------------------------------------------
-// `e` points at (row, field 0, lane) of the entry (LDS or global pointer); field f is at e[f*64].
-
-// A load the compiler may not merge with its neighbours: the two halves of a packed fp32 pair come from two
-// rows; merged ds_read2 loads of two FIELDS of one row would land in the wrong register pairing and cost a
-// v_mov per value to untangle.
-template <typename P>
-__device__ __forceinline__ float load_single(P p) {
-  using E = std::remove_pointer_t<P>;
-  using VP = std::conditional_t<kIsLdsPointer<P>, volatile __attribute__((address_space(3))) const float *, volatile const float *>;
-  (void)sizeof(E);
-  return *(VP)(p);
-}
-
-// UNIFORM: the level has one bandwidth vector; ninv[d] = -1/(2 c_d), scale = rsqrt(prod_d c_d).
-// OFF (fp32 retries only): every exponent is raised by `xoff` (base-2 units) and clamped below the overflow
-// of exp2 -- see Num<float>::tiny_total.
-template <typename T, int D, bool OFF = false>
-struct EvalUniform {
-  T center[D], ninv[D], scale;
-  T xoff;
-  const double *tab;
-  __device__ __forceinline__ EvalUniform<T, D, true> with_offset(T o) const {
-    EvalUniform<T, D, true> e;
-#pragma unroll
-    for (int d = 0; d < D; ++d) { e.center[d] = center[d]; e.ninv[d] = ninv[d]; }
-    e.scale = scale; e.tab = tab; e.xoff = o;
-    return e;
-  }
-  template <typename V> struct RowT { V m[D], w; };  // the fields of one entry (V = T) or of two (packed pair)
-  using Row = RowT<T>;
-  template <typename P>
-  __device__ __forceinline__ Row load(P e) const {
-    Row r;
-#pragma unroll
-    for (int d = 0; d < D; ++d) r.m[d] = e[d * 64];
-    r.w = e[D * 64];
-    return r;
-  }
-  // value = front * exp(exponent)
-  template <typename V>
-  __device__ __forceinline__ V exponent(const RowT<V> &r, V &front) const {
-    V acc = OFF ? V(xoff) : V(0);
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-      const V dl = r.m[d] - center[d];
-      acc = Num<V>::fma(dl * dl, V(ninv[d]), acc);
-    }
-    if constexpr (OFF) acc = clamp_hi(acc, V(T(126)));
-    // (no per-entry NaN test: on the fast paths every tile value is finite and positive, so a NaN can
-    // only come from the wave-uniform centre/cov and then hits every entry -- handled on the total)
-    front = r.w * scale;
-    return acc;
-  }
-  template <typename V>
-  __device__ __forceinline__ V eval(const RowT<V> &r) const {
-    V front;
-    const V x = exponent<V>(r, front);
-    return front * Num<V>::exp_fast(x, tab);
-  }
-  // the same value in two halves: arg() ends by issuing the exp table lookup, fin() uses it
-  struct Mid { T front; typename Num<T>::ExpMid e; };
-  __device__ __forceinline__ Mid arg(const Row &r) const {
-    Mid m;
-    const T x = exponent<T>(r, m.front);
-    m.e = Num<T>::exp_begin(x, tab);
-    return m;
-  }
-  __device__ __forceinline__ T fin(const Mid &m) const { return m.front * Num<T>::exp_end(m.e); }
-  __device__ __forceinline__ T operator()(const Row &r) const { return eval<T>(r); }
-  template <typename P>
-  __device__ __forceinline__ T operator()(P e) const { return (*this)(load(e)); }
-  static constexpr bool kPairs = true;
-  template <typename P>
-  __device__ __forceinline__ kdehip_f2 pair(P e, int RS) const {  // entries at e and e + RS
-    RowT<kdehip_f2> r;
-#pragma unroll
-    for (int d = 0; d < D; ++d) r.m[d] = kdehip_f2{load_single(e + d * 64), load_single(e + RS + d * 64)};
-    r.w = kdehip_f2{load_single(e + D * 64), load_single(e + RS + D * 64)};
-    return eval<kdehip_f2>(r);
-  }
-};
-
-// FAST: per-node bandwidths; one rsqrt instead of D divides and D logs.
-template <typename T, int D, bool MASKED, bool OFF = false>
-struct EvalFast {
-  T center[D], cov[D];
-  T xoff;
-  const double *tab;
-  uint32_t act;  // MASKED: dimensions that take part (:282); an inactive one contributes c = 1, delta = 0
-  __device__ __forceinline__ EvalFast<T, D, MASKED, true> with_offset(T o) const {
-    EvalFast<T, D, MASKED, true> e;
-#pragma unroll
-    for (int d = 0; d < D; ++d) { e.center[d] = center[d]; e.cov[d] = cov[d]; }
-    e.tab = tab; e.act = act; e.xoff = o;
-    return e;
-  }
-  template <typename V> struct RowT { V m[D], v[D], w; };
-  using Row = RowT<T>;
-  template <typename P>
-  __device__ __forceinline__ Row load(P e) const {
-    Row r;
-#pragma unroll
-    for (int d = 0; d < D; ++d) { r.m[d] = e[d * 64]; r.v[d] = e[(D + d) * 64]; }
-    r.w = e[2 * D * 64];
-    return r;
-  }
-  template <typename V>
-  __device__ __forceinline__ V exponent(const RowT<V> &row, V &front) const {
-    V c[D], d2[D];
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-      c[d] = row.v[d] + cov[d];
-      const V dl = row.m[d] - center[d];
-      d2[d] = dl * dl;
-      if constexpr (MASKED) {
-        const bool on = (act >> d) & 1u;
-        c[d] = on ? c[d] : V(1);
-        d2[d] = on ? d2[d] : V(0);
-      }
-    }
-    const V w = row.w;
-    // pre[d]*suf[d] = prod_{k != d} c[k]; P = prod_k c[k]
-    V pre[D], suf[D];
-    pre[0] = V(1);
-#pragma unroll
-    for (int d = 1; d < D; ++d) pre[d] = pre[d - 1] * c[d - 1];
-    suf[D - 1] = V(1);
-#pragma unroll
-    for (int d = D - 2; d >= 0; --d) suf[d] = suf[d + 1] * c[d + 1];
-    const V prod = pre[D - 1] * c[D - 1];
-    V num = V(0);
-#pragma unroll
-    for (int d = 0; d < D; ++d) num = Num<V>::fma(d2[d], pre[d] * suf[d], num);
-    const V r = Num<V>::rsqrt(prod);
-    const V q = num * r * r;  // = sum_d delta_d^2 / c_d
-    front = w * r;
-    if constexpr (OFF)
-      return clamp_hi(Num<V>::fma(q, V(T(-0.5) * T(Num<T>::kExpArg)), V(xoff)), V(T(126)));
-    else
-      return V(T(-0.5) * T(Num<T>::kExpArg)) * q;
-  }
-  template <typename V>
-  __device__ __forceinline__ V eval(const RowT<V> &row) const {
-    V front;
-    const V x = exponent<V>(row, front);
-    return front * Num<V>::exp_fast(x, tab);
-  }
-  struct Mid { T front; typename Num<T>::ExpMid e; };
-  __device__ __forceinline__ Mid arg(const Row &row) const {
-    Mid m;
-    const T x = exponent<T>(row, m.front);
-    m.e = Num<T>::exp_begin(x, tab);
-    return m;
-  }
-  __device__ __forceinline__ T fin(const Mid &m) const { return m.front * Num<T>::exp_end(m.e); }
-  __device__ __forceinline__ T operator()(const Row &row) const { return eval<T>(row); }
-  template <typename P>
-  __device__ __forceinline__ T operator()(P e) const { return (*this)(load(e)); }
-  static constexpr bool kPairs = true;
-  template <typename P>
-  __device__ __forceinline__ kdehip_f2 pair(P e, int RS) const {  // entries at e and e + RS
-    RowT<kdehip_f2> r;
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-      r.m[d] = kdehip_f2{load_single(e + d * 64), load_single(e + RS + d * 64)};
-      r.v[d] = kdehip_f2{load_single(e + (D + d) * 64), load_single(e + RS + (D + d) * 64)};
-    }
-    r.w = kdehip_f2{load_single(e + 2 * D * 64), load_single(e + RS + 2 * D * 64)};
-    return eval<kdehip_f2>(r);
-  }
-};
-
-// GENERIC: literally the reference's accumulation (:280-303) incl. inactive dimensions.
-template <typename T, int D, bool OFF = false>
-struct EvalGeneric {
-  T center[D], cov[D];
-  T xoff;
-  uint32_t act;
-  __device__ __forceinline__ EvalGeneric<T, D, true> with_offset(T o) const {
-    EvalGeneric<T, D, true> e;
-#pragma unroll
-    for (int d = 0; d < D; ++d) { e.center[d] = center[d]; e.cov[d] = cov[d]; }
-    e.act = act; e.xoff = o;
-    return e;
-  }
-  struct Row { T m[D], v[D], w; };
-  template <typename P>
-  __device__ __forceinline__ Row load(P e) const {
-    Row r;
-#pragma unroll
-    for (int d = 0; d < D; ++d) { r.m[d] = e[d * 64]; r.v[d] = e[(D + d) * 64]; }
-    r.w = e[2 * D * 64];
-    return r;
-  }
-  __device__ __forceinline__ T operator()(const Row &row) const {
-    T acc = T(0);
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-      if ((act >> d) & 1u) {
-        const T c = row.v[d] + cov[d];
-        const T dl = row.m[d] - center[d];
-        const T distr = (dl * dl) / c;
-        if (distr == distr) {
-          acc += distr;
-          acc += Num<T>::log(c);
-        }
-      }
-    }
-    T arg = T(-0.5) * acc;
-    if constexpr (OFF) {  // xoff binades = xoff * ln 2 in the natural exponent; stay below exp's overflow
-      arg = arg + xoff * T(0.6931471805599453);
-      arg = clamp_hi(arg, T(87));
-    }
-    const T p = Num<T>::exp(arg) * row.w;
-    return (p != p) ? T(0) : p;
-  }
-  template <typename P>
-  __device__ __forceinline__ T operator()(P e) const { return (*this)(load(e)); }
-  struct Mid { T p; };
-  __device__ __forceinline__ Mid arg(const Row &row) const { return {(*this)(row)}; }
-  __device__ __forceinline__ T fin(const Mid &m) const { return m.p; }
-  static constexpr bool kPairs = false;
-};
-
-// ---- one categorical label draw over a frontier -------------------------------------------------
-// Evaluates every node of the frontier with `ev`, and returns the tile position (row*64 + lane) of
-// the entry selected by the uniform draw `u`: the first z with u <= cdf[z], else the last
-// (selectLabelOnLevel :330-351 applied to the CDF of makeFasterSampleIndex! :318-325).
-// `rows` points at row 0, field 0, lane 0 of the tile (LDS or global pointer type P).
-// pass 1 over rows held at `rows` (LDS or global): the lane's private sum over its contiguous entries
-template <typename P> constexpr bool kIsLdsPtr = false;
-template <typename T> constexpr bool kIsLdsPtr<const __attribute__((address_space(3))) T *> = true;
-
-template <typename T, typename P, typename Eval, bool PREFETCH = true>
-__device__ __forceinline__ T lane_sum_rows(P rows, int nrows, int RS, int lane, const Eval &ev) {
-  constexpr bool kUsePairs = sizeof(T) == 4 && Eval::kPairs;
-  if constexpr (kUsePairs) {
-    // fp32: two rows per trip through the packed-math pipe (their 2F loads are in flight together)
-    kdehip_f2 S2 = {0.0f, 0.0f};
-    P e2 = rows + lane;
-    int i2 = 0;
-    for (; i2 + 2 <= nrows; i2 += 2, e2 += 2 * RS) S2 += ev.pair(e2, RS);
-    T Sp = S2.x + S2.y;
-    if (i2 < nrows) Sp += ev(e2);
-    return Sp;
-  }
-  if constexpr (!PREFETCH) {
-    T S0 = T(0);
-    P e0 = rows + lane;
-#pragma unroll 2
-    for (int i = 0; i < nrows; ++i, e0 += RS) S0 += ev(e0);
-    return S0;
-  }
-  // software pipelined, two rows per trip with ping-pong register sets (no copies): the fields of the
-  // next row are requested before the current row is evaluated, so the LDS (or L2) round trip overlaps
-  // ~40-100 fp64 instructions instead of stalling in front of each of them.
-  T S = T(0);
-  P e = rows + lane;
-  typename Eval::Row ra = ev.load(e);
-  // LDS tiles: have row 0 landed before the loop, otherwise the compiler's wait-count bookkeeping merges
-  // "row 0 pending" into the loop head and waits for every prefetch right after issuing it
-  if constexpr (kIsLdsPtr<P>) __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) only
-  int i = 0;
-  for (; i + 2 <= nrows; i += 2) {
-    const typename Eval::Row rb = ev.load(e + RS);  // row i+1
-    __builtin_amdgcn_sched_barrier(0);              // keep the requests above the arithmetic
-    const typename Eval::Mid ma = ev.arg(ra);       // ... ends by issuing row i's exp table lookup
-    __builtin_amdgcn_sched_barrier(0);
-    const typename Eval::Mid mb = ev.arg(rb);       // hides the latency of row i's lookup
-    e += (i + 2 < nrows) ? 2 * RS : RS;             // row i+2, or row i+1 again (never past the tile)
-    ra = ev.load(e);
-    __builtin_amdgcn_sched_barrier(0);
-    S += ev.fin(ma);
-    S += ev.fin(mb);
-  }
-  if (i < nrows) S += ev(ra);
-  return S;
-}
-
-// Uniform draws over the frontier that replaced an underflowed conditional (:311-315) are counted in the 8 bytes
-// in front of the plan's level table (a layout contract with product.hip: the table's address is live in scalar
-// registers anyway, so the counter costs the common path nothing): how tests compare the fp32 path's fallback
-// behaviour with fp64's and the oracle's.  `fb` = the level table's address.
-__device__ __forceinline__ void count_fallback(const void *fb, int lane) {
-  if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(const_cast<void *>(fb)) - 1, 1ull);
-}
-
-template <typename T, typename P, typename Eval>
-__device__ __forceinline__ int select_from_scan(T incl, T S, P rows, const LevelDesc &ds, int lane, const Eval &ev,
-                                                double u, T thr, bool final, const void *fb
-#ifdef KDEHIP_STAMPS
-                                                , unsigned long long *stamp_acc, bool stamp_on
-#endif
-);
-
-// Selection from the lane sums S: wavefront scan, winning lane, then pass 2 over the winning lane's
-// block read through `rows` (row 0, field 0, lane 0 of the whole tile; LDS or global).
-template <typename T, typename P, typename Eval>
-__device__ __forceinline__ int select_label(T S, P rows, const LevelDesc &ds, int lane, const Eval &ev, double u,
-                                            T thr, bool final, const void *fb
-#ifdef KDEHIP_STAMPS
-                                            , unsigned long long *stamp_acc, bool stamp_on
-#endif
-) {
-  return select_from_scan<T, P>(wave_inclusive_scan(S), S, rows, ds, lane, ev, u, thr, final, fb KSTAMP_ARGS);
-}
-
-// The selection proper, from the inclusive wavefront scan `incl` of the lane sums S.  Also entered
-// directly with a scan that was computed ahead of time (conditional tables, single-row frontiers).
-// A total below `thr` (or NaN) is the reference's underflow case: with `final` the uniform fallback is taken,
-// otherwise -1 is returned and the caller repeats the evaluation with raised exponents (fp32 only).
-template <typename T, typename P, typename Eval>
-__device__ __forceinline__ int select_from_scan(T incl, T S, P rows, const LevelDesc &ds, int lane, const Eval &ev,
-                                                double u, T thr, bool final, const void *fb
-#ifdef KDEHIP_STAMPS
-                                                , unsigned long long *stamp_acc, bool stamp_on
-#endif
-) {
-  const int n = ds.n, B = ds.B, F = ds.F;
-  const int RS = F * 64 + 1;
-  KSTAMP(tp1);
-  const T total = lane_read(incl, 63);
-
-  if (!(total >= thr)) {  // also taken when every weight is NaN (:302 zeroes them all)
-    if (!final) return -1;
-    count_fallback(fb, lane);
-    // "stick with selection of others": uniform over the frontier (:311-315); with a zero/NaN
-    // last weight the reference's CDF is all-NaN and the last entry is taken.
-    const int zl = n - 1;
-    const T wl = rows[(zl % B) * RS + (F - 1) * 64 + zl / B];
-    int z = n - 1;
-    if (wl > T(0)) {
-      z = static_cast<int>(ceil(u * static_cast<double>(n))) - 1;
-      z = z < 0 ? 0 : (z > n - 1 ? n - 1 : z);
-    }
-    return (z % B) * 64 + z / B;
-  }
-
-  const T target = static_cast<T>(u) * total;
-  const unsigned long long hit = __ballot(target <= incl);
-  const int last_lane = ds.last_lane;
-  int lstar = hit ? (__ffsll(hit) - 1) : last_lane;
-  if (lstar > last_lane) lstar = last_lane;
-  KSTAMP(tp2);
-  KSTAMP_ADD(3, tp1, tp2);
-  if (B == 1) return lstar;
-
-  // pass 2: narrow inside the winning lane's block until a single node is left
-  T base = lane_read(incl - S, lstar);  // exclusive prefix of the block
-  int r0 = 0;
-  int len = n - lstar * B;
-  if (len > B) len = B;
-  P col = rows + lstar;
-  while (len > 64) {  // only for frontiers beyond 4096 nodes
-    const int b2 = (len + 63) / 64;
-    T S2 = T(0);
-    for (int i = 0; i < b2; ++i) {
-      const int r = lane * b2 + i;
-      if (r < len) S2 += ev(col + (r0 + r) * RS);
-    }
-    const T inc2 = wave_inclusive_scan(S2);
-    const unsigned long long h2 = __ballot(target <= base + inc2);
-    const int lastl = (len - 1) / b2;
-    int l2 = h2 ? (__ffsll(h2) - 1) : lastl;
-    if (l2 > lastl) l2 = lastl;
-    base += lane_read(inc2 - S2, l2);
-    r0 += l2 * b2;
-    len = (len - l2 * b2 < b2) ? (len - l2 * b2) : b2;
-  }
-  T p2 = T(0);
-  if (lane < len) p2 = ev(col + (r0 + lane) * RS);
-  const T inc3 = wave_inclusive_scan(p2);
-  const unsigned long long h3 = __ballot((target <= base + inc3) && (lane < len));
-  const int istar = h3 ? (__ffsll(h3) - 1) : (len - 1);
-  KSTAMP(tp3);
-  KSTAMP_ADD(4, tp2, tp3);
-  return (r0 + istar) * 64 + lstar;
-}
-
-// whole tile readable through one pointer (resident / streamed LDS image, or global memory)
-// Frontiers of 2 .. BMAX rows per lane whose tile is in LDS, in builds with registers to spare: the lane keeps
-// the BMAX values of its block from the first pass, so the second pass needs no re-evaluation, no LDS gather
-// and no second wavefront scan -- every lane forms the running sums of its own block (the same sequential
-// sums the first pass accumulates), finds the first row that reaches the target, and the answer is read from
-// the winning lane.  (Rows beyond B are padding of weight 0 in the tile; they are not even evaluated.)
-template <typename T, typename P, typename Eval, int BMAX>
-__device__ __forceinline__ int draw_label_kept(P rows, const LevelDesc &ds, int lane, const Eval &ev, double u,
-                                               const void *fb) {
-  const int n = ds.n, B = ds.B, F = ds.F;
-  const int RS = F * 64 + 1;
-  T v[BMAX];
-  P e = rows + lane;
-  // first pass: the two-rows-per-trip schedule of lane_sum_rows (next row requested early, the two rows
-  // interleaved around their exp table lookups), fully unrolled so that the values stay in registers
-  typename Eval::Row ra = ev.load(e);
-#pragma unroll
-  for (int i = 0; i < BMAX; i += 2) {
-    if (i + 2 <= B) {  // wave-uniform
-      const typename Eval::Row rb = ev.load(e + (i + 1) * RS);
-      __builtin_amdgcn_sched_barrier(0);
-      const typename Eval::Mid ma = ev.arg(ra);
-      if (i + 2 < B) ra = ev.load(e + (i + 2) * RS);
-      __builtin_amdgcn_sched_barrier(0);
-      const typename Eval::Mid mb = ev.arg(rb);
-      __builtin_amdgcn_sched_barrier(0);
-      v[i] = ev.fin(ma);
-      v[i + 1] = ev.fin(mb);
-    } else if (i < B) {
-      v[i] = ev(ra);
-      v[i + 1] = T(0);
-    } else {
-      v[i] = T(0);
-      v[i + 1] = T(0);
-    }
-  }
-  T S = T(0);
-#pragma unroll
-  for (int i = 0; i < BMAX; ++i) S += v[i];  // (+0 for the rows beyond B: the first pass's sequential sum)
-  const T incl = wave_inclusive_scan(S);
-  const T total = lane_read(incl, 63);
-  if (!(total >= Num<T>::tiny_total())) {  // uniform fallback (:311-315), as in select_from_scan
-    count_fallback(fb, lane);
-    const int zl = n - 1;
-    const T wl = rows[(zl % B) * RS + (F - 1) * 64 + zl / B];
-    int z = n - 1;
-    if (wl > T(0)) {
-      z = static_cast<int>(ceil(u * static_cast<double>(n))) - 1;
-      z = z < 0 ? 0 : (z > n - 1 ? n - 1 : z);
-    }
-    return (z % B) * 64 + z / B;
-  }
-  const T target = static_cast<T>(u) * total;
-  const unsigned long long hit = __ballot(target <= incl);
-  const int last_lane = ds.last_lane;
-  int lstar = hit ? (__ffsll(hit) - 1) : last_lane;
-  if (lstar > last_lane) lstar = last_lane;
-  // second pass, in every lane on its own block: first row r with target <= exclusive prefix + v[0..r]
-  // (the running sums never decrease, so the first row that reaches the target = the number of rows below it)
-  T run = incl - S;
-  int first = 0;
-#pragma unroll
-  for (int r = 0; r < BMAX; ++r) {
-    run += v[r];
-    first += (target <= run) ? 0 : 1;
-  }
-  int len = n - lstar * B;
-  if (len > B) len = B;
-  int istar = __builtin_amdgcn_readlane(first, lstar);
-  if (istar > len - 1) istar = len - 1;  // no row reached the target (rounding), or only padding rows did
-  return istar * 64 + lstar;
-}
-
-// fp32: the evaluation is repeated with every exponent raised by 110, 220, 330 binades while the sum stays below
-// 2^-100 (Num<float>::tiny_total); the last attempt applies the reference's threshold.  Rare (densities far
-// apart), so these passes are the plain ones: no prefetch, any readable pointer (LDS image or global memory).
-template <typename T, typename P, typename Eval>
-__device__ __forceinline__ int draw_label_raised(P rows, const LevelDesc &ds, int lane, const Eval &ev, double u,
-                                              const void *fb) {
-  int pos = -1;
-  for (int k = 1; k <= Num<T>::kOffsetSteps && pos < 0; ++k) {
-    const auto evo = ev.with_offset(T(Num<T>::kOffsetStep) * T(k));
-    const T S = lane_sum_rows<T, P, std::decay_t<decltype(evo)>, false>(rows, ds.B, ds.F * 64 + 1, lane, evo);
-    const bool final = (k == Num<T>::kOffsetSteps);
-    pos = select_from_scan<T, P>(wave_inclusive_scan(S), S, rows, ds, lane, evo, u,
-                                 final ? Num<T>::final_total() : Num<T>::tiny_total(), final, fb
-#ifdef KDEHIP_STAMPS
-                                 , nullptr, false
-#endif
-    );
-  }
-  return pos;
-}
-
-// selection from first-pass lane sums S formed at offset 0, then the raised attempts if the sum underflowed
-template <typename T, typename P, typename Eval>
-__device__ __forceinline__ int select_or_raise(T S, P rows, const LevelDesc &ds, int lane, const Eval &ev, double u,
-                                               const void *fb
-#ifdef KDEHIP_STAMPS
-                                               , unsigned long long *stamp_acc, bool stamp_on
-#endif
-) {
-  constexpr bool kOneAttempt = (Num<T>::kOffsetSteps == 0);
-  const int pos = select_label<T, P>(S, rows, ds, lane, ev, u, Num<T>::tiny_total(), kOneAttempt, fb KSTAMP_ARGS);
-  if constexpr (kOneAttempt) return pos;
-  else {
-    if (__builtin_expect(pos >= 0, 1)) return pos;
-    return draw_label_raised<T, P>(rows, ds, lane, ev, u, fb);
-  }
-}
-
-template <typename T, typename P, bool PREFETCH, bool kKeptRows, typename Eval>
-__device__ __forceinline__ int draw_label(P rows, const LevelDesc &ds, int lane, const Eval &ev, double u,
-                                          const void *fb
-#ifdef KDEHIP_STAMPS
-                                          , unsigned long long *stamp_acc, bool stamp_on
-#endif
-) {
-#if !defined(KDEHIP_STAMPS) && !defined(KDEHIP_NO_KEPT)
-  // PREFETCH marks the builds with registers to spare (see kPrefetchRows); fp32 has its packed-pair first pass
-  if constexpr (PREFETCH && kIsLdsPtr<P> && sizeof(T) == 8 && kKeptRows) {
-    if (ds.B > 1 && ds.B <= 4) return draw_label_kept<T, P, Eval, 4>(rows, ds, lane, ev, u, fb);
-    if (ds.B > 4 && ds.B <= 8) return draw_label_kept<T, P, Eval, 8>(rows, ds, lane, ev, u, fb);
-  }
-#endif
-  KSTAMP(tp0);
-  const T S = lane_sum_rows<T, P, Eval, PREFETCH>(rows, ds.B, ds.F * 64 + 1, lane, ev);
-  KSTAMP(tp1);
-  KSTAMP_ADD(2, tp0, tp1);
-  return select_or_raise<T, P>(S, rows, ds, lane, ev, u, fb KSTAMP_ARGS);
-}
-
-// ---- the sampler ----------------------------------------------------------------------------------
-
-// LDS of one workgroup (ONE object, so the compiler keeps direct-to-LDS loads asynchronous):
-//   [exp table 256 B][per-wave chain state][tile pool kLdsPoolBytes]
-template <typename T, int D, int WAVES>
-struct LdsLayout {
-  static constexpr int kStatePerWave = (2 * KDEHIP_MAX_DENS * D) * int(sizeof(T)) + KDEHIP_MAX_DENS * int(sizeof(int));
-  static constexpr int kStateOff = 256;
-  static constexpr int kPoolOff = (kStateOff + WAVES * kStatePerWave + 1023) / 1024 * 1024;
-  static constexpr int kBytes = kPoolOff + kLdsPoolBytes;
-  static_assert(kBytes <= 160 * 1024, "LDS budget of one CU exceeded");
-};
-
-template <typename T> using LdsPtr = const __attribute__((address_space(3))) T *;
-// read-only, wave-uniform tables are read through the constant address space so that the compiler
-// uses scalar loads (s_load_*, lgkmcnt) and never drains the direct-to-LDS copies in flight (vmcnt)
-typedef int kdehip_v16i __attribute__((ext_vector_type(16)));
-struct LevelTable {
-  const __attribute__((address_space(4))) kdehip_v16i *p;
-  __device__ __forceinline__ LevelDesc operator[](int idx) const {
-    const kdehip_v16i raw = p[idx];  // one s_load_dwordx16
-    LevelDesc d;
-    __builtin_memcpy(&d, &raw, sizeof(LevelDesc));
-    return d;
-  }
-};
-// conditional-table descriptors (32 B each) through the constant address space, like LevelTable
-typedef int kdehip_v8i __attribute__((ext_vector_type(8)));
-struct TabTable {
-  const __attribute__((address_space(4))) kdehip_v8i *p;
-  __device__ __forceinline__ TabDesc operator[](int idx) const {
-    const kdehip_v8i raw = p[idx];  // one s_load_dwordx8
-    TabDesc d;
-    __builtin_memcpy(&d, &raw, sizeof(TabDesc));
-    return d;
-  }
-};
-
-using LdsVoidPtr = __attribute__((address_space(3))) void *;
-
-// Cooperative, asynchronous copy of one tile image (bytes is a multiple of 1 KiB) into the pool: every
-// wavefront issues direct-to-LDS loads for its share of 1-KiB pieces (16 bytes per lane).
-// The MUBUF form (buffer_load_dwordx4 ... lds) is used rather than global_load_lds: the compiler counts the
-// FLAT-encoded form against lgkmcnt as well and, while such a copy is in flight, turns EVERY LDS wait into
-// s_waitcnt lgkmcnt(0) -- which would serialise the row prefetches of the first pass behind each other.
-// Both forms are tracked by vmcnt in hardware.
-template <int WAVES>
-__device__ __forceinline__ void stage_tile(const unsigned char *__restrict__ src, unsigned char *dst,
-                                           int bytes, int wave, int lane) {
-  // raw buffer over exactly this image: base = src, stride 0, num_records = bytes, gfx9 dword 3
-  const __amdgpu_buffer_rsrc_t rsrc =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(src), 0, bytes, 0x00020000);
-  const int pieces = bytes >> 10;
-  for (int c = wave; c < pieces; c += WAVES)
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LdsVoidPtr)(dst + (c << 10)), 16, lane << 4, c << 10, 0, 0);
-}
 
 template <typename T, int D, int MODE, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan, RunArgs a) {
@@ -1238,25 +521,7 @@ static int launch_waves(const PlanDev &plan, const RunArgs &args, hipStream_t st
 template <typename T, int D, int MODE>
 static int launch_one(const PlanDev &plan, const RunArgs &args, hipStream_t stream) {
   if (args.Np <= 0) return KDEHIP_OK;
-  // Chains per workgroup (= wavefronts per CU, one workgroup per CU at a time): fewer wavefronts per SIMD run
-  // each chain faster, more hide each other's latencies.  Pick the width with the smallest estimated time
-  // rounds(width) * cost(width); the relative costs of one round are measured ones (config 3: 0.59, 0.79,
-  // 1.10, 1.37 ms for 4, 8, 12, 16 chains per workgroup) and differ little between shapes.
-  const int v = args.variant % 1000;
-  const int64_t cus = device_cu_count();
-  int waves = 16;
-  if (v == 8 || v == 12 || v == 16) waves = v;
-  else if (v == 2) waves = 4;
-  else {
-    static const int kWidth[4] = {4, 8, 12, 16};
-    static const double kCost[4] = {1.0, 1.34, 1.86, 2.31};
-    double best = 0.0;
-    for (int i = 0; i < 4; ++i) {
-      const int64_t wgs = (args.Np + kWidth[i] - 1) / kWidth[i];
-      const double t = static_cast<double>((wgs + cus - 1) / cus) * kCost[i];
-      if (i == 0 || t < best) { best = t; waves = kWidth[i]; }
-    }
-  }
+  const int waves = chains_per_workgroup(args.Np, args.variant);
   if (waves == 16) launch_waves<T, D, MODE, 16>(plan, args, stream);
   else if (waves == 12) launch_waves<T, D, MODE, 12>(plan, args, stream);
   else if (waves == 8) launch_waves<T, D, MODE, 8>(plan, args, stream);

@@ -1,0 +1,448 @@
+// gibbs_lean.hip -- the multiscale-Gibbs product sampler for products of 2..4 densities with every dimension
+// active (the common case: BASELINE configs 1, 2, 3 and 5), gfx950 only.
+//
+// Same algorithm, tiles, staging modes, conditional tables and random streams as gibbs_kernel.hip (the kernel
+// for any density count / arithmetic mode; read its header first) -- what differs is where a chain keeps its
+// state and how much bookkeeping a draw step carries:
+//   * the density count M is a template parameter and the sweep over densities is unrolled, so "the currently
+//     selected kernel of density j" (1/variance and mean/variance per dimension, lanes = dimensions) lives in
+//     REGISTERS indexed at compile time instead of in per-wavefront LDS: the leave-one-out Gaussian product
+//     (gaussianProductMeanCov!, src/MSGibbs01.jl:176-216) is M-1 register adds, adopting a drawn kernel
+//     (updateGlbParticlesVariance!, :89-115) is one LDS gather + reciprocal, and no LDS round trip or
+//     wavefront fence separates consecutive steps;
+//   * the M level descriptors are read once per level (scalar registers) instead of once per step;
+//   * the D*(L+1) normal deviates of a chain are produced (Philox) or fetched (caller's randN) once, lane-parallel,
+//     into a per-wavefront LDS strip, instead of D at a time at every level.
+// Results: labels identical to gibbs_kernel.hip and to the oracle, points bit-identical to gibbs_kernel.hip
+// (same reciprocal / product forms) -- tested (tests/test_gpu_lean.py).
+#define KDEHIP_EXP256 1
+#include "gibbs_device.hpp"
+
+namespace kdehip {
+
+template <int I> using IC = std::integral_constant<int, I>;
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+  if constexpr (I < N) {
+    f(IC<I>{});
+    static_for<N, I + 1>(f);
+  }
+}
+
+constexpr int kLeanMaxNormals = 128;  // D*(L+1) normals of a chain kept in LDS (1 KiB per wavefront)
+
+// A scalar copied through an opaque move: the copy is a register of its own.  The level descriptors arrive as one
+// 16-dword scalar load; used directly, the register allocator treats the 16 registers as one unit and, under
+// pressure, spills and reloads ALL of them around every use of one field (16 v_readlane per reload, several
+// reloads per step).  The few fields a step needs are detached from that unit here, once per level.
+__device__ __forceinline__ int scalar_copy(int x) {
+  int y;
+  asm("s_mov_b32 %0, %1" : "=s"(y) : "s"(x));
+  return y;
+}
+
+// One density's tile on the current level: what the steps of a level need, as independent scalars.
+template <int D>
+struct LeanTile {
+  int n;            // frontier size
+  int flags;        // last_lane | uniform_bw << 8
+  int lds_off;      // byte offset of the image in the LDS pool (resident mode)
+  int stage_bytes;  // bytes of the image (streamed mode)
+  int chunk_rows;   // rows per chunk (chunked mode)
+  int hdr_lo, hdr_hi;  // element offset of the tile header in the plan's data
+  // the members the draw functions of gibbs_device.hpp read
+  int B, F, last_lane;
+  int uniform_bw;
+  __device__ __forceinline__ int64_t hdr_off() const {
+    return (static_cast<int64_t>(hdr_hi) << 32) | static_cast<uint32_t>(hdr_lo);
+  }
+  __device__ __forceinline__ void load(const LevelDesc &d) {
+    n = scalar_copy(d.n);
+    flags = scalar_copy(d.last_lane | (d.uniform_bw << 8));
+    lds_off = scalar_copy(d.lds_off);
+    stage_bytes = scalar_copy(d.stage_bytes);
+    chunk_rows = scalar_copy(d.chunk_rows);
+    hdr_lo = scalar_copy(static_cast<int>(d.hdr_off));
+    hdr_hi = scalar_copy(static_cast<int>(d.hdr_off >> 32));
+    B = (n + 63) >> 6;
+    last_lane = flags & 0xFF;
+    uniform_bw = flags >> 8;
+    F = uniform_bw ? D + 1 : 2 * D + 1;
+  }
+};
+
+template <typename T, int D, int M, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan, RunArgs a) {
+  constexpr bool kPrefetchRows = (WAVES <= 12) || sizeof(T) == 4 || D <= 4;  // as in gibbs_kernel.hip
+  constexpr bool kKeptRows = (WAVES <= 8);
+  // LDS: [exp table 2 KiB][normals: WAVES x 1 KiB][uniforms: WAVES x 1 KiB][tile pool]
+  constexpr int kNormOff = 2048;
+  constexpr int kUnifOff = kNormOff + WAVES * kLeanMaxNormals * 8;
+  constexpr int kPoolOff = kUnifOff + WAVES * 1024;
+  static_assert(kPoolOff + kLdsPoolBytes <= 160 * 1024, "LDS budget of one CU exceeded");
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[kPoolOff + kLdsPoolBytes];
+
+  double *sExpTab = reinterpret_cast<double *>(smem);
+  if (threadIdx.x < 256) sExpTab[threadIdx.x] = kExp2Tab256[threadIdx.x];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  int64_t s = static_cast<int64_t>(blockIdx.x) * WAVES + wave;
+  const bool live = s < a.Np;  // surplus wavefronts of the last workgroup replay the last chain and store nothing
+  if (!live) s = a.Np - 1;
+  const uint64_t gs = static_cast<uint64_t>(a.sample_offset + s);
+
+  const int L = plan.L;
+  const T *__restrict__ data = static_cast<const T *>(plan.data);
+  const LevelTable levels{(const __attribute__((address_space(4))) kdehip_v16i *)(plan.levels)};
+  unsigned char *pool = smem + kPoolOff;
+  const int dl = lane < D ? lane : D - 1;  // this lane's dimension in the "lanes = dimensions" phases
+  const int vlev = a.variant % 1000;
+
+  // ---- the chain's normal deviates, once (samplePoint! consumes D per level + D at the end, :440-463) ----
+  double *sNorm = reinterpret_cast<double *>(smem + kNormOff) + wave * kLeanMaxNormals;
+  const int R = D * (L + 1);
+  for (int r = lane; r < R; r += 64)
+    sNorm[r] = a.rng_philox ? philox_normal(a.seed, gs, static_cast<uint32_t>(r)) : a.randN[s * a.R + r];
+  __syncthreads();  // (exp table; the strip itself is only read by its own wavefront)
+
+  // ---- chain state: selected kernel of every density, lanes = dimensions ----
+  T lam[M], lmu[M];  // 1/variance and mean/variance
+  int psel[M];       // tile position of the selected entry (wave-uniform)
+
+  // adopt entry `pos` of the tile whose header is at `hdr` (LDS or global) as density j's kernel
+  auto adopt = [&](auto jc, const auto &ds, auto hdr, int pos) {
+    constexpr int j = decltype(jc)::value;
+    auto e = hdr + kTileHeader + (pos >> 6) * (ds.F * 64 + 1) + (pos & 63);
+    const T mu = e[dl * 64];
+    const T var = ds.uniform_bw ? hdr[dl] : e[(D + dl) * 64];
+    const T l = fast_rcp(var);
+    lam[j] = l;
+    lmu[j] = mu * l;
+    psel[j] = pos;
+  };
+  // Gaussian product of the selected kernels without density `skip` (-1: all) for this lane's dimension, the
+  // reference's summation order (:199-213)
+  auto product = [&](auto skipc, T &mean, T &cov) {
+    constexpr int skip = decltype(skipc)::value;
+    T ls = T(0), ms = T(0);
+    static_for<M>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      if constexpr (k != skip) { ls += lam[k]; ms += lmu[k]; }
+    });
+    cov = fast_rcp(ls);
+    mean = cov * ms;
+  };
+
+  // One label draw on level descriptor ds against the per-dimension (mean, cov) held by the dimension lanes
+  // (makeFasterSampleIndex! + selectLabelOnLevel, :250-351); `run(ev)` gets the evaluator.
+  auto draw = [&](const auto &ds, auto hdr, T mean, T cov, auto &&run) -> int {
+    if (ds.uniform_bw) {
+      EvalUniform<T, D> ev;
+      ev.tab = sExpTab;
+      const T c = hdr[dl] + cov;
+      const T ni = (T(-0.5) * T(Num<T>::kExpArg)) * fast_rcp(c);
+      T Pr = T(1);
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        ev.center[d] = lane_read(mean, d);
+        ev.ninv[d] = lane_read(ni, d);
+        Pr *= lane_read(c, d);
+      }
+      ev.scale = Num<T>::rsqrt(Pr);
+      return run(ev);
+    }
+    EvalFast<T, D, false> ev;
+    ev.tab = sExpTab;
+    ev.act = 0;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      ev.center[d] = lane_read(mean, d);
+      ev.cov[d] = lane_read(cov, d);
+    }
+    return run(ev);
+  };
+
+  // ---- uniform draws: 128 at a time across the lanes, handed out with v_readlane (as gibbs_kernel.hip) ----
+  uint32_t c = static_cast<uint32_t>(M);  // select call index; the M init calls read nothing (:477-497)
+  uint32_t ubatch = 0xFFFFFFFFu;
+  double *sUnif = reinterpret_cast<double *>(smem + kUnifOff) + wave * 128;  // this wavefront's current 128 uniforms
+  auto next_uniform = [&]() -> double {
+    const uint32_t b = c >> 7;
+    if (b != ubatch) {  // lane ln produces uniforms 128*b + 2*ln and + 2*ln+1 (one Philox block, or two stream elements)
+      ubatch = b;
+      double u_even, u_odd;
+      if (a.rng_philox) {
+        const Philox4 r = philox_block(a.seed, gs, b * 64u + static_cast<uint32_t>(lane), 0u);
+        u_even = bits_to_unit(r.v[0], r.v[1]);
+        u_odd = bits_to_unit(r.v[2], r.v[3]);
+      } else {  // element i of the sample's slice feeds call i+1
+        const int64_t i0 = s * a.K + static_cast<int64_t>(b) * 128 + 2 * lane - 1;
+        u_even = (i0 >= 0 && i0 < a.nU) ? a.randU[i0] : 0.5;
+        u_odd = (i0 + 1 < a.nU) ? a.randU[i0 + 1] : 0.5;
+      }
+      wave_sync();
+      sUnif[2 * lane] = u_even;
+      sUnif[2 * lane + 1] = u_odd;
+      wave_sync();
+    }
+    const double u = sUnif[c & 127u];  // one broadcast read: the value is the same in every lane
+    ++c;
+    return u;
+  };
+
+  // ---- init: frontier = {root}, label = root (levelInit!/initIndices!/calcIndices!, :587-589) ----
+  static_for<M>([&](auto jc) {
+    const LevelDesc ds = levels[decltype(jc)::value * (L + 1)];
+    adopt(jc, ds, data + ds.hdr_off, 0);
+  });
+
+  const TabTable tabs{(const __attribute__((address_space(4))) kdehip_v8i *)(plan.tabdesc)};
+  const T *tables = static_cast<const T *>(plan.tables);
+  const int Lt = (vlev == 1 || vlev == 4 || !a.use_tables) ? 0 : plan.Lt;
+
+  // one (pass, density) step on a tile readable through one pointer: leave-one-out product (sweeps) or the point
+  // just drawn (sampleIndices! pass, :364-385), the draw, and the new kernel
+  auto step = [&](auto jc, const auto &ds, auto hdr, bool first, T x) {
+    T mean = x, cov = T(0);
+    if (!first) product(jc, mean, cov);
+    const double u = next_uniform();
+    auto rows = hdr + kTileHeader;
+    using P = decltype(rows);
+    const int pos = __builtin_amdgcn_readfirstlane(draw(ds, hdr, mean, cov, [&](const auto &ev) {
+      return draw_label<T, P, kPrefetchRows, kKeptRows>(rows, ds, lane, ev, u, plan.levels);
+    }));
+    adopt(jc, ds, hdr, pos);
+  };
+
+  int gchunk = 0;  // workgroup-wide running chunk counter of the chunked mode (selects the pool half)
+  auto stage_chunk = [&](const auto &ds, int r0, int half) {
+    const int RS = ds.F * 64 + 1, rc = ds.chunk_rows;
+    const int nrows = (ds.B - r0 < rc) ? (ds.B - r0) : rc;
+    const int bytes = (nrows * RS * int(sizeof(T)) + 1023) & ~1023;
+    stage_tile<WAVES>(reinterpret_cast<const unsigned char *>(data + ds.hdr_off() + kTileHeader + static_cast<int64_t>(r0) * RS),
+                      pool + half * (kLdsPoolBytes / 2), bytes, wave, lane);
+  };
+
+#ifdef KDEHIP_EXPERIMENTS  // diagnostic builds: variant 100+k stops after level k (scripts/level_profile.sh)
+  const int Lrun = (vlev >= 100 && vlev - 100 < L) ? vlev - 100 : L;
+#else
+  const int Lrun = L;
+#endif
+  for (int l = 1; l <= Lrun; ++l) {
+    // samplePoint! (:440-463): x = mean + sqrt(cov) * randn, all densities included
+    T x;
+    {
+      T mean, cov;
+      product(IC<-1>{}, mean, cov);
+      x = mean + Num<T>::sqrt(cov) * static_cast<T>(sNorm[(l - 1) * D + dl]);
+    }
+    LeanTile<D> dsc[M];
+    int level_mode = 0;
+    static_for<M>([&](auto jc) {
+      const LevelDesc d = levels[decltype(jc)::value * (L + 1) + l];
+      dsc[decltype(jc)::value].load(d);
+      if constexpr (decltype(jc)::value == 0) level_mode = scalar_copy(d.stage_mode);
+    });
+    const int mode = vlev == 1 ? int(kStageGlobal) : level_mode;
+    const bool tabulated = (l <= Lt);
+    const int npass = tabulated ? 1 : a.Niter + 1;  // tabulated levels: only the sampleIndices! pass runs here
+
+    if (mode == kStageResident) {
+      __syncthreads();  // every wavefront is done reading the previous level's images
+      static_for<M>([&](auto jc) {
+        const LeanTile<D> &ds = dsc[decltype(jc)::value];
+        stage_tile<WAVES>(reinterpret_cast<const unsigned char *>(data + ds.hdr_off()), pool + ds.lds_off, ds.stage_bytes, wave, lane);
+      });
+      __syncthreads();
+      for (int p = 0; p < npass; ++p)
+        static_for<M>([&](auto jc) {
+          const LeanTile<D> &ds = dsc[decltype(jc)::value];
+          step(jc, ds, (LdsPtr<T>)(pool + ds.lds_off), p == 0, x);
+        });
+    } else if (mode == kStageStream) {
+      __syncthreads();
+      stage_tile<WAVES>(reinterpret_cast<const unsigned char *>(data + dsc[0].hdr_off()), pool, dsc[0].stage_bytes, wave, lane);
+      int t = 0;
+      const int nsteps = npass * M;
+      for (int p = 0; p < npass; ++p)
+        static_for<M>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          constexpr int jn = (j + 1 == M) ? 0 : j + 1;
+          const LeanTile<D> &ds = dsc[j];
+          T mean = x, cov = T(0);
+          if (p != 0) product(jc, mean, cov);
+          const double u = next_uniform();
+          // tile t has been copied by all wavefronts once everyone passes this barrier; buffer (t+1)&1 was last
+          // read in step t-1, which everyone has left -> start the next copy
+          __syncthreads();
+          if (t + 1 < nsteps)
+            stage_tile<WAVES>(reinterpret_cast<const unsigned char *>(data + dsc[jn].hdr_off()),
+                              pool + ((t + 1) & 1) * (kLdsPoolBytes / 2), dsc[jn].stage_bytes, wave, lane);
+          auto hdr = (LdsPtr<T>)(pool + (t & 1) * (kLdsPoolBytes / 2));
+          auto rows = hdr + kTileHeader;
+          const int pos = __builtin_amdgcn_readfirstlane(draw(ds, hdr, mean, cov, [&](const auto &ev) {
+            return draw_label<T, LdsPtr<T>, kPrefetchRows, kKeptRows>(rows, ds, lane, ev, u, plan.levels);
+          }));
+          adopt(jc, ds, hdr, pos);
+          ++t;
+        });
+    } else if (mode == kStageChunked) {
+      // tiles larger than half the pool: pass 1 streams the rows through the two pool halves (one barrier per
+      // chunk, the copy of chunk g+1 overlaps the evaluation of chunk g); the second pass and the new kernel are
+      // read from global memory
+      __syncthreads();
+      stage_chunk(dsc[0], 0, gchunk & 1);
+      int t = 0;
+      const int nsteps = npass * M;
+      for (int p = 0; p < npass; ++p)
+        static_for<M>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          constexpr int jn = (j + 1 == M) ? 0 : j + 1;
+          const LeanTile<D> &ds = dsc[j];
+          T mean = x, cov = T(0);
+          if (p != 0) product(jc, mean, cov);
+          const double u = next_uniform();
+          const T *hdr = data + ds.hdr_off();
+          const int pos = draw(ds, hdr, mean, cov, [&](const auto &ev) {
+            const int RS = ds.F * 64 + 1, rc = ds.chunk_rows;
+            T S = T(0);
+            for (int r0 = 0; r0 < ds.B; r0 += rc, ++gchunk) {
+              __syncthreads();  // this chunk has landed for every wavefront; the other half is free again
+              if (r0 + rc < ds.B) stage_chunk(ds, r0 + rc, (gchunk + 1) & 1);
+              else if (t + 1 < nsteps) stage_chunk(dsc[jn], 0, (gchunk + 1) & 1);
+              const int nrows = (ds.B - r0 < rc) ? (ds.B - r0) : rc;
+              S += lane_sum_rows<T, LdsPtr<T>, std::decay_t<decltype(ev)>, kPrefetchRows>(
+                  (LdsPtr<T>)(pool + (gchunk & 1) * (kLdsPoolBytes / 2)), nrows, RS, lane, ev);
+            }
+            return __builtin_amdgcn_readfirstlane(select_or_raise<T, const T *>(S, hdr + kTileHeader, ds, lane, ev, u, plan.levels));
+          });
+          adopt(jc, ds, hdr, pos);
+          ++t;
+        });
+    } else {  // kStageGlobal
+      for (int p = 0; p < npass; ++p)
+        static_for<M>([&](auto jc) {
+          const LeanTile<D> &ds = dsc[decltype(jc)::value];
+          step(jc, ds, data + ds.hdr_off(), p == 0, x);
+        });
+    }
+
+    if (tabulated) {
+      // ---- tabulated sweeps (see gibbs_kernel.hip "conditional tables"): the labels of all densities packed in
+      // one scalar word, one table row load per step, the unchanged selection ----
+      TabDesc td[M];
+      static_for<M>([&](auto jc) { td[decltype(jc)::value] = tabs[decltype(jc)::value * (L + 1) + l]; });
+      uint32_t word = 0;
+      static_for<M>([&](auto jc) { word |= static_cast<uint32_t>(psel[decltype(jc)::value]) << td[decltype(jc)::value].shift; });
+      word = __builtin_amdgcn_readfirstlane(word);
+      for (int p = 1; p <= a.Niter; ++p)
+        static_for<M>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          const TabDesc &tj = td[j];
+          const uint32_t cfg = (word & ((1u << tj.shift) - 1u)) | ((word >> (tj.shift + tj.bits)) << tj.shift);
+          const T *row = tables + tj.off + static_cast<int64_t>(cfg) * (tj.n + 1);
+          const int n = tj.n;
+          const T incl = row[lane < n ? lane : n];
+          const double u = next_uniform();
+          const T total = lane_read(incl, n < 64 ? n : 63);  // (a 64-node row: its last scan value IS the total)
+          int pos;
+          if (!(total >= Num<T>::tiny_total())) {  // uniform fallback (:311-315), rare
+            count_fallback(plan.levels, lane);
+            const LeanTile<D> &dk = dsc[j];
+            const T wl = ((LdsPtr<T>)(pool + dk.lds_off) + kTileHeader)[(dk.F - 1) * 64 + (n - 1)];
+            int z = n - 1;
+            if (wl > T(0)) {
+              z = static_cast<int>(ceil(u * static_cast<double>(n))) - 1;
+              z = z < 0 ? 0 : (z > n - 1 ? n - 1 : z);
+            }
+            pos = __builtin_amdgcn_readfirstlane(z);
+          } else {
+            const T target = static_cast<T>(u) * total;
+            unsigned long long hit = __ballot(target <= incl);
+            if (n < 64) hit &= (1ull << n) - 1ull;
+            pos = hit ? (__ffsll(hit) - 1) : (n - 1);
+          }
+          word = (word & ~(((1u << tj.bits) - 1u) << tj.shift)) | (static_cast<uint32_t>(pos) << tj.shift);
+        });
+      // the level's sweeps are over: unpack the labels and adopt the selected kernels for what follows
+      static_for<M>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        const int pk = static_cast<int>((word >> td[j].shift) & ((1u << td[j].bits) - 1u));
+        adopt(jc, dsc[j], (LdsPtr<T>)(pool + dsc[j].lds_off), pk);
+      });
+    }
+    if (a.labels && live && lane == 0) {
+      static_for<M>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        a.labels[(s * M + j) * L + (l - 1)] = plan.perm[levels[j * (L + 1) + l].perm_off + psel[j]];
+      });
+    }
+    if (l == L && live && lane == 0) {  // final labels (:612-616)
+      static_for<M>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        a.indices[s * M + j] = static_cast<int64_t>(plan.perm[levels[j * (L + 1) + l].perm_off + psel[j]]) + 1;
+      });
+    }
+  }
+
+  {  // final point (:625)
+    T mean, cov;
+    product(IC<-1>{}, mean, cov);
+    T xf = mean;
+    if (a.addEntropy) xf = mean + Num<T>::sqrt(cov) * static_cast<T>(sNorm[L * D + dl]);
+    if (live && lane < D) a.points[s * D + lane] = static_cast<double>(xf);
+  }
+}
+
+// ---- launcher --------------------------------------------------------------------------------------
+
+template <typename T, int D, int M, int WAVES>
+static void launch_lean_waves(const PlanDev &plan, const RunArgs &args, hipStream_t stream) {
+  const int64_t blocks = (args.Np + WAVES - 1) / WAVES;
+  hipLaunchKernelGGL((gibbs_lean_kernel<T, D, M, WAVES>), dim3(static_cast<unsigned>(blocks)), dim3(WAVES * 64), 0,
+                     stream, plan, args);
+}
+
+template <typename T, int D, int M>
+static int launch_lean_m(const PlanDev &plan, const RunArgs &args, hipStream_t stream) {
+  const int waves = chains_per_workgroup(args.Np, args.variant);
+  if (waves == 16) launch_lean_waves<T, D, M, 16>(plan, args, stream);
+  else if (waves == 12) launch_lean_waves<T, D, M, 12>(plan, args, stream);
+  else if (waves == 8) launch_lean_waves<T, D, M, 8>(plan, args, stream);
+  else launch_lean_waves<T, D, M, 4>(plan, args, stream);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess)
+    return set_error(KDEHIP_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString(e));
+  return KDEHIP_OK;
+}
+
+#ifndef KDEHIP_DIM
+#error "compile gibbs_lean.hip with -DKDEHIP_DIM=<1..8>"
+#endif
+#define KDEHIP_CAT2(a, b) a##b
+#define KDEHIP_CAT(a, b) KDEHIP_CAT2(a, b)
+
+// Returns kLeanNotCovered when the run is outside this kernel's domain (the caller then uses gibbs_kernel.hip).
+int KDEHIP_CAT(launch_lean_d, KDEHIP_DIM)(int precision, int mode, const PlanDev &plan, const RunArgs &args,
+                                          void *stream) {
+  constexpr int D = KDEHIP_DIM;
+  if (mode != kModeFast || args.table_build || plan.M < 2 || plan.M > 4 || D * (plan.L + 1) > kLeanMaxNormals)
+    return kLeanNotCovered;
+  if (args.Np <= 0) return KDEHIP_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const bool f64 = (precision == 64);
+#ifdef KDEHIP_LEAN_DEV  // development builds (scripts/dev_lean.sh): only the config-3 instantiation, compiles in seconds
+  if (!f64 || plan.M != 4 || chains_per_workgroup(args.Np, args.variant) != 8) return kLeanNotCovered;
+  launch_lean_waves<double, D, 4, 8>(plan, args, st);
+  return KDEHIP_OK;
+#else
+  switch (plan.M) {
+    case 2: return f64 ? launch_lean_m<double, D, 2>(plan, args, st) : launch_lean_m<float, D, 2>(plan, args, st);
+    case 3: return f64 ? launch_lean_m<double, D, 3>(plan, args, st) : launch_lean_m<float, D, 3>(plan, args, st);
+    default: return f64 ? launch_lean_m<double, D, 4>(plan, args, st) : launch_lean_m<float, D, 4>(plan, args, st);
+  }
+#endif
+}
+
+}  // namespace kdehip

@@ -1,0 +1,81 @@
+"""The register-resident kernel for products of 2..4 densities (csrc/gibbs_lean.hip) against the general kernel
+(csrc/gibbs_kernel.hip, forced with plan variants 30+): same labels, bit-identical points, every staging mode,
+both precisions, with and without conditional tables; plus oracle parity through the lean path."""
+import numpy as np
+import pytest
+
+import kdehip
+from oracle import oracle
+from tests.helpers import silverman_bw, synth_mixture
+
+pytestmark = pytest.mark.gpu
+
+
+def _trees(seed, D, Ns, weighted=False):
+    rng = np.random.default_rng(seed)
+    g, o = [], []
+    for N in Ns:
+        pts = synth_mixture(rng, D, N)
+        ks = silverman_bw(pts) if N > 1 else np.full(D, 0.5)
+        ks = np.where(ks > 0, ks, 0.5)
+        w = rng.uniform(0.2, 1.0, size=N) if weighted else None
+        g.append(kdehip.kde(pts, ks, w))
+        o.append(oracle.OracleDensity(pts, ks, w))
+    return g, o
+
+
+@pytest.mark.parametrize("D,Ns,Np,Niter,weighted", [
+    (1, [100, 100], 100, 5, False),            # BASELINE config 1
+    (2, [200, 200, 200], 256, 5, False),       # config 2
+    (6, [1000] * 4, 300, 4, False),            # config 3 shape: resident + streamed levels, tables
+    (3, [37, 128, 129, 300], 70, 2, True),     # ragged sizes
+    (2, [5000, 4000], 40, 2, False),           # frontiers beyond 4096 nodes: recursive narrowing, streamed tiles
+    (6, [10000] * 4, 24, 2, False),            # config 5 shape: chunked staging
+    (8, [130, 90], 50, 1, True),
+    (4, [1, 60, 7], 33, 3, False),             # a single-point density
+])
+@pytest.mark.parametrize("prec", [64, 32])
+def test_lean_kernel_equals_general_kernel(D, Ns, Np, Niter, weighted, prec):
+    g, o = _trees(100 * D + len(Ns), D, Ns, weighted)
+    seed = 77
+    with kdehip.ProductPlan(g, precision=prec) as plan:
+        assert plan.fast_math_path
+        res = {}
+        for variant in (0, 4, 1, 30, 34, 31):   # lean: default / no tables / global; general: the same three
+            plan.set_variant(variant)
+            res[variant] = plan.sample(Np, Niter=Niter, seed=seed, want_labels=True)
+        K, R = plan.randu_per_sample(Niter), plan.randn_per_sample()
+    for variant in (4, 1, 30, 34, 31):
+        for a, b in zip(res[0], res[variant]):
+            assert np.array_equal(a, b), variant
+    if prec == 64 and max(Ns) <= 5000:
+        u, n = kdehip.philox_streams(seed, 0, Np, K, R)
+        op, oi, ol = oracle.gibbs1(o, Np, Niter, u, n, want_labels=True)
+        assert np.array_equal(res[0][1], oi) and np.array_equal(res[0][2], ol)
+        assert np.allclose(res[0][0], op, rtol=1e-11, atol=1e-11)
+
+
+@pytest.mark.parametrize("width", [2, 8, 12, 16])
+def test_lean_kernel_widths_and_caller_streams(width):
+    """every workgroup width, caller-supplied randU/randN (the reference's consumption order) and addEntropy=false"""
+    D, Ns, Np, Niter = 3, [300, 200, 257], 100, 3
+    g, o = _trees(5, D, Ns)
+    K, R, nU, nN = oracle.rng_sizes(len(Ns), D, Np, Niter, Ns)
+    rng = np.random.default_rng(1)
+    randU, randN = rng.random(nU), rng.standard_normal(nN)
+    import torch
+    dev = torch.device("cuda", 0)
+    dU, dN = torch.from_numpy(randU).to(dev), torch.from_numpy(randN).to(dev)
+    for addEntropy in (True, False):
+        op, oi = oracle.gibbs1(o, Np, Niter, randU, randN, addEntropy=addEntropy)
+        with kdehip.ProductPlan(g) as plan:
+            for variant in (width, 30 + width):
+                plan.set_variant(variant)
+                d_pts = torch.zeros(D * Np, dtype=torch.float64, device=dev)
+                d_ind = torch.zeros(len(Ns) * Np, dtype=torch.int64, device=dev)
+                plan.sample_streams_device(Np, Niter, dU, nU, dN, nN, addEntropy, d_pts, d_ind)
+                torch.cuda.synchronize()
+                gp = d_pts.cpu().numpy().reshape(Np, D).T
+                gi = d_ind.cpu().numpy().reshape(Np, len(Ns)).T
+                assert np.array_equal(gi, oi), (variant, addEntropy)
+                assert np.allclose(gp, op, rtol=1e-12, atol=1e-12)
