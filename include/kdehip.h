@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define KDEHIP_VERSION 100 /* 0.1.0 */
+#define KDEHIP_VERSION 200 /* 0.2.0 */
 
 enum {
   KDEHIP_OK = 0,
@@ -87,6 +87,24 @@ int kdehip_gibbs1_trace(int Ndens, const kdehip_density *trees, int64_t Np, int 
                         int addEntropy, int ndims, const uint8_t *partialDimMask, int device,
                         int32_t *labels);
 
+/* The same on `ngpus` GPUs of one node (devices device .. device+ngpus-1), one process: the chains are split into
+ * contiguous ranges (sample s of the call depends only on the densities and on its own slices randU[s*K ..],
+ * randN[s*R ..], so the result is identical for every ngpus), each device gets the packed densities and its slice
+ * of the streams, and returns its slice of pts / ind (/ labels, as kdehip_gibbs1_trace; may be NULL) to the host.
+ * ngpus = 1 is kdehip_gibbs1_trace. */
+int kdehip_gibbs1_multi(int Ndens, const kdehip_density *trees, int64_t Np, int Niter, double *pts,
+                        int64_t *ind, const double *randU, int64_t nU, const double *randN, int64_t nN,
+                        int addEntropy, int ndims, const uint8_t *partialDimMask, int device, int ngpus,
+                        int32_t *labels);
+
+/* prodAppxMSGibbsS when the caller passes no randU / randN (reference src/MSGibbs01.jl:645-703; its
+ * `rand(...)` / `randn(...)` defaults, :661-662, are replaced by the on-device Philox4x32-10 stream keyed by
+ * (seed, sample index, draw index): kdehip_philox_fill_* reproduce the numbers).  One-shot: pack, upload, run,
+ * copy back.  precision 64 or 32; ngpus and labels as in kdehip_gibbs1_multi. */
+int kdehip_prod_philox(int Ndens, const kdehip_density *trees, int64_t Np, int Niter, double *pts, int64_t *ind,
+                       uint64_t seed, int addEntropy, int ndims, const uint8_t *partialDimMask, int precision,
+                       int device, int ngpus, int32_t *labels);
+
 /* ---- (2) resident product plan ----------------------------------------------------------------
  * The densities are re-laid-out once (per-level tiles, "pack_levels") and kept in HBM so repeated
  * products -- and bench.py's timed region -- start with inputs resident on the device.  The first run
@@ -140,6 +158,24 @@ int64_t kdehip_product_fallback_count(kdehip_product *plan);
  * 1 = read every tile from global memory (no LDS staging), 4 = no conditional tables,
  * 2 / 8 / 12 / 16 = 4 / 8 / 12 / 16 chains per workgroup (default: chosen from the number of chains). */
 int kdehip_product_set_variant(kdehip_product *plan, int variant);
+
+/* ---- (2b) resident plans on several GPUs of one node (one process) --------------------------------
+ * One plan per device (the packed densities are replicated), chains in contiguous ranges, Philox counters keyed by
+ * the GLOBAL sample index (results identical for every number of devices), and ONE all-gather of [pGM | indices]
+ * at the end, done with peer writes over xGMI: after the call's work has run, EVERY device holds the complete
+ * d_points[g] (double[ndims*Np]) and d_indices[g] (int64[Ndens*Np]); these are device pointers on device
+ * first_device+g, streams[g] (hipStream_t, or streams == NULL for the null streams) is where device g's work is
+ * enqueued.  The call only enqueues; each stream waits for the slices of all other devices before later work on
+ * it runs. */
+typedef struct kdehip_product_multi kdehip_product_multi;
+int kdehip_product_multi_create(kdehip_product_multi **out, int Ndens, const kdehip_density *trees, int ndims,
+                                const uint8_t *partialDimMask, int precision, int first_device, int ngpus);
+void kdehip_product_multi_destroy(kdehip_product_multi *mp);
+int kdehip_product_multi_ngpus(const kdehip_product_multi *mp);
+kdehip_product *kdehip_product_multi_plan(kdehip_product_multi *mp, int g); /* the plan on device g (owned by mp) */
+int kdehip_product_multi_sample_philox(kdehip_product_multi *mp, int64_t Np, int Niter, uint64_t seed,
+                                       int64_t sample_offset, int addEntropy, double *const *d_points,
+                                       int64_t *const *d_indices, void *const *streams);
 
 /* ---- (3) host twin of the device RNG ----------------------------------------------------------
  * Fills the arrays a caller would pass as randU / randN so that a streams-run (or the Julia

@@ -110,8 +110,13 @@ struct RunArgs {
 // payload is a rounding of it).
 struct PackedProduct {
   int M = 0, D = 0, L = 0;
+  int precision = 64;              // element type of the tiles the geometry was computed for
   std::vector<LevelDesc> levels;   // [M][L+1]
-  std::vector<double> data;        // fp64 payload
+  std::vector<int32_t> front;      // every frontier's node ids (1-based), frontier (j, l) at front_off[j*(L+1)+l]
+  std::vector<int64_t> front_off;  // [M*(L+1) + 1]
+  int64_t data_elems = 0;          // elements of the tile payload (incl. the readable tail)
+  int64_t perm_elems = 0;          // int32 entries of the permutation rows
+  std::vector<double> data;        // fp64 payload (pack_levels only)
   std::vector<int32_t> perm;
   int64_t nodes_per_sweep = 0;     // sum_j sum_{l>=1} n_{j,l}
   bool fast = true;                // product/rsqrt arithmetic + compact uniform tiles in use
@@ -127,6 +132,11 @@ struct PackedProduct {
 // uniform-bandwidth tiles -- may be used (out.fast).
 int pack_levels(int Ndens, const kdehip_density *trees, int ndims, const uint8_t *mask, int precision,
                 PackedProduct &out);
+// The same in two steps, for callers that own the destination (product.hip packs straight into the pinned upload
+// buffer): geometry, descriptors and frontier ids; then the payload in the layout's precision.
+int pack_layout(int Ndens, const kdehip_density *trees, int ndims, const uint8_t *mask, int precision,
+                PackedProduct &out);
+void pack_fill(const PackedProduct &pp, const kdehip_density *trees, void *data, int32_t *perm);
 
 // floor(log(maxNp)/log(2) + 1), reference src/MSGibbs01.jl:568
 int nlevels_for(int64_t maxNp);

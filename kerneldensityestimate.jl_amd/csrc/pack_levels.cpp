@@ -26,7 +26,7 @@ int nlevels_for(int64_t maxNp) {
   return static_cast<int>(std::floor(std::log(static_cast<double>(maxNp)) / std::log(2.0) + 1.0));
 }
 
-int pack_levels(int Ndens, const kdehip_density *trees, int ndims, const uint8_t *mask, int precision,
+int pack_layout(int Ndens, const kdehip_density *trees, int ndims, const uint8_t *mask, int precision,
                 PackedProduct &out) {
   if (Ndens < 1 || !trees) return set_error(KDEHIP_ERR_ARG, "need at least one density");
   if (Ndens > KDEHIP_MAX_DENS)
@@ -48,7 +48,9 @@ int pack_levels(int Ndens, const kdehip_density *trees, int ndims, const uint8_t
   const int L = nlevels_for(maxN);
   out = PackedProduct();
   out.M = M; out.D = D; out.L = L;
+  out.precision = precision;
   out.levels.resize(static_cast<size_t>(M) * (L + 1));
+  out.front_off.assign(static_cast<size_t>(M) * (L + 1) + 1, 0);
 
   const uint32_t all = (1u << D) - 1u;
   std::vector<uint32_t> mask_bits(M, all), others_bits(M, 0);
@@ -63,43 +65,54 @@ int pack_levels(int Ndens, const kdehip_density *trees, int ndims, const uint8_t
   for (int j = 0; j < M; ++j)
     for (int k = 0; k < M; ++k) if (k != j) others_bits[j] |= mask_bits[k];
 
-  // ---- phase 1: expand every frontier (levelDown!, src/MSGibbs01.jl:503-511) and collect ranges
-  std::vector<std::vector<int64_t>> frontier(static_cast<size_t>(M) * (L + 1));
-  std::vector<double> bw_lo(D, INFINITY), bw_hi(D, 0.0);
+  // ---- phase 1: expand every frontier (levelDown!, src/MSGibbs01.jl:503-511) into one flat id array, and look at
+  // every frontier node once: finiteness, bandwidth range, and whether a level shares one bandwidth vector
+  double bw_lo[KDEHIP_MAX_DIMS], bw_hi[KDEHIP_MAX_DIMS];
+  for (int d = 0; d < D; ++d) { bw_lo[d] = INFINITY; bw_hi[d] = 0.0; }
   bool finite_ok = true;
+  std::vector<uint8_t> level_uniform(static_cast<size_t>(M) * (L + 1), 1);
+  out.front.clear();
   for (int j = 0; j < M; ++j) {
     const kdehip_density &t = trees[j];
     const int64_t N = t.npts;
-    auto valid = [N](int64_t id) { return id > 0 && id <= 2 * N; };  // BallTree01.jl:83
-    std::vector<int64_t> cur(1, 1);  // levelInit!: frontier = {root()}
+    out.front.reserve(out.front.size() + static_cast<size_t>(N) * (L + 1) / 2 + 64);
     for (int l = 0; l <= L; ++l) {
-      if (l > 0) {
-        std::vector<int64_t> nxt;
-        nxt.reserve(cur.size() * 2);
-        for (int64_t node : cur) {
+      const size_t idx = static_cast<size_t>(j) * (L + 1) + l;
+      const size_t begin = out.front.size();
+      out.front_off[idx] = static_cast<int64_t>(begin);
+      if (l == 0) {
+        out.front.push_back(1);  // levelInit!: frontier = {root()}
+      } else {
+        const size_t pb = static_cast<size_t>(out.front_off[idx - 1]), pe = begin;
+        for (size_t z = pb; z < pe; ++z) {
+          const int64_t node = out.front[z];
           const int64_t a = t.left_child[node - 1], b = t.right_child[node - 1];
-          if (valid(a)) nxt.push_back(a);
-          if (valid(b)) nxt.push_back(b);
+          if (a > 0 && a <= 2 * N) out.front.push_back(static_cast<int32_t>(a));  // validIndex, BallTree01.jl:83
+          if (b > 0 && b <= 2 * N) out.front.push_back(static_cast<int32_t>(b));
         }
-        if (nxt.empty() || static_cast<int64_t>(nxt.size()) > N)
-          return set_error(KDEHIP_ERR_ARG, "malformed tree: frontier empty or larger than Npts");
-        cur.swap(nxt);
-        out.nodes_per_sweep += static_cast<int64_t>(cur.size());
+        const int64_t n = static_cast<int64_t>(out.front.size() - begin);
+        if (n == 0 || n > N) return set_error(KDEHIP_ERR_ARG, "malformed tree: frontier empty or larger than Npts");
+        out.nodes_per_sweep += n;
       }
-      for (int64_t node : cur) {
-        if (!valid(node)) return set_error(KDEHIP_ERR_ARG, "malformed tree: child id out of range");
+      const double *bw0 = t.bandwidth + (static_cast<int64_t>(out.front[begin]) - 1) * D;
+      bool uni = true;
+      for (size_t z = begin; z < out.front.size(); ++z) {
+        const int64_t node = out.front[z];
+        const double *mu = t.means + (node - 1) * D, *v = t.bandwidth + (node - 1) * D;
         for (int d = 0; d < D; ++d) {
-          const double mu = t.means[(node - 1) * D + d], v = t.bandwidth[(node - 1) * D + d];
-          if (!(std::isfinite(mu) && std::isfinite(v) && v > 0.0)) finite_ok = false;
-          if (v < bw_lo[d]) bw_lo[d] = v;
-          if (v > bw_hi[d]) bw_hi[d] = v;
+          // (means beyond 1e100 would overflow the squared distances of the product/rsqrt forms)
+          if (!(std::fabs(mu[d]) < 1e100 && std::isfinite(v[d]) && v[d] > 0.0)) finite_ok = false;
+          if (v[d] < bw_lo[d]) bw_lo[d] = v[d];
+          if (v[d] > bw_hi[d]) bw_hi[d] = v[d];
+          if (v[d] != bw0[d]) uni = false;
         }
         const double w = t.weights[node - 1];
         if (!(std::isfinite(w) && w >= 0.0)) finite_ok = false;
       }
-      frontier[static_cast<size_t>(j) * (L + 1) + l] = cur;
+      level_uniform[idx] = uni ? 1 : 0;
     }
   }
+  out.front_off.back() = static_cast<int64_t>(out.front.size());
 
   // The product/rsqrt form multiplies up to D variances c_d in [bw_lo, 2*bw_hi] (bandwidth plus a
   // leave-one-out product variance that is never larger than the largest bandwidth).  It is used
@@ -113,27 +126,23 @@ int pack_levels(int Ndens, const kdehip_density *trees, int ndims, const uint8_t
   }
   const bool in_range = (precision == 64) ? (up < 1e120 && dn > 1e-120) : (up < 1e15 && dn > 1e-15);
   // the fast forms evaluate every dimension: they need every dimension of every density to be informed by
-  // some OTHER density too (false for a one-density "product", where the reference weighs by w alone)
-  // (a one-density "product" or a partialDimMask leaves dimensions inactive: masked fast form)
+  // some OTHER density too (a one-density "product" or a partialDimMask leaves dimensions inactive: masked fast form)
   out.all_active = true;
   for (int j = 0; j < M; ++j) if ((mask_bits[j] & others_bits[j]) != all) out.all_active = false;
   out.fast = finite_ok && in_range;
 
-  // ---- phase 2: write the tiles
+  // ---- phase 2: tile geometry and offsets (the payload is written by pack_fill)
   const int64_t esz = (precision == 64) ? 8 : 4;
+  int64_t nelem = 0, nperm = 0;
   for (int j = 0; j < M; ++j) {
-    const kdehip_density &t = trees[j];
     for (int l = 0; l <= L; ++l) {
-      const std::vector<int64_t> &cur = frontier[static_cast<size_t>(j) * (L + 1) + l];
-      const int64_t n = static_cast<int64_t>(cur.size());
+      const size_t idx = static_cast<size_t>(j) * (L + 1) + l;
+      const int64_t n = out.front_off[idx + 1] - out.front_off[idx];
       const int64_t B = (n + 63) / 64;
-      bool uni = out.fast;  // compact tiles only on the fast path
-      for (int64_t z = 1; z < n && uni; ++z)
-        for (int d = 0; d < D; ++d)
-          if (t.bandwidth[(cur[z] - 1) * D + d] != t.bandwidth[(cur[0] - 1) * D + d]) { uni = false; break; }
+      const bool uni = out.fast && level_uniform[idx];  // compact tiles only on the fast path
       const int F = uni ? D + 1 : 2 * D + 1;
       const int64_t RS = static_cast<int64_t>(F) * 64 + 1;
-      LevelDesc &ds = out.levels[static_cast<size_t>(j) * (L + 1) + l];
+      LevelDesc &ds = out.levels[idx];
       std::memset(&ds, 0, sizeof(ds));
       ds.n = static_cast<int32_t>(n);
       ds.B = static_cast<int32_t>(B);
@@ -141,41 +150,20 @@ int pack_levels(int Ndens, const kdehip_density *trees, int ndims, const uint8_t
       ds.uniform_bw = uni ? 1 : 0;
       ds.mask_bits = mask_bits[j];
       ds.others_bits = others_bits[j];
-      while (out.data.size() % 8) out.data.push_back(0.0);  // tiles start 64-byte (fp32: 32-byte) aligned
-      ds.hdr_off = static_cast<int64_t>(out.data.size());
-      for (int d = 0; d < kTileHeader; ++d)
-        out.data.push_back(d < D ? t.bandwidth[(cur[0] - 1) * D + d] : 0.0);
-      const int64_t rows_off = static_cast<int64_t>(out.data.size());
-      ds.perm_off = static_cast<int64_t>(out.perm.size());
-      out.data.resize(out.data.size() + static_cast<size_t>(B * RS), 0.0);
-      out.perm.resize(out.perm.size() + static_cast<size_t>(B * 64), 0);
+      nelem = (nelem + 7) & ~int64_t(7);  // tiles start 64-byte (fp32: 32-byte) aligned
+      ds.hdr_off = nelem;
+      nelem += kTileHeader + B * RS;
+      ds.perm_off = nperm;
+      nperm += B * 64;
       const int64_t bytes = (kTileHeader + B * RS) * esz;
       if (bytes > (int64_t(1) << 30)) return set_error(KDEHIP_ERR_UNSUPPORTED, "level tile too large");
       ds.stage_bytes = static_cast<int32_t>((bytes + 1023) / 1024 * 1024);
       ds.last_lane = static_cast<int32_t>((n - 1) / B);
       ds.chunk_rows = static_cast<int32_t>(((kLdsPoolBytes / 2 - 1024) / (RS * esz)) & ~int64_t(3));
-      double *tile = out.data.data() + rows_off;
-      int32_t *prow = out.perm.data() + ds.perm_off;
-      for (int64_t i = 0; i < B; ++i)
-        for (int ln = 0; ln < 64; ++ln) {
-          double *e = tile + i * RS + ln;
-          const int64_t z = static_cast<int64_t>(ln) * B + i;
-          if (z < n) {
-            const int64_t node = cur[static_cast<size_t>(z)];
-            for (int d = 0; d < D; ++d) e[d * 64] = t.means[(node - 1) * D + d];
-            if (!uni) for (int d = 0; d < D; ++d) e[(D + d) * 64] = t.bandwidth[(node - 1) * D + d];
-            e[(F - 1) * 64] = t.weights[node - 1];
-            prow[i * 64 + ln] = static_cast<int32_t>(t.permutation[node - 1]);
-          } else {  // padding: mean 0, variance 1, weight 0
-            for (int d = 0; d < D; ++d) e[d * 64] = 0.0;
-            if (!uni) for (int d = 0; d < D; ++d) e[(D + d) * 64] = 1.0;
-            e[(F - 1) * 64] = 0.0;
-          }
-        }
     }
   }
-  // staged copies are rounded up to whole KiB: keep the tail readable
-  out.data.resize(out.data.size() + 1024 / 4, 0.0);
+  out.data_elems = nelem + 1024 / 4;  // staged copies are rounded up to whole KiB: keep the tail readable
+  out.perm_elems = nperm;
 
   // ---- phase 3: where each level's tiles live while the kernel works on that level
   for (int l = 0; l <= L; ++l) {
@@ -238,6 +226,73 @@ int pack_levels(int Ndens, const kdehip_density *trees, int ndims, const uint8_t
     out.tab_entries = entries;
     out.tab_rows = rows;
   }
+  return KDEHIP_OK;
+}
+
+
+// Writes the payload of a layout: tiles (element type by `precision` of the layout) and permutation rows.
+// Row by row, field by field, 64 contiguous lanes at a time (the sources are gathered through the frontier ids).
+template <typename T>
+static void fill_tiles(const PackedProduct &pp, const kdehip_density *trees, T *data, int32_t *perm) {
+  const int D = pp.D, M = pp.M, L = pp.L;
+  for (int j = 0; j < M; ++j) {
+    const kdehip_density &t = trees[j];
+    for (int l = 0; l <= L; ++l) {
+      const size_t idx = static_cast<size_t>(j) * (L + 1) + l;
+      const LevelDesc &ds = pp.levels[idx];
+      const int32_t *cur = pp.front.data() + pp.front_off[idx];
+      const int64_t n = ds.n, B = ds.B;
+      const int F = ds.F;
+      const bool uni = ds.uniform_bw != 0;
+      const int64_t RS = static_cast<int64_t>(F) * 64 + 1;
+      T *hdr = data + ds.hdr_off;
+      for (int d = 0; d < kTileHeader; ++d)
+        hdr[d] = d < D ? static_cast<T>(t.bandwidth[(static_cast<int64_t>(cur[0]) - 1) * D + d]) : T(0);
+      T *tile = hdr + kTileHeader;
+      int32_t *prow = perm + ds.perm_off;
+      for (int64_t i = 0; i < B; ++i) {
+        int64_t src[64];  // source offset (node - 1) of lane ln's entry in this row, -1 = padding
+        for (int ln = 0; ln < 64; ++ln) {
+          const int64_t z = static_cast<int64_t>(ln) * B + i;
+          src[ln] = z < n ? static_cast<int64_t>(cur[z]) - 1 : -1;
+        }
+        T *row = tile + i * RS;
+        for (int d = 0; d < D; ++d) {
+          T *dst = row + d * 64;
+          for (int ln = 0; ln < 64; ++ln) dst[ln] = src[ln] >= 0 ? static_cast<T>(t.means[src[ln] * D + d]) : T(0);
+        }
+        if (!uni)
+          for (int d = 0; d < D; ++d) {
+            T *dst = row + (D + d) * 64;
+            for (int ln = 0; ln < 64; ++ln) dst[ln] = src[ln] >= 0 ? static_cast<T>(t.bandwidth[src[ln] * D + d]) : T(1);
+          }
+        T *wdst = row + (F - 1) * 64;
+        for (int ln = 0; ln < 64; ++ln) wdst[ln] = src[ln] >= 0 ? static_cast<T>(t.weights[src[ln]]) : T(0);
+        row[F * 64] = T(0);  // the pad element
+        int32_t *pdst = prow + i * 64;
+        for (int ln = 0; ln < 64; ++ln) pdst[ln] = src[ln] >= 0 ? static_cast<int32_t>(t.permutation[src[ln]]) : 0;
+      }
+      // gap up to the next tile's aligned start
+      const int64_t end = ds.hdr_off + kTileHeader + B * RS;
+      const int64_t next = (idx + 1 < pp.levels.size()) ? pp.levels[idx + 1].hdr_off : pp.data_elems;
+      for (int64_t e = end; e < next; ++e) data[e] = T(0);
+    }
+  }
+}
+
+void pack_fill(const PackedProduct &pp, const kdehip_density *trees, void *data, int32_t *perm) {
+  if (pp.precision == 64) fill_tiles<double>(pp, trees, static_cast<double *>(data), perm);
+  else fill_tiles<float>(pp, trees, static_cast<float *>(data), perm);
+}
+
+// Layout + payload in host vectors (fp64 payload whatever the precision of the layout): tests and tools.
+int pack_levels(int Ndens, const kdehip_density *trees, int ndims, const uint8_t *mask, int precision,
+                PackedProduct &out) {
+  const int rc = pack_layout(Ndens, trees, ndims, mask, precision, out);
+  if (rc != KDEHIP_OK) return rc;
+  out.data.assign(static_cast<size_t>(out.data_elems), 0.0);
+  out.perm.assign(static_cast<size_t>(out.perm_elems), 0);
+  fill_tiles<double>(out, trees, out.data.data(), out.perm.data());
   return KDEHIP_OK;
 }
 

@@ -61,7 +61,7 @@ int check_run(const kdehip_product *plan, int64_t Np, int Niter, const void *d_p
 
 // Conditional tables are filled by the sampler kernel itself (table_build launch), on the caller's stream,
 // the first time a run is large enough to pay for them.
-int maybe_build_tables(kdehip_product *plan, int64_t Np, RunArgs &a, void *stream) {
+int maybe_build_tables(kdehip_product *plan, int64_t Np, RunArgs &a, void *stream, bool private_plan = false) {
   a.table_build = 0;
   a.use_tables = 0;
   if (plan->dev.Lt <= 0 || plan->dev.tab_rows_total <= 0) return KDEHIP_OK;
@@ -74,8 +74,8 @@ int maybe_build_tables(kdehip_product *plan, int64_t Np, RunArgs &a, void *strea
     b.variant = 8;
     const int rc = launch_gibbs(plan->precision, plan->mode, plan->dev, b, stream);
     if (rc != KDEHIP_OK) return rc;
-    // one-time: runs on other streams must not overtake the build
-    KDEHIP_CHECK(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    // one-time: runs on other streams must not overtake the build (a plan private to one call has no other streams)
+    if (!private_plan) KDEHIP_CHECK(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
     plan->tables_built = true;
   }
   a.use_tables = 1;
@@ -94,10 +94,27 @@ int reserve_work(kdehip_product *plan, size_t bytes) {
 }
 inline size_t align256(size_t x) { return (x + 255) & ~static_cast<size_t>(255); }
 
+// Results of a host-buffer run: the output arrays sit back to back in the plan's scratch, so they come back with ONE
+// DMA transfer into pinned memory (from the library's cache) and are handed out from there -- two or three blocking
+// copies into pageable memory cost tens of microseconds each, which is visible against a ~0.6 ms product.
+struct OutPiece { void *host; size_t dev_off, bytes; };
+int copy_out(const void *d_base, size_t span, const OutPiece *pieces, int npieces) {
+  void *h = nullptr;
+  KDEHIP_CHECK(cached_host_malloc(&h, span));
+  hipError_t e = hipMemcpyAsync(h, d_base, span, hipMemcpyDeviceToHost, nullptr);
+  if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+  if (e == hipSuccess)
+    for (int i = 0; i < npieces; ++i)
+      if (pieces[i].host && pieces[i].bytes) std::memcpy(pieces[i].host, static_cast<unsigned char *>(h) + pieces[i].dev_off, pieces[i].bytes);
+  cached_host_free(h, span);
+  if (e != hipSuccess) return set_error(KDEHIP_ERR_HIP, std::string("result copy: ") + hipGetErrorString(e));
+  return KDEHIP_OK;
+}
+
 // The two run forms, enqueue only (no bookkeeping of who waits for the work: see the callers).
 int enqueue_streams(kdehip_product *plan, int64_t Np, int Niter, const double *d_randU, int64_t nU,
                     const double *d_randN, int64_t nN, int addEntropy, double *d_points, int64_t *d_indices,
-                    int32_t *d_labels, void *stream) {
+                    int32_t *d_labels, void *stream, bool private_plan = false) {
   int rc = check_run(plan, Np, Niter, d_points, d_indices);
   if (rc != KDEHIP_OK) return rc;
   if (Np == 0) return KDEHIP_OK;
@@ -117,13 +134,14 @@ int enqueue_streams(kdehip_product *plan, int64_t Np, int Niter, const double *d
   a.randU = d_randU; a.randN = d_randN; a.K = K; a.R = R; a.nU = nU; a.nN = nN;
   a.seed = 0; a.sample_offset = 0;
   a.points = d_points; a.indices = d_indices; a.labels = d_labels;
-  rc = maybe_build_tables(plan, Np, a, stream);
+  rc = maybe_build_tables(plan, Np, a, stream, private_plan);
   if (rc != KDEHIP_OK) return rc;
   return launch_gibbs(plan->precision, plan->mode, plan->dev, a, stream);
 }
 
 int enqueue_philox(kdehip_product *plan, int64_t Np, int Niter, uint64_t seed, int64_t sample_offset,
-                   int addEntropy, double *d_points, int64_t *d_indices, int32_t *d_labels, void *stream) {
+                   int addEntropy, double *d_points, int64_t *d_indices, int32_t *d_labels, void *stream,
+                   bool private_plan = false) {
   int rc = check_run(plan, Np, Niter, d_points, d_indices);
   if (rc != KDEHIP_OK) return rc;
   if (Np == 0) return KDEHIP_OK;
@@ -139,9 +157,110 @@ int enqueue_philox(kdehip_product *plan, int64_t Np, int Niter, uint64_t seed, i
   a.R = kdehip_product_randn_per_sample(plan);
   a.seed = seed; a.sample_offset = sample_offset;
   a.points = d_points; a.indices = d_indices; a.labels = d_labels;
-  rc = maybe_build_tables(plan, Np, a, stream);
+  rc = maybe_build_tables(plan, Np, a, stream, private_plan);
   if (rc != KDEHIP_OK) return rc;
   return launch_gibbs(plan->precision, plan->mode, plan->dev, a, stream);
+}
+
+
+// The device image of a product, assembled once in pinned host memory (from the library's cache) in the tiles'
+// final precision: [.. fallback counter | levels | table descriptors | permutation | tiles] (+ room for the
+// conditional tables on the device).  One image can be instantiated on several devices (multi-GPU entry points).
+struct PlanImage {
+  PackedProduct host;
+  void *h_blob = nullptr;
+  size_t off_lev = 0, off_count = 0, off_tab = 0, off_perm = 0, off_data = 0, off_tables = 0, total = 0;
+  int precision = 64;
+  ~PlanImage() { if (h_blob) cached_host_free(h_blob, off_tables); }
+};
+
+int build_image(PlanImage &im, int Ndens, const kdehip_density *trees, int ndims, const uint8_t *partialDimMask,
+                int precision) {
+  if (precision != 64 && precision != 32) return set_error(KDEHIP_ERR_ARG, "precision must be 64 or 32");
+  int rc = pack_layout(Ndens, trees, ndims, partialDimMask, precision, im.host);
+  if (rc != KDEHIP_OK) return rc;
+  im.precision = precision;
+  const size_t nelem = static_cast<size_t>(im.host.data_elems);
+  const size_t esz = (precision == 64) ? sizeof(double) : sizeof(float);
+  const size_t nperm = static_cast<size_t>(im.host.perm_elems);
+  const size_t nlev = im.host.levels.size();
+  const size_t ntab = im.host.tabdesc.size();
+  im.off_lev = 256;                                        // the fallback counter sits in the 8 bytes before it
+  im.off_count = im.off_lev - sizeof(unsigned long long);
+  im.off_tab = align256(im.off_lev + nlev * sizeof(LevelDesc));
+  im.off_perm = align256(im.off_tab + ntab * sizeof(TabDesc));
+  im.off_data = align256(im.off_perm + nperm * sizeof(int32_t));
+  im.off_tables = align256(im.off_data + nelem * esz);
+  im.total = im.off_tables + static_cast<size_t>(im.host.tab_entries) * esz;
+  // (pinned memory needs a HIP runtime with a device: a host without one fails here, loudly, as it must)
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return set_error(KDEHIP_ERR_NO_DEVICE, "no HIP device available (libkdehip has no CPU fallback by design)");
+  KDEHIP_CHECK(cached_host_malloc(&im.h_blob, im.off_tables));
+  unsigned char *hb = static_cast<unsigned char *>(im.h_blob);
+  std::memset(hb, 0, im.off_lev);
+  std::memcpy(hb + im.off_lev, im.host.levels.data(), nlev * sizeof(LevelDesc));
+  std::memcpy(hb + im.off_tab, im.host.tabdesc.data(), ntab * sizeof(TabDesc));
+  pack_fill(im.host, trees, hb + im.off_data, reinterpret_cast<int32_t *>(hb + im.off_perm));
+  std::vector<int32_t>().swap(im.host.front);  // (only the descriptors are needed from here on)
+  return KDEHIP_OK;
+}
+
+// A plan on `device` from an image: one device allocation, one DMA transfer (hipMalloc / hipFree cost tens of
+// microseconds each and would dominate a one-shot small product; blocks come from the library's cache).
+int instantiate(const PlanImage &im, int device, kdehip_product **out) {
+  *out = nullptr;
+  kdehip_product *p = new (std::nothrow) kdehip_product();
+  if (!p) return set_error(KDEHIP_ERR_ALLOC, "out of host memory");
+  DeviceGuard guard;
+  int rc = guard.enter(device);
+  if (rc != KDEHIP_OK) { delete p; return rc; }
+  p->device = device;
+  p->precision = im.precision;
+  p->host = im.host;  // descriptors (the frontier ids were released by build_image)
+  p->fast = p->host.fast;
+  p->mode = !p->host.fast ? kModeGeneric : (p->host.all_active ? kModeFast : kModeFastMasked);
+  hipError_t e = cached_malloc(&p->d_blob, im.total);
+  if (e == hipSuccess) p->blob_bytes = im.total;
+  if (e == hipSuccess) e = hipMemcpyAsync(p->d_blob, im.h_blob, im.off_tables, hipMemcpyHostToDevice, nullptr);
+  if (e == hipSuccess) e = hipStreamSynchronize(nullptr);  // (the pinned image may be recycled after this call)
+  if (e != hipSuccess) {
+    const std::string m = std::string("plan upload: ") + hipGetErrorString(e);
+    kdehip_product_destroy(p);
+    return set_error(KDEHIP_ERR_HIP, m);
+  }
+  unsigned char *base = static_cast<unsigned char *>(p->d_blob);
+  p->d_levels = reinterpret_cast<LevelDesc *>(base + im.off_lev);
+  p->d_tabdesc = reinterpret_cast<TabDesc *>(base + im.off_tab);
+  p->d_perm = reinterpret_cast<int32_t *>(base + im.off_perm);
+  p->d_data = base + im.off_data;
+  p->d_fallbacks = reinterpret_cast<unsigned long long *>(base + im.off_count);
+  p->d_tables = im.host.tab_entries ? base + im.off_tables : nullptr;
+  p->packed_bytes = static_cast<int64_t>(im.total);
+  p->dev.data = p->d_data;
+  p->dev.perm = p->d_perm;
+  p->dev.levels = p->d_levels;
+  p->dev.tables = p->d_tables;
+  p->dev.tabdesc = p->d_tabdesc;
+  p->dev.tab_rows_total = p->host.tab_rows;
+  p->dev.M = p->host.M;
+  p->dev.L = p->host.L;
+  p->dev.D = p->host.D;
+  p->dev.Lt = (p->mode == kModeGeneric) ? 0 : p->host.Lt;
+  *out = p;
+  return KDEHIP_OK;
+}
+
+// contiguous share of `Np` chains for device g of G
+inline int64_t share_begin(int64_t Np, int g, int G) { return Np * g / G; }
+
+int check_devices(int device, int ngpus) {
+  if (ngpus < 1) return set_error(KDEHIP_ERR_ARG, "ngpus must be >= 1");
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+    return set_error(KDEHIP_ERR_NO_DEVICE, "no HIP device available (libkdehip has no CPU fallback by design)");
+  if (device < 0 || device + ngpus > n) return set_error(KDEHIP_ERR_ARG, "device range outside the visible devices");
+  return KDEHIP_OK;
 }
 
 }  // namespace
@@ -161,76 +280,10 @@ int kdehip_product_create(kdehip_product **out, int Ndens, const kdehip_density 
                           const uint8_t *partialDimMask, int precision, int device) {
   if (!out) return set_error(KDEHIP_ERR_ARG, "null out pointer");
   *out = nullptr;
-  if (precision != 64 && precision != 32) return set_error(KDEHIP_ERR_ARG, "precision must be 64 or 32");
-  kdehip_product *p = new (std::nothrow) kdehip_product();
-  if (!p) return set_error(KDEHIP_ERR_ALLOC, "out of host memory");
-  DeviceGuard guard;
-  int rc = pack_levels(Ndens, trees, ndims, partialDimMask, precision, p->host);
-  if (rc == KDEHIP_OK) rc = guard.enter(device);
-  if (rc != KDEHIP_OK) { delete p; return rc; }
-  p->device = device;
-  p->precision = precision;
-  p->fast = p->host.fast;
-  p->mode = !p->host.fast ? kModeGeneric : (p->host.all_active ? kModeFast : kModeFastMasked);
-
-  // One device allocation and one upload per plan (hipMalloc / hipFree cost tens of microseconds each and
-  // dominate a one-shot small product): [levels | table descriptors | permutation | tiles | tables], the
-  // table region is filled later by the table-build launch.
-  const size_t nelem = p->host.data.size();
-  const size_t esz = (precision == 64) ? sizeof(double) : sizeof(float);
-  const size_t nperm = p->host.perm.size();
-  const size_t nlev = p->host.levels.size();
-  const size_t ntab = p->host.tabdesc.size();
-  const size_t tab_bytes = static_cast<size_t>(p->host.tab_entries) * esz;
-  auto align = [](size_t x) { return (x + 255) & ~static_cast<size_t>(255); };
-  const size_t off_lev = 256;                                  // the fallback counter sits in the 8 bytes before it
-  const size_t off_count = off_lev - sizeof(unsigned long long); // (zeroed with the rest of the upload)
-  const size_t off_tab = align(off_lev + nlev * sizeof(LevelDesc));
-  const size_t off_perm = align(off_tab + ntab * sizeof(TabDesc));
-  const size_t off_data = align(off_perm + nperm * sizeof(int32_t));
-  const size_t off_tables = align(off_data + nelem * esz);
-  const size_t total = off_tables + tab_bytes;
-  std::vector<unsigned char> blob(off_tables, 0);
-  std::memcpy(blob.data() + off_lev, p->host.levels.data(), nlev * sizeof(LevelDesc));
-  std::memcpy(blob.data() + off_tab, p->host.tabdesc.data(), ntab * sizeof(TabDesc));
-  std::memcpy(blob.data() + off_perm, p->host.perm.data(), nperm * sizeof(int32_t));
-  if (precision == 64) {
-    std::memcpy(blob.data() + off_data, p->host.data.data(), nelem * esz);
-  } else {
-    float *f = reinterpret_cast<float *>(blob.data() + off_data);
-    for (size_t i = 0; i < nelem; ++i) f[i] = static_cast<float>(p->host.data[i]);
-  }
-  hipError_t e = cached_malloc(&p->d_blob, total);
-  if (e == hipSuccess) p->blob_bytes = total;
-  if (e == hipSuccess) e = hipMemcpy(p->d_blob, blob.data(), off_tables, hipMemcpyHostToDevice);
-  if (e != hipSuccess) {
-    const std::string m = std::string("plan upload: ") + hipGetErrorString(e);
-    kdehip_product_destroy(p);
-    return set_error(KDEHIP_ERR_HIP, m);
-  }
-  unsigned char *base = static_cast<unsigned char *>(p->d_blob);
-  p->d_levels = reinterpret_cast<LevelDesc *>(base + off_lev);
-  p->d_tabdesc = reinterpret_cast<TabDesc *>(base + off_tab);
-  p->d_perm = reinterpret_cast<int32_t *>(base + off_perm);
-  p->d_data = base + off_data;
-  p->d_fallbacks = reinterpret_cast<unsigned long long *>(base + off_count);
-  p->d_tables = tab_bytes ? base + off_tables : nullptr;
-  p->packed_bytes = static_cast<int64_t>(total);
-  std::vector<double>().swap(p->host.data);
-  std::vector<int32_t>().swap(p->host.perm);
-
-  p->dev.data = p->d_data;
-  p->dev.perm = p->d_perm;
-  p->dev.levels = p->d_levels;
-  p->dev.tables = p->d_tables;
-  p->dev.tabdesc = p->d_tabdesc;
-  p->dev.tab_rows_total = p->host.tab_rows;
-  p->dev.M = p->host.M;
-  p->dev.L = p->host.L;
-  p->dev.D = p->host.D;
-  p->dev.Lt = (p->mode == kModeGeneric) ? 0 : p->host.Lt;
-  *out = p;
-  return KDEHIP_OK;
+  PlanImage im;
+  int rc = build_image(im, Ndens, trees, ndims, partialDimMask, precision);
+  if (rc != KDEHIP_OK) return rc;
+  return instantiate(im, device, out);
 }
 
 void kdehip_product_destroy(kdehip_product *plan) {
@@ -329,63 +382,249 @@ int kdehip_product_sample_philox_host(kdehip_product *plan, int64_t Np, int Nite
   // the flag is only ever set, by the device-pointer entry points, and read by kdehip_product_destroy)
   rc = enqueue_philox(plan, Np, Niter, seed, sample_offset, addEntropy, dp, di, dl, nullptr);
   if (rc != KDEHIP_OK) return rc;
-  KDEHIP_CHECK(hipMemcpy(points, dp, sizeof(double) * D * Np, hipMemcpyDeviceToHost));
-  KDEHIP_CHECK(hipMemcpy(indices, di, sizeof(int64_t) * M * Np, hipMemcpyDeviceToHost));
-  if (labels) KDEHIP_CHECK(hipMemcpy(labels, dl, sizeof(int32_t) * M * L * Np, hipMemcpyDeviceToHost));
+  const size_t lab_bytes = labels ? sizeof(int32_t) * M * L * Np : 0;
+  const OutPiece out[3] = {{points, 0, sizeof(double) * D * Np}, {indices, off_i, sizeof(int64_t) * M * Np},
+                           {labels, off_l, lab_bytes}};
+  (void)dl;
+  return copy_out(w, off_l + lab_bytes, out, 3);
+}
+
+// ---- one-shot entry points (host buffers in, host buffers out, blocking; one or several GPUs) -----------------
+namespace {
+
+// Per-device state of a one-shot call.  Chains are split into contiguous ranges; nothing crosses
+// devices: every device returns its own slice to the host.
+struct Shard {
+  kdehip_product *plan = nullptr;
+  int device = 0;
+  int64_t lo = 0, hi = 0;
+  size_t off_p = 0, off_i = 0, off_l = 0, span = 0;  // layout of the plan's scratch: [streams ..][points][indices][labels]
+  void *h_out = nullptr;                              // pinned landing zone of the results
+  ~Shard() {
+    if (h_out) cached_host_free(h_out, span);
+    kdehip_product_destroy(plan);
+  }
+};
+
+// randU == nullptr: device Philox stream keyed by (seed, global sample index); otherwise the caller's streams.
+int one_shot(int Ndens, const kdehip_density *trees, int64_t Np, int Niter, double *pts, int64_t *ind,
+             const double *randU, int64_t nU, const double *randN, int64_t nN, uint64_t seed, int addEntropy,
+             int ndims, const uint8_t *partialDimMask, int precision, int device, int ngpus, int32_t *labels) {
+  int rc = check_devices(device, ngpus);
+  if (rc != KDEHIP_OK) {
+    // argument errors of the product itself take precedence over "no device" only when they are detectable
+    // without one: validate the densities first so that hosts without a GPU still get the reference's messages
+    PackedProduct probe;
+    const int prc = pack_layout(Ndens, trees, ndims, partialDimMask, precision == 32 ? 32 : 64, probe);
+    return prc != KDEHIP_OK ? prc : rc;
+  }
+  PlanImage im;
+  rc = build_image(im, Ndens, trees, ndims, partialDimMask, precision);
+  if (rc != KDEHIP_OK) return rc;
+  if (Np < 0) return set_error(KDEHIP_ERR_ARG, "Np must be >= 0");
+  if (Niter < 0) return set_error(KDEHIP_ERR_ARG, "Niter must be >= 0");
+  if (Np > 0 && (!pts || !ind)) return set_error(KDEHIP_ERR_ARG, "null output pointer");
+  if (Np == 0) return KDEHIP_OK;
+  const size_t D = ndims, M = Ndens, L = im.host.L;
+  const int64_t K = static_cast<int64_t>(M) * (1 + static_cast<int64_t>(L) * (Niter + 1));
+  const int64_t R = static_cast<int64_t>(D) * (L + 1);
+  const bool streams = randU != nullptr || randN != nullptr;
+  if (streams) {
+    if (!randU || nU < Np * K - 1)
+      return set_error(KDEHIP_ERR_RAND_SHORT, "randU shorter than Np*K-1 values (Julia: BoundsError)");
+    if (!randN || nN < Np * R)
+      return set_error(KDEHIP_ERR_RAND_SHORT, "randN shorter than Np*R values (Julia: BoundsError)");
+  }
+  // the reference records a label only inside sampleIndex (:426): nothing with Niter = 0
+  const bool trace = labels != nullptr && Niter > 0;
+  if (ngpus > Np) ngpus = static_cast<int>(Np);
+  std::vector<Shard> sh(ngpus);
+  DeviceGuard guard;
+  // launch everywhere first (uploads and kernels of different devices overlap), then collect
+  for (int g = 0; g < ngpus; ++g) {
+    Shard &S = sh[g];
+    S.device = device + g;
+    S.lo = share_begin(Np, g, ngpus);
+    S.hi = share_begin(Np, g + 1, ngpus);
+    const int64_t n = S.hi - S.lo;
+    rc = instantiate(im, S.device, &S.plan);
+    if (rc != KDEHIP_OK) return rc;
+    rc = guard.enter(S.device);
+    if (rc != KDEHIP_OK) return rc;
+    const int64_t useU = streams ? ((nU - S.lo * K < n * K) ? nU - S.lo * K : n * K) : 0, useN = streams ? n * R : 0;
+    const size_t off_n = align256(sizeof(double) * useU);
+    S.off_p = align256(off_n + sizeof(double) * useN);
+    S.off_i = align256(S.off_p + sizeof(double) * D * n);
+    S.off_l = align256(S.off_i + sizeof(int64_t) * M * n);
+    const size_t lab_bytes = trace ? sizeof(int32_t) * M * L * n : 0;
+    S.span = S.off_l + lab_bytes - S.off_p;
+    rc = reserve_work(S.plan, S.off_l + lab_bytes);
+    if (rc != KDEHIP_OK) return rc;
+    unsigned char *w = static_cast<unsigned char *>(S.plan->d_work);
+    double *dp = reinterpret_cast<double *>(w + S.off_p);
+    int64_t *di = reinterpret_cast<int64_t *>(w + S.off_i);
+    int32_t *dl = trace ? reinterpret_cast<int32_t *>(w + S.off_l) : nullptr;
+    if (streams) {
+      double *du = reinterpret_cast<double *>(w), *dn = reinterpret_cast<double *>(w + off_n);
+      // sample s of this shard reads element (s - lo)*K + c - 1 of its slice = element s*K + c - 1 of the caller's array
+      KDEHIP_CHECK(hipMemcpyAsync(du, randU + S.lo * K, sizeof(double) * useU, hipMemcpyHostToDevice, nullptr));
+      KDEHIP_CHECK(hipMemcpyAsync(dn, randN + S.lo * R, sizeof(double) * useN, hipMemcpyHostToDevice, nullptr));
+      rc = enqueue_streams(S.plan, n, Niter, du, useU, dn, useN, addEntropy, dp, di, dl, nullptr, /*private_plan=*/true);
+    } else {
+      rc = enqueue_philox(S.plan, n, Niter, seed, S.lo, addEntropy, dp, di, dl, nullptr, /*private_plan=*/true);
+    }
+    if (rc != KDEHIP_OK) return rc;
+    KDEHIP_CHECK(cached_host_malloc(&S.h_out, S.span));
+    KDEHIP_CHECK(hipMemcpyAsync(S.h_out, w + S.off_p, S.span, hipMemcpyDeviceToHost, nullptr));
+  }
+  for (int g = 0; g < ngpus; ++g) {
+    Shard &S = sh[g];
+    rc = guard.enter(S.device);
+    if (rc != KDEHIP_OK) return rc;
+    KDEHIP_CHECK(hipStreamSynchronize(nullptr));
+    const int64_t n = S.hi - S.lo;
+    const unsigned char *h = static_cast<const unsigned char *>(S.h_out);
+    std::memcpy(pts + S.lo * D, h, sizeof(double) * D * n);
+    std::memcpy(ind + S.lo * M, h + (S.off_i - S.off_p), sizeof(int64_t) * M * n);
+    if (trace) std::memcpy(labels + S.lo * M * L, h + (S.off_l - S.off_p), sizeof(int32_t) * M * L * n);
+  }
   return KDEHIP_OK;
 }
+
+}  // namespace
 
 int kdehip_gibbs1(int Ndens, const kdehip_density *trees, int64_t Np, int Niter, double *pts,
                   int64_t *ind, const double *randU, int64_t nU, const double *randN, int64_t nN,
                   int addEntropy, int ndims, const uint8_t *partialDimMask, int device) {
-  return kdehip_gibbs1_trace(Ndens, trees, Np, Niter, pts, ind, randU, nU, randN, nN, addEntropy, ndims,
-                             partialDimMask, device, nullptr);
+  return kdehip_gibbs1_multi(Ndens, trees, Np, Niter, pts, ind, randU, nU, randN, nN, addEntropy, ndims,
+                             partialDimMask, device, 1, nullptr);
 }
 
 int kdehip_gibbs1_trace(int Ndens, const kdehip_density *trees, int64_t Np, int Niter, double *pts,
                         int64_t *ind, const double *randU, int64_t nU, const double *randN, int64_t nN,
                         int addEntropy, int ndims, const uint8_t *partialDimMask, int device,
                         int32_t *labels) {
-  kdehip_product *plan = nullptr;
-  int rc = kdehip_product_create(&plan, Ndens, trees, ndims, partialDimMask, 64, device);
+  return kdehip_gibbs1_multi(Ndens, trees, Np, Niter, pts, ind, randU, nU, randN, nN, addEntropy, ndims,
+                             partialDimMask, device, 1, labels);
+}
+
+int kdehip_gibbs1_multi(int Ndens, const kdehip_density *trees, int64_t Np, int Niter, double *pts,
+                        int64_t *ind, const double *randU, int64_t nU, const double *randN, int64_t nN,
+                        int addEntropy, int ndims, const uint8_t *partialDimMask, int device, int ngpus,
+                        int32_t *labels) {
+  static const double kNone = 0.0;  // (a null stream pointer must mean "too short", not "use Philox")
+  return one_shot(Ndens, trees, Np, Niter, pts, ind, randU ? randU : &kNone, randU ? nU : 0, randN ? randN : &kNone,
+                  randN ? nN : 0, 0, addEntropy, ndims, partialDimMask, 64, device, ngpus, labels);
+}
+
+int kdehip_prod_philox(int Ndens, const kdehip_density *trees, int64_t Np, int Niter, double *pts, int64_t *ind,
+                       uint64_t seed, int addEntropy, int ndims, const uint8_t *partialDimMask, int precision,
+                       int device, int ngpus, int32_t *labels) {
+  return one_shot(Ndens, trees, Np, Niter, pts, ind, nullptr, 0, nullptr, 0, seed, addEntropy, ndims, partialDimMask,
+                  precision, device, ngpus, labels);
+}
+
+// ---- resident multi-GPU plans: one plan per device, chains in contiguous ranges, one all-gather ----------------
+struct kdehip_product_multi {
+  int first_device = 0, ngpus = 0;
+  std::vector<kdehip_product *> plans;
+  std::vector<hipEvent_t> done;  // per device: its slice has been written to every device
+};
+
+int kdehip_product_multi_create(kdehip_product_multi **out, int Ndens, const kdehip_density *trees, int ndims,
+                                const uint8_t *partialDimMask, int precision, int first_device, int ngpus) {
+  if (!out) return set_error(KDEHIP_ERR_ARG, "null out pointer");
+  *out = nullptr;
+  int rc = check_devices(first_device, ngpus);
   if (rc != KDEHIP_OK) return rc;
-  struct Guard { kdehip_product *p; ~Guard() { kdehip_product_destroy(p); } } guard{plan};
-  rc = check_run(plan, Np, Niter, pts, ind);
+  PlanImage im;
+  rc = build_image(im, Ndens, trees, ndims, partialDimMask, precision);
   if (rc != KDEHIP_OK) return rc;
+  kdehip_product_multi *mp = new (std::nothrow) kdehip_product_multi();
+  if (!mp) return set_error(KDEHIP_ERR_ALLOC, "out of host memory");
+  mp->first_device = first_device;
+  mp->ngpus = ngpus;
+  DeviceGuard guard;
+  for (int g = 0; g < ngpus && rc == KDEHIP_OK; ++g) {
+    kdehip_product *p = nullptr;
+    rc = instantiate(im, first_device + g, &p);
+    if (rc != KDEHIP_OK) break;
+    mp->plans.push_back(p);
+    rc = guard.enter(first_device + g);
+    if (rc != KDEHIP_OK) break;
+    hipEvent_t ev;
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { rc = set_error(KDEHIP_ERR_HIP, "hipEventCreate failed"); break; }
+    mp->done.push_back(ev);
+    // direct peer writes over xGMI where the topology allows them (hipMemcpyPeerAsync stages through the host otherwise)
+    for (int h = 0; h < ngpus; ++h) {
+      int can = 0;
+      if (h != g && hipDeviceCanAccessPeer(&can, first_device + g, first_device + h) == hipSuccess && can)
+        (void)hipDeviceEnablePeerAccess(first_device + h, 0);  // "already enabled" is fine
+    }
+    (void)hipGetLastError();
+  }
+  if (rc != KDEHIP_OK) { kdehip_product_multi_destroy(mp); return rc; }
+  *out = mp;
+  return KDEHIP_OK;
+}
+
+void kdehip_product_multi_destroy(kdehip_product_multi *mp) {
+  if (!mp) return;
+  DeviceGuard guard;
+  for (size_t g = 0; g < mp->done.size(); ++g)
+    if (guard.enter(mp->first_device + static_cast<int>(g)) == KDEHIP_OK) {
+      (void)hipDeviceSynchronize();
+      (void)hipEventDestroy(mp->done[g]);
+    }
+  for (kdehip_product *p : mp->plans) kdehip_product_destroy(p);
+  delete mp;
+}
+
+int kdehip_product_multi_ngpus(const kdehip_product_multi *mp) { return mp ? mp->ngpus : 0; }
+kdehip_product *kdehip_product_multi_plan(kdehip_product_multi *mp, int g) {
+  return (mp && g >= 0 && g < mp->ngpus) ? mp->plans[g] : nullptr;
+}
+
+int kdehip_product_multi_sample_philox(kdehip_product_multi *mp, int64_t Np, int Niter, uint64_t seed,
+                                       int64_t sample_offset, int addEntropy, double *const *d_points,
+                                       int64_t *const *d_indices, void *const *streams) {
+  if (!mp || !d_points || !d_indices) return set_error(KDEHIP_ERR_ARG, "null argument");
+  if (Np < 0) return set_error(KDEHIP_ERR_ARG, "Np must be >= 0");
   if (Np == 0) return KDEHIP_OK;
-  const int64_t K = kdehip_product_randu_per_sample(plan, Niter);
-  const int64_t R = kdehip_product_randn_per_sample(plan);
-  if (!randU || nU < Np * K - 1)
-    return set_error(KDEHIP_ERR_RAND_SHORT, "randU shorter than Np*K-1 values (Julia: BoundsError)");
-  if (!randN || nN < Np * R)
-    return set_error(KDEHIP_ERR_RAND_SHORT, "randN shorter than Np*R values (Julia: BoundsError)");
-  const size_t D = ndims, M = Ndens;
-  const int64_t useU = (nU < Np * K) ? nU : Np * K, useN = Np * R;
-  DeviceGuard dguard;
-  rc = dguard.enter(device);
-  if (rc != KDEHIP_OK) return rc;
-  std::lock_guard<std::mutex> lock(plan->work_mutex);
-  const size_t off_n = align256(sizeof(double) * useU);
-  const size_t off_p = align256(off_n + sizeof(double) * useN);
-  const size_t off_i = align256(off_p + sizeof(double) * D * Np);
-  const size_t off_l = align256(off_i + sizeof(int64_t) * M * Np);
-  // the reference records a label only inside sampleIndex (:426): nothing with Niter = 0
-  const bool trace = labels != nullptr && Niter > 0;
-  const size_t lab_bytes = trace ? sizeof(int32_t) * M * static_cast<size_t>(plan->host.L) * Np : 0;
-  rc = reserve_work(plan, off_l + lab_bytes);
-  if (rc != KDEHIP_OK) return rc;
-  unsigned char *w = static_cast<unsigned char *>(plan->d_work);
-  double *du = reinterpret_cast<double *>(w), *dn = reinterpret_cast<double *>(w + off_n);
-  double *dp = reinterpret_cast<double *>(w + off_p);
-  int64_t *di = reinterpret_cast<int64_t *>(w + off_i);
-  int32_t *dl = trace ? reinterpret_cast<int32_t *>(w + off_l) : nullptr;
-  KDEHIP_CHECK(hipMemcpy(du, randU, sizeof(double) * useU, hipMemcpyHostToDevice));
-  KDEHIP_CHECK(hipMemcpy(dn, randN, sizeof(double) * useN, hipMemcpyHostToDevice));
-  rc = enqueue_streams(plan, Np, Niter, du, useU, dn, useN, addEntropy, dp, di, dl, nullptr);
-  if (rc != KDEHIP_OK) return rc;
-  KDEHIP_CHECK(hipMemcpy(pts, dp, sizeof(double) * D * Np, hipMemcpyDeviceToHost));
-  KDEHIP_CHECK(hipMemcpy(ind, di, sizeof(int64_t) * M * Np, hipMemcpyDeviceToHost));
-  if (trace) KDEHIP_CHECK(hipMemcpy(labels, dl, lab_bytes, hipMemcpyDeviceToHost));
+  const int G = mp->ngpus;
+  const size_t D = mp->plans[0]->host.D, M = mp->plans[0]->host.M;
+  DeviceGuard guard;
+  for (int g = 0; g < G; ++g) {
+    const int64_t lo = share_begin(Np, g, G), hi = share_begin(Np, g + 1, G);
+    if (!d_points[g] || !d_indices[g]) return set_error(KDEHIP_ERR_ARG, "null output pointer");
+    int rc = guard.enter(mp->first_device + g);
+    if (rc != KDEHIP_OK) return rc;
+    hipStream_t st = static_cast<hipStream_t>(streams ? streams[g] : nullptr);
+    if (hi > lo) {
+      // global sample index = sample_offset + lo + s: the result does not depend on the number of devices
+      rc = enqueue_philox(mp->plans[g], hi - lo, Niter, seed, sample_offset + lo, addEntropy, d_points[g] + lo * D,
+                          d_indices[g] + lo * M, nullptr, st);
+      if (rc != KDEHIP_OK) return rc;
+      mp->plans[g]->async_pending.store(true);
+      // the all-gather of [pGM | indices]: device g writes its slice into every other device's arrays
+      for (int h = 0; h < G; ++h) {
+        if (h == g) continue;
+        KDEHIP_CHECK(hipMemcpyPeerAsync(d_points[h] + lo * D, mp->first_device + h, d_points[g] + lo * D,
+                                        mp->first_device + g, sizeof(double) * D * (hi - lo), st));
+        KDEHIP_CHECK(hipMemcpyPeerAsync(d_indices[h] + lo * M, mp->first_device + h, d_indices[g] + lo * M,
+                                        mp->first_device + g, sizeof(int64_t) * M * (hi - lo), st));
+      }
+    }
+    KDEHIP_CHECK(hipEventRecord(mp->done[g], st));
+  }
+  // every device's stream continues only once all slices have arrived in its arrays
+  for (int h = 0; h < G; ++h) {
+    int rc = guard.enter(mp->first_device + h);
+    if (rc != KDEHIP_OK) return rc;
+    hipStream_t st = static_cast<hipStream_t>(streams ? streams[h] : nullptr);
+    for (int g = 0; g < G; ++g)
+      if (g != h) KDEHIP_CHECK(hipStreamWaitEvent(st, mp->done[g], 0));
+  }
   return KDEHIP_OK;
 }
 

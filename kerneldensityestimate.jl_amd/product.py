@@ -137,6 +137,49 @@ class ProductPlan:
         return out
 
 
+class MultiProductPlan:
+    """One resident plan per GPU of a node, one process (kdehip_product_multi_*): chains in contiguous ranges, Philox
+    counters keyed by the global sample index, one all-gather of [pGM | indices] by peer writes over xGMI, after which
+    every device holds the complete result."""
+
+    def __init__(self, trees, partialDimMask=None, precision=64, first_device=0, ngpus=1, ndims=None):
+        trees = list(trees)
+        self.Ndens = len(trees)
+        self.ndims = int(ndims) if ndims is not None else max(Ndim(t) for t in trees)
+        arr = (_lib.CDensity * self.Ndens)(*[t._cstruct() for t in trees])
+        mask = _mask_array(partialDimMask, self.Ndens, self.ndims)
+        h = C.c_void_p()
+        _lib.check(_lib.lib.kdehip_product_multi_create(C.byref(h), self.Ndens, arr, self.ndims,
+                                                        None if mask is None else ptr(mask, u8p), int(precision),
+                                                        int(first_device), int(ngpus)))
+        self._h = h
+        self.first_device = int(first_device)
+        self.ngpus = int(_lib.lib.kdehip_product_multi_ngpus(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib.kdehip_product_multi_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def sample_philox_device(self, Np, Niter, seed, sample_offset, addEntropy, d_points, d_indices, streams=None):
+        """d_points / d_indices: one device array (torch tensor or address) per GPU; enqueue only."""
+        G = self.ngpus
+        P = (C.c_void_p * G)(*[ProductPlan._addr(x) for x in d_points])
+        I = (C.c_void_p * G)(*[ProductPlan._addr(x) for x in d_indices])
+        S = None if streams is None else (C.c_void_p * G)(*[ProductPlan._addr(x) for x in streams])
+        _lib.check(_lib.lib.kdehip_product_multi_sample_philox(self._h, int(Np), int(Niter),
+                                                               C.c_uint64(int(seed) & (2 ** 64 - 1)), int(sample_offset),
+                                                               int(bool(addEntropy)), P, I, S))
+
+
 def philox_streams(seed, sample_begin, nsamples, K, R):
     """Host twin of the device RNG: the (randU, randN) arrays a Philox run consumes
     (kdehip_philox_fill_uniform / _normal)."""
@@ -171,7 +214,7 @@ def makeEmptyGbGlb(recordChoosen=False):
 
 
 def gibbs1(Ndens, trees, Np, Niter, pts, ind, randU, randN, *, addEntropy=True, ndims=None,
-           partialDimMask=None, glbs=None, device=0):
+           partialDimMask=None, glbs=None, device=0, ngpus=1):
     """`gibbs1` (reference src/MSGibbs01.jl:527-537): fills the caller's `pts` (length ndims*Np,
     column-major) and `ind` (Ndens x Np, column-major) in place; returns None.  With
     `glbs.recordChoosen` the label trace lands in `glbs.labelsChoosen` as in the reference."""
@@ -191,10 +234,10 @@ def gibbs1(Ndens, trees, Np, Niter, pts, ind, randU, randN, *, addEntropy=True, 
     labels = None
     if glbs is not None and glbs.recordChoosen:
         labels = np.zeros((Np, Ndens, nlevels(max(Npts(t) for t in trees))), dtype=np.int32)
-    _lib.check(_lib.lib.kdehip_gibbs1_trace(int(Ndens), arr, int(Np), int(Niter), ptr(pts.reshape(-1), f64p),
+    _lib.check(_lib.lib.kdehip_gibbs1_multi(int(Ndens), arr, int(Np), int(Niter), ptr(pts.reshape(-1), f64p),
                                             ptr(tmp_ind, i64p), ptr(randU, f64p), randU.size, ptr(randN, f64p),
                                             randN.size, int(bool(addEntropy)), int(ndims),
-                                            None if mask is None else ptr(mask, u8p), int(device),
+                                            None if mask is None else ptr(mask, u8p), int(device), int(ngpus),
                                             None if labels is None else ptr(labels, i32p)))
     if labels is not None:
         glbs._fill(labels, Niter)
@@ -208,7 +251,7 @@ def gibbs1(Ndens, trees, Np, Niter, pts, ind, randU, randN, *, addEntropy=True, 
 def prodAppxMSGibbsS(npd0, trees, anFcns=None, anParams=None, *deprecated_niter, Niter=3, addEntropy=True, ndims=None,
                      Ndens=None, Np=None, maxNp=None, Nlevels=None, randU=None, randN=None, partialDimMask=None,
                      addop=None, diffop=None, getMu=None, getLambda=None, glbs=None,
-                     seed=None, device=0, precision=64):
+                     seed=None, device=0, precision=64, ngpus=1):
     """`prodAppxMSGibbsS` (reference src/MSGibbs01.jl:645-703).
 
     npd0 only supplies Np = Npts(npd0) (:658); anFcns/anParams are ignored as in the reference
@@ -242,17 +285,24 @@ def prodAppxMSGibbsS(npd0, trees, anFcns=None, anParams=None, *deprecated_niter,
         points = np.zeros(ndims * Np)
         indices = np.ones((Ndens, Np), dtype=np.int64)
         gibbs1(Ndens, trees, Np, Niter, points, indices, randU, randN, addEntropy=addEntropy, ndims=ndims,
-               partialDimMask=partialDimMask, glbs=glbs, device=device)
+               partialDimMask=partialDimMask, glbs=glbs, device=device, ngpus=ngpus)
         return points.reshape(Np, ndims).T.copy(), indices
     if seed is None:
         seed = int.from_bytes(os.urandom(8), "little")
     trace = glbs is not None and glbs.recordChoosen
-    with ProductPlan(trees[:Ndens], partialDimMask=partialDimMask, precision=precision, device=device,
-                     ndims=ndims) as plan:
-        out = plan.sample(Np, Niter=Niter, seed=seed, addEntropy=addEntropy, want_labels=trace)
+    trees = trees[:Ndens]
+    arr = (_lib.CDensity * Ndens)(*[t._cstruct() for t in trees])
+    mask = _mask_array(partialDimMask, Ndens, ndims)
+    pts = np.zeros(ndims * Np)
+    ind = np.ones(Ndens * Np, dtype=np.int64)
+    labels = np.zeros((Np, Ndens, nlevels(max(Npts(t) for t in trees))), dtype=np.int32) if trace else None
+    _lib.check(_lib.lib.kdehip_prod_philox(int(Ndens), arr, int(Np), int(Niter), ptr(pts, f64p), ptr(ind, i64p),
+                                           C.c_uint64(int(seed) & (2 ** 64 - 1)), int(bool(addEntropy)), int(ndims),
+                                           None if mask is None else ptr(mask, u8p), int(precision), int(device),
+                                           int(ngpus), None if labels is None else ptr(labels, i32p)))
     if trace:
-        glbs._fill(out[2], Niter)
-    return out[0], out[1]
+        glbs._fill(labels, Niter)
+    return pts.reshape(Np, ndims).T.copy(), ind.reshape(Np, Ndens).T.copy()
 
 
 def mul(trees, *, glbs=None, addEntropy=True, seed=None, device=0):

@@ -1,0 +1,98 @@
+"""Multi-GPU entry points of the C ABI (one process, one plan per device; include/kdehip.h sections 1 and 2b).
+The GPU boxes of the test pool have ONE device: the one-device degenerate path must reproduce the single-GPU entry
+points bit for bit, a device range beyond the visible devices must be refused, and where a second device exists the
+two-device results must equal the one-device results (chains are independent; Philox counters use the global index)."""
+import numpy as np
+import pytest
+
+import kdehip
+from oracle import oracle
+from tests.helpers import silverman_bw, synth_mixture
+
+pytestmark = pytest.mark.gpu
+
+
+def _trees(seed, D, M, N):
+    rng = np.random.default_rng(seed)
+    g, o = [], []
+    for _ in range(M):
+        pts = synth_mixture(rng, D, N)
+        ks = silverman_bw(pts)
+        g.append(kdehip.kde(pts, ks))
+        o.append(oracle.OracleDensity(pts, ks))
+    return g, o
+
+
+def test_one_shot_philox_equals_resident_plan_and_oracle():
+    D, M, N, Np, Niter, seed = 3, 3, 300, 257, 4, 99
+    g, o = _trees(1, D, M, N)
+    with kdehip.ProductPlan(g) as plan:
+        ref = plan.sample(Np, Niter=Niter, seed=seed, want_labels=True)
+        K, R = plan.randu_per_sample(Niter), plan.randn_per_sample()
+    glbs = kdehip.makeEmptyGbGlb(recordChoosen=True)
+    pts, ind = kdehip.prodAppxMSGibbsS(None, g, None, None, Niter=Niter, Np=Np, seed=seed, glbs=glbs, ngpus=1)
+    assert np.array_equal(pts, ref[0]) and np.array_equal(ind, ref[1])
+    L = ref[2].shape[2]
+    assert [glbs.labelsChoosen[5][2][l + 1] for l in range(L)] == list(ref[2][4, 1])
+    u, n = kdehip.philox_streams(seed, 0, Np, K, R)
+    op, oi = oracle.gibbs1(o, Np, Niter, u, n)
+    assert np.array_equal(ind, oi) and np.allclose(pts, op, rtol=1e-11, atol=1e-11)
+    # the drop-in with the same numbers as caller streams, through the multi entry with one device
+    p2 = np.zeros(D * Np)
+    i2 = np.ones((M, Np), dtype=np.int64)
+    kdehip.gibbs1(M, g, Np, Niter, p2, i2, u, n, ngpus=1)
+    assert np.array_equal(i2, oi) and np.allclose(p2.reshape(Np, D).T, op, rtol=1e-11, atol=1e-11)
+    # fp32 one-shot = fp32 resident plan
+    with kdehip.ProductPlan(g, precision=32) as p32:
+        r32 = p32.sample(Np, Niter=Niter, seed=seed)
+    q32 = kdehip.prodAppxMSGibbsS(None, g, None, None, Niter=Niter, Np=Np, seed=seed, precision=32)
+    assert np.array_equal(q32[0], r32[0]) and np.array_equal(q32[1], r32[1])
+
+
+def test_resident_multi_plan_with_one_device_equals_single_plan():
+    import torch
+    D, M, N, Np, Niter, seed = 6, 4, 500, 300, 3, 5
+    g, _ = _trees(2, D, M, N)
+    dev = torch.device("cuda", 0)
+    with kdehip.ProductPlan(g) as plan:
+        ref = plan.sample(Np, Niter=Niter, seed=seed, sample_offset=40)
+    with kdehip.MultiProductPlan(g, first_device=0, ngpus=1) as mp:
+        assert mp.ngpus == 1
+        P = torch.zeros(D * Np, dtype=torch.float64, device=dev)
+        I = torch.zeros(M * Np, dtype=torch.int64, device=dev)
+        st = torch.cuda.Stream(device=dev)
+        mp.sample_philox_device(Np, Niter, seed, 40, True, [P], [I], [st.cuda_stream])
+        st.synchronize()
+        assert np.array_equal(P.cpu().numpy().reshape(Np, D).T, ref[0])
+        assert np.array_equal(I.cpu().numpy().reshape(Np, M).T, ref[1])
+        mp.sample_philox_device(Np, Niter, seed, 40, True, [P], [I])   # null streams
+        torch.cuda.synchronize()
+        assert np.array_equal(I.cpu().numpy().reshape(Np, M).T, ref[1])
+
+
+def test_device_range_beyond_the_visible_devices_is_refused():
+    g, _ = _trees(3, 2, 2, 50)
+    n = kdehip.device_count()
+    with pytest.raises(kdehip.KdeHipError) as ei:
+        kdehip.prodAppxMSGibbsS(None, g, None, None, Np=10, seed=1, ngpus=n + 1)
+    assert ei.value.code == -1
+    with pytest.raises(kdehip.KdeHipError):
+        kdehip.MultiProductPlan(g, first_device=0, ngpus=n + 1)
+
+
+@pytest.mark.skipif(kdehip.device_count() < 2, reason="needs two visible GPUs")
+def test_two_devices_equal_one_device():
+    import torch
+    D, M, N, Np, Niter, seed = 3, 3, 400, 501, 3, 8
+    g, _ = _trees(4, D, M, N)
+    one = kdehip.prodAppxMSGibbsS(None, g, None, None, Niter=Niter, Np=Np, seed=seed, ngpus=1)
+    two = kdehip.prodAppxMSGibbsS(None, g, None, None, Niter=Niter, Np=Np, seed=seed, ngpus=2)
+    assert np.array_equal(one[0], two[0]) and np.array_equal(one[1], two[1])
+    with kdehip.MultiProductPlan(g, first_device=0, ngpus=2) as mp:
+        Ps = [torch.zeros(D * Np, dtype=torch.float64, device=torch.device("cuda", d)) for d in range(2)]
+        Is = [torch.zeros(M * Np, dtype=torch.int64, device=torch.device("cuda", d)) for d in range(2)]
+        mp.sample_philox_device(Np, Niter, seed, 0, True, Ps, Is)
+        for d in range(2):
+            torch.cuda.synchronize(d)
+            assert np.array_equal(Ps[d].cpu().numpy().reshape(Np, D).T, one[0])   # every device holds everything
+            assert np.array_equal(Is[d].cpu().numpy().reshape(Np, M).T, one[1])

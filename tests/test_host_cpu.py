@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol():
     from importlib import import_module
     bound = set(import_module("kdehip._lib").SIGNATURES)
     assert declared == bound, declared ^ bound
-    assert kdehip.version() == 100
+    assert kdehip.version() == 200
 
 
 def test_product_tree_builder_matches_reference_goldens(golden_dir):
