@@ -10,11 +10,14 @@ product samples over RCCL.  Weak scaling: per-GPU work is fixed.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line.  `roofline.achieved` = algorithmic bytes (Nout * E * B,
-E = (Niter+1) * sum_j sum_l n_{j,l} kernel evaluations per sample, B = (2D+1)*8 bytes) divided by
-the kernel's average duration measured with HIP events on the launch stream.  The working set
-(832 KB) is cache resident, so this is a normalised throughput against the 8 TB/s HBM peak, not
-DRAM traffic; `traffic` carries the PMC-measured HBM bytes per launch when a profile is committed.
+Rank 0 prints ONE JSON line.  The path is bound by vector-ALU issue, not by memory (the working set, 832 KB at
+config 3, is LDS/L2 resident; PMC-measured HBM traffic is ~10 MB per launch): `roofline` therefore reports the
+algorithmic fp64 (fp32) flops of the kernel evaluations -- E * (6D+4) per sample, E = (Niter+1) * sum_j sum_l
+n_{j,l} -- per second of kernel time (HIP events on the launch stream) against the MI355X vector
+peak, and `traffic` carries the PMC-measured HBM bytes per launch of the committed profile.  SURVEY.md 8(d)'s
+"algorithmic bytes / 8 TB/s" figure is kept as `normalised_hbm` (a throughput normalisation, not a roofline: it
+exceeds 1).  `call_inclusive` times the calls a drop-in user makes (pack + upload + kernel + copy back).
+--strong splits the configuration's TOTAL chain count over the ranks instead of giving every rank a full batch.
 """
 import argparse
 import json
@@ -36,6 +39,9 @@ CONFIGS = {
     "c4": (3, 8, 5000, 2048, 10, 64, 4),      # 16384 over 8 GPUs
     "c5": (6, 4, 10000, 8192, 20, 32, 5),     # 65536 over 8 GPUs, fp32
 }
+# chains of the whole job as BASELINE.json states the configs (--strong splits these over the ranks)
+TOTAL_NOUT = {"c2": 256, "c3": 2048, "c4": 16384, "c5": 65536}
+VALU_PEAK_TFLOPS = {64: 78.6, 32: 157.3}  # MI355X vector peaks: 256 CU x 4 SIMD x 16 (32) lanes x 2 flop x 2.4 GHz
 
 
 def synth_inputs(kdehip, D, M, N, config_id):
@@ -69,16 +75,17 @@ def usable_cores():
 
 
 def load_traffic(workload):
-    """HBM bytes per launch from the committed PMC profile (profiles/traffic_latest.json), or None."""
+    """The committed PMC profile of this workload (profiles/traffic_latest.json): HBM bytes per launch and the
+    issue-slot counters, or an empty dict."""
     p = os.path.join(ROOT, "profiles", "traffic_latest.json")
     try:
         with open(p) as f:
             t = json.load(f)
         if t.get("workload") == workload:
-            return t.get("hbm_bytes_per_launch")
+            return t
     except (OSError, ValueError):
         pass
-    return None
+    return {}
 
 
 def main():
@@ -90,6 +97,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--nout", type=int, default=0, help="override chains per GPU (experiments; 0 = the config's)")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: the configuration's TOTAL chain count split over the ranks")
     args = ap.parse_args()
 
     import torch
@@ -126,7 +135,13 @@ def main():
     D, M, N, Nout, Niter, prec, cid = CONFIGS[args.config]
     if args.nout > 0:
         Nout = args.nout
-    workload = f"{args.config}: {D}-D, {M} densities x {N} pts, Nout={Nout}/GPU, Niter={Niter}, fp{prec}"
+    if args.strong:
+        Np_total = TOTAL_NOUT[args.config] if args.nout <= 0 else args.nout
+        Nout = (Np_total + world - 1) // world   # chains of the largest shard (what one launch processes)
+    else:
+        Np_total = Nout * world
+    workload = (f"{args.config}: {D}-D, {M} densities x {N} pts, Nout={Np_total} total over {world} GPU(s), Niter={Niter}, fp{prec}"
+                if args.strong else f"{args.config}: {D}-D, {M} densities x {N} pts, Nout={Nout}/GPU, Niter={Niter}, fp{prec}")
     pts_all, bw_all = synth_inputs(kdehip, D, M, N, cid)
     trees = [kdehip.kde(p, b) for p, b in zip(pts_all, bw_all)]
     plan = kdehip.ProductPlan(trees, precision=prec, device=dev_index)
@@ -134,7 +149,6 @@ def main():
         plan.set_variant(args.variant)
     sp = ShardedProduct(plan, dev)
     seed = 20260101
-    Np_total = Nout * world
 
     def step(i):  # warm-up: both buffer slots of the pipelined timed loop get their first kernel and gather here
         return sp.sample_async(Np_total, Niter=Niter, seed=seed, sample_base=i * Np_total, slot=i & 1).result()
@@ -187,10 +201,15 @@ def main():
         kern_ms = float(t.item())
 
     if rank == 0:
+        import shutil
         E = plan.evals_per_sample(Niter)
         B = plan.bytes_per_eval
-        alg_bytes = float(Nout) * E * B
-        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        flops_per_eval = 6 * D + 4
+        alg_bytes = float(hi - lo) * E * B
+        alg_flops = float(hi - lo) * E * flops_per_eval
+        achieved_tf = alg_flops / (kern_ms * 1e-3) / 1e12
+        peak_tf = VALU_PEAK_TFLOPS[prec]
+        prof = load_traffic(args.config)
         out = {
             "metric": "gibbs_product_samples_per_sec",
             "value": Np_total * args.steps / elapsed,
@@ -200,30 +219,35 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None,
             "dtype": "f64" if prec == 64 else "f32",
             "data": "synthetic",
+            "julia": "present" if shutil.which("julia") else "absent",
             "config": {"workload": workload, "ndims": D, "ndens": M, "npts": N, "nout_per_gpu": Nout,
                        "nout_total": Np_total, "niter": Niter, "rng": "device philox4x32-10",
-                       "evals_per_sample": E, "bytes_per_eval": B,
+                       "evals_per_sample": E, "bytes_per_eval": B, "flops_per_eval": flops_per_eval,
                        "parallelism": f"chains sharded over {world} GPU(s), 1 all-gather"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(args.config),
-                         "kernel": "gibbs_product_kernel", "kernel_ms": kern_ms,
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "working set is cache-resident: normalised throughput vs HBM peak, not DRAM traffic"},
-            # second view of the same kernel: the path is bound by the fp64 vector pipe, not by HBM.  Algorithmic
-            # flops per kernel evaluation = 6D+4; 78.6 TFLOP/s = MI355X fp64 vector peak (fp32: 157.3).
-            "compute": {"bound": "valu", "flops_per_eval": 6 * D + 4,
-                        "achieved": Nout * E * (6 * D + 4) / (kern_ms * 1e-3) / 1e12,
-                        "peak": 78.6 if prec == 64 else 157.3, "unit": "TFLOP/s",
-                        "frac": Nout * E * (6 * D + 4) / (kern_ms * 1e-3) / 1e12 / (78.6 if prec == 64 else 157.3),
-                        "note": "algorithmic flops only (exp, rsqrt, scans, selection not counted); measured VALU pipe "
-                                "utilisation is in profiles/*_rocprof_summary.md"},
-            "kernel_samples_per_sec": Nout / (kern_ms * 1e-3),
+            # The binding resource: vector-ALU issue.  achieved = algorithmic flops of the kernel evaluations (exp, rsqrt,
+            # scans and selection not counted) per second of kernel time; peak = the MI355X vector peak of the dtype.
+            "roofline": {"bound": "valu", "achieved": achieved_tf, "peak": peak_tf, "unit": "TFLOP/s",
+                         "frac": achieved_tf / peak_tf, "traffic": prof.get("hbm_bytes_per_launch"),
+                         "kernel": "gibbs_lean_kernel" if (2 <= M <= 4) else "gibbs_product_kernel", "kernel_ms": kern_ms,
+                         "algorithmic_flops_per_launch": alg_flops,
+                         # issue-slot view from the committed PMC profile of this workload (profiles/): instructions the
+                         # wavefronts issued per chain against the 4-cycle issue slots of their lifetime
+                         "issue": prof.get("issue"),
+                         "note": "working set is LDS/L2 resident (HBM traffic ~0.1 % of peak): bound by vector issue + per-step latency"},
+            # SURVEY.md 8(d)'s figure, kept for continuity: algorithmic bytes / kernel time against 8 TB/s.  NOT a roofline
+            # (the bytes never come from HBM; the ratio exceeds 1).
+            "normalised_hbm": {"achieved_GBps": alg_bytes / (kern_ms * 1e-3) / 1e9, "peak_GBps": HBM_PEAK_GBS,
+                               "ratio": alg_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "algorithmic_bytes_per_launch": alg_bytes},
+            "kernel_samples_per_sec": (hi - lo) / (kern_ms * 1e-3),
             "fast_math_path": plan.fast_math_path,
         }
+        if world == 1:
+            out["call_inclusive"] = call_inclusive(kdehip, trees, plan, D, M, Nout, Niter, seed, prec)
         if world == 1 and not args.no_cpu_baseline:
             out.update(cpu_baseline_and_parity(kdehip, plan, pts_all, bw_all, D, M, N, Nout, Niter, seed, args.warmup))
     if use_dist:
@@ -235,6 +259,33 @@ def main():
         os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
         os.dup2(2, 1)
+
+
+def call_inclusive(kdehip, trees, plan, D, M, Nout, Niter, seed, prec):
+    """What a drop-in caller sees (wall time of one prodAppxMSGibbsS-equivalent call, host buffers in and
+    out): median of 15 calls each of (a) prodAppxMSGibbsS with the device Philox stream = pack + upload + [table build]
+    + kernel + copy back (kdehip_prod_philox), (b) the gibbs1 drop-in with caller-supplied randU/randN, which
+    additionally uploads the streams over PCIe (kdehip_gibbs1), (c) a run of the resident plan + copy back."""
+    K, R = plan.randu_per_sample(Niter), plan.randn_per_sample()
+    randU, randN = kdehip.philox_streams(seed, 0, Nout, K, R)
+
+    def med(f, n=15):
+        f()
+        f()
+        ts = []
+        for _ in range(n):
+            t = time.perf_counter()
+            f()
+            ts.append(time.perf_counter() - t)
+        return float(np.median(ts)) * 1e3
+    t_prod = med(lambda: kdehip.prodAppxMSGibbsS(None, trees, None, None, Niter=Niter, Np=Nout, seed=seed, precision=prec))
+    t_g1 = med(lambda: kdehip.prodAppxMSGibbsS(None, trees, None, None, Niter=Niter, Np=Nout, randU=randU, randN=randN)) \
+        if prec == 64 else None
+    t_res = med(lambda: plan.sample(Nout, Niter=Niter, seed=seed))
+    return {"ms": t_prod, "samples_per_sec": Nout / (t_prod * 1e-3),
+            "what": "prodAppxMSGibbsS, device Philox: pack + H2D + kernel + D2H, host buffers in and out (median of 15)",
+            "gibbs1_caller_streams_ms": t_g1, "randU_MB_over_pcie": randU.nbytes / 1e6,
+            "resident_plan_run_plus_d2h_ms": t_res}
 
 
 def cpu_baseline_and_parity(kdehip, plan, pts_all, bw_all, D, M, N, Nout, Niter, seed, warmup):

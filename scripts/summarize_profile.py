@@ -44,7 +44,7 @@ def counters(d, sub, match):
 
 def main():
     tag = sys.argv[1]
-    match = sys.argv[2] if len(sys.argv) > 2 else "gibbs_product_kernel"
+    match = sys.argv[2] if len(sys.argv) > 2 else "gibbs_lean_kernel"
     workload = sys.argv[3] if len(sys.argv) > 3 else "c3"
     calib = float(sys.argv[4]) if len(sys.argv) > 4 else 2.0
     d = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
@@ -88,6 +88,20 @@ def main():
         out["valu_pipe_busy_frac_lower_bound"] = pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / simd_cycles
         if "SQ_INSTS_VALU" in pmc and "SQ_WAVES" in pmc:
             out["valu_insts_per_chain"] = pmc["SQ_INSTS_VALU"] / pmc["SQ_WAVES"]
+    # Issue-slot view (what binds the kernel): a wavefront issues at most one instruction per 4-cycle slot of its
+    # SIMD; SQ_WAVE_CYCLES and SQ_ACTIVE_INST_* count those slots ("quads") summed over wavefronts.
+    if all(k in pmc for k in ("SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS")):
+        nw = pmc["SQ_WAVES"]
+        out["issue"] = {
+            "valu_insts_per_chain": pmc["SQ_INSTS_VALU"] / nw,
+            "salu_insts_per_chain": pmc["SQ_INSTS_SALU"] / nw,
+            "lds_insts_per_chain": pmc["SQ_INSTS_LDS"] / nw,
+            "issue_slots_per_chain": pmc["SQ_WAVE_CYCLES"] / nw,
+            "slots_issuing_frac": pmc.get("SQ_ACTIVE_INST_ANY", float("nan")) / pmc["SQ_WAVE_CYCLES"],
+            "slots_waiting_for_data_frac": pmc.get("SQ_WAIT_ANY", float("nan")) / pmc["SQ_WAVE_CYCLES"],
+            "slots_waiting_to_issue_frac": pmc.get("SQ_WAIT_INST_ANY", float("nan")) / pmc["SQ_WAVE_CYCLES"],
+            "unit": "4-cycle issue slots of one wavefront (SQ 'quad' cycles); tag " + tag,
+        }
     bench = {}
     try:
         bench = json.loads(open(os.path.join(d, "bench_stats.json")).read().strip().splitlines()[-1])
@@ -101,7 +115,8 @@ def main():
     if "hbm_bytes_per_launch" in out:
         with open(os.path.join(ROOT, "profiles", "traffic_latest.json"), "w") as f:
             json.dump({"workload": workload, "tag": tag, "hbm_bytes_per_launch": out["hbm_bytes_per_launch"],
-                       "raw_bytes": out["hbm_bytes_per_launch_raw"], "fetch_calibration": calib}, f, indent=1)
+                       "raw_bytes": out["hbm_bytes_per_launch_raw"], "fetch_calibration": calib,
+                       "issue": out.get("issue")}, f, indent=1)
     lines = [f"# rocprofv3 summary `{tag}` ({workload})", "",
              "Command (on the MI355X box): `scripts/profile_gpu.sh " + tag + "` = `rocprofv3 --kernel-trace --stats -- python3 bench.py "
              "--steps 20 --warmup 3 --no-cpu-baseline` plus separate `--pmc` passes.", "",
@@ -116,6 +131,11 @@ def main():
     if "hbm_bytes_per_launch" in out:
         lines += [f"HBM bytes per launch: raw (FETCH_SIZE+WRITE_SIZE)*1024 = {out['hbm_bytes_per_launch_raw']:.4g}; "
                   f"with FETCH_SIZE x {calib} = {out['hbm_bytes_per_launch']:.4g}", ""]
+    if "issue" in out:
+        i = out["issue"]
+        lines += [f"issue slots per chain: {i['issue_slots_per_chain']:.0f}; instructions per chain: VALU {i['valu_insts_per_chain']:.0f}, "
+                  f"SALU {i['salu_insts_per_chain']:.0f}, LDS {i['lds_insts_per_chain']:.0f}; slots issuing {i['slots_issuing_frac']:.3f}, "
+                  f"waiting for data {i['slots_waiting_for_data_frac']:.3f}, waiting to issue {i['slots_waiting_to_issue_frac']:.3f}", ""]
     if "valu_pipe_busy_frac_lower_bound" in out:
         lines += [f"fp64 VALU pipe busy (lower bound, 2.4 GHz): {out['valu_pipe_busy_frac_lower_bound']:.3f}; "
                   f"VALU instructions per chain: {out.get('valu_insts_per_chain', float('nan')):.0f}", ""]
