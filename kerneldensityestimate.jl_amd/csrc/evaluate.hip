@@ -155,33 +155,6 @@ __global__ void eval_finish_kernel(const FinishBatch batch, int loo) {
   pb.out[pb.out_idx ? pb.out_idx[q] : q] = p;
 }
 
-// Leave-one-out finish fused with the entropy reduction of nLOO_LL: block b of problem y writes
-// hpart[y][b] = sum over its queries of W_q * log(p_q)  (evalAvgLogL, src/DualTree01.jl:450-474;
-// a zero likelihood that carries weight makes the log-likelihood -Inf, :460-463).
-constexpr int kFinishThreads = 256;
-__global__ __launch_bounds__(kFinishThreads) void loo_entropy_kernel(const FinishBatch batch,
-                                                                   double *__restrict__ hpart, int nblocks) {
-  __shared__ double red[kFinishThreads];
-  const FinishProblem &pb = batch.p[blockIdx.y];
-  const int64_t q = static_cast<int64_t>(blockIdx.x) * kFinishThreads + threadIdx.x;
-  double term = 0.0;
-  if (q < pb.Nq) {
-    double s = 0.0;
-    for (int c = 0; c < pb.nchunks; ++c) s += pb.partial[static_cast<int64_t>(c) * pb.Nq + q];
-    const double w = pb.w[q];
-    const double p = s * pb.inv_norm / (1.0 - w);
-    if (p == 0.0) term = (w != 0.0) ? -INFINITY : 0.0;
-    else term = log(p) * w;
-  }
-  red[threadIdx.x] = term;
-  __syncthreads();
-  for (int off = kFinishThreads / 2; off > 0; off >>= 1) {
-    if (static_cast<int>(threadIdx.x) < off) red[threadIdx.x] += red[threadIdx.x + off];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) hpart[blockIdx.y * nblocks + blockIdx.x] = red[0];
-}
-
 template <int D>
 void launch_partial(const EvalBatch &d_problems, int nprob, int64_t maxNq, int ngroups, int loo,
                     hipStream_t st) {
@@ -283,27 +256,84 @@ extern "C" int kdehip_evaluate(const kdehip_density *bd, const double *pos, int6
 }
 
 // ---- kde!(points): per-dimension LOOCV bandwidth ------------------------------------------------------
+// The whole search runs on the device: a preparation kernel (sort of every marginal + the bottom-up interval
+// arithmetic that stands in for the marginal's ball tree), then rounds of two launches -- the all-pairs
+// leave-one-out sums of all D one-dimensional problems, and the fused finish + log-likelihood reduction -- that are
+// enqueued back to back WITHOUT host synchronisation: the golden-section state machine of every dimension
+// (golden, src/CrossValidation.jl:44-98) lives in device memory and is advanced in the prologue of the round's
+// first kernel (every block redoes the few dozen scalar operations; block 0 of a dimension stores the result in
+// the other half of a double-buffered state).  The host only looks at the state after a batch of rounds.
 
 namespace {
 
-// Host state of one 1-D golden-section search (golden, src/CrossValidation.jl:44-98).
+constexpr double kGoldenTol = 1e-2;  // ksize, src/CrossValidation.jl:116
+constexpr int kPrepThreads = 1024;
+constexpr int64_t kPrepMaxN = 4096;  // marginals up to this size are prepared on the device (LDS: 40 bytes per point)
+
+// State of one 1-D golden-section search (golden, src/CrossValidation.jl:44-98) + what ksize needs around it.
 struct Golden {
   double x0, x1, x2, x3, f1, f2;
   double minm, maxm;
   double bcur;        // current leaf variance of the search density (drifts like the reference's (b*a)/a)
-  int phase;          // 0: needs f1, 1: needs f2, 2: iterating, 3: done
-  int pending;        // which of f1/f2 the evaluation in flight fills (1 or 2)
   double alpha;       // argument of the evaluation in flight
-  int nevals;
+  double bw_eval;     // bcur * alpha^2: the variance that evaluation uses
   double result;
+  int phase;          // 0: needs f1, 1: needs f2, 2: iterating, 3: done
+  int pending;        // which of f1/f2 the evaluation in flight fills (1 or 2), 0 = none
+  int nevals;
+  int pad_;
 };
+
+// Initial bracket of ksize (src/CrossValidation.jl:110-120) from neighborMinMax (:100-108).
+__host__ __device__ inline void golden_init(Golden &s, double minm, double maxm) {
+  if (minm < 1e-6) minm = 1e-6;
+  const double mid = (minm + maxm) / 2.0;
+  s.minm = minm; s.maxm = maxm; s.bcur = mid * mid;
+  const double ax = 2.0 * minm / (minm + maxm), bx = 1.0, cx = 2.0 * maxm / (minm + maxm);
+  const double C = (3.0 - sqrt(5.0)) / 2.0;
+  s.x0 = ax; s.x3 = cx;
+  if (fabs(cx - bx) > fabs(bx - ax)) { s.x1 = bx; s.x2 = bx + C * (cx - bx); }
+  else { s.x1 = bx - C * (bx - ax); s.x2 = bx; }
+  s.phase = 0; s.nevals = 0; s.pending = 0; s.alpha = 0; s.bw_eval = 0; s.f1 = s.f2 = 0; s.result = 0;
+}
+
+// The state machine in two halves.  book: the evaluation that was in flight has finished (its block partials of
+// W*log p are in `hpart`, summed in block order); decide: what to evaluate next, or finish.
+__host__ __device__ inline void golden_book(Golden &s, const double *hpart, int nfb) {
+  if (s.phase == 3 || !s.pending) return;
+  double ll = 0.0;
+  for (int b = 0; b < nfb; ++b) ll += hpart[b];
+  const double H = -ll;  // entropy = -evalAvgLogL (src/DualTree01.jl:505-508); -(-Inf) = +Inf
+  const double a2 = s.alpha * s.alpha;
+  s.bcur = (s.bcur * a2) / a2;  // nLOO_LL: bandwidth *= alpha^2 ... /= alpha^2 (src/CrossValidation.jl:15-24)
+  s.nevals += 1;
+  if (s.pending == 1) s.f1 = H; else s.f2 = H;
+  if (s.phase < 2) s.phase += 1;
+  s.pending = 0;
+}
+__host__ __device__ inline void golden_decide(Golden &s) {
+  const double C = (3.0 - sqrt(5.0)) / 2.0, R = 1.0 - C;
+  if (s.phase == 3) return;
+  if (s.phase == 0) { s.alpha = s.x1; s.pending = 1; }
+  else if (s.phase == 1) { s.alpha = s.x2; s.pending = 2; }
+  else {
+    if (!(fabs(s.x3 - s.x0) > kGoldenTol * (fabs(s.x1) + fabs(s.x2)))) {
+      s.result = (s.f1 < s.f2) ? s.x1 : s.x2;
+      s.phase = 3;
+      return;
+    }
+    if (s.f2 < s.f1) { s.x0 = s.x1; s.x1 = s.x2; s.x2 = R * s.x1 + C * s.x3; s.f1 = s.f2; s.alpha = s.x2; s.pending = 2; }
+    else { s.x3 = s.x2; s.x2 = s.x1; s.x1 = R * s.x2 + C * s.x0; s.f2 = s.f1; s.alpha = s.x1; s.pending = 1; }
+  }
+  s.bw_eval = s.bcur * (s.alpha * s.alpha);
+}
 
 // Bounding interval (centre, half-range) of the 1-D ball-tree node that covers the sorted ranks
 // [a, b], computed bottom-up exactly as calcStatsBall! does (src/BallTree01.jl:282-336): in one
 // dimension the median splits of buildBall! (:371-394) make every node a rank interval, so the
 // tree's `ranges` -- all neighborMinMax needs (src/CrossValidation.jl:100-108) -- follow from a sort.
 // `low`/`high` are the reference's 1-based leaf ids of the interval ends; min2r collects the minimum
-// of sqrt((2*range)^2) over internal nodes.
+// of sqrt((2*range)^2) over internal nodes.  (Host form, for marginals beyond kPrepMaxN points.)
 void interval_stats(const double *xs, int64_t low, int64_t high, int64_t leaf0, double &centre, double &half,
                     double &min2r) {
   if (low == high) { centre = xs[low - leaf0]; half = 0.0; return; }
@@ -317,6 +347,259 @@ void interval_stats(const double *xs, int64_t low, int64_t high, int64_t leaf0, 
   centre = bottom + half;
   const double v = std::sqrt((2.0 * half) * (2.0 * half));
   if (v < min2r) min2r = v;
+}
+
+// The rank interval [low, high] (0-based ranks) of node `t` at depth `d` of the median-split tree over n ranks
+// (children of [low, high]: [low, split], [split+1, high] with split = floor((low+high)/2) on the reference's
+// 1-based leaf ids N+1..2N, :371).  Returns false if the node does not exist (an ancestor is a single leaf).
+__device__ inline bool node_interval(int64_t n, int d, int t, int64_t &low, int64_t &high) {
+  low = 0; high = n - 1;
+  for (int b = d - 1; b >= 0; --b) {
+    if (low == high) return false;
+    const int64_t split = ((low + n + 1) + (high + n + 1)) / 2 - (n + 1);  // same rounding as on the 1-based ids
+    if ((t >> b) & 1) low = split + 1; else high = split;
+  }
+  return true;
+}
+
+// One block per dimension: x_d in original order to `xo`, sort in LDS, interval arithmetic, initial search state.
+__global__ __launch_bounds__(kPrepThreads) void loocv_prep_kernel(const double *__restrict__ points, int64_t N, int D,
+                                                                 double *__restrict__ xo, Golden *__restrict__ state) {
+  extern __shared__ double sm[];
+  const int d = blockIdx.x;
+  int64_t P = 1;
+  while (P < N) P <<= 1;
+  double *xs = sm;              // [P] sorted marginal (padded with +inf)
+  double *cen = sm + P;         // [2][P] centre of the nodes of two consecutive depths
+  double *hal = sm + 3 * P;     // [2][P] half-range
+  __shared__ double s_min[kPrepThreads / 64];
+  for (int64_t i = threadIdx.x; i < P; i += kPrepThreads) {
+    const double v = i < N ? points[i * D + d] : INFINITY;
+    xs[i] = v;
+    if (i < N) xo[static_cast<int64_t>(d) * N + i] = v;
+  }
+  __syncthreads();
+  // bitonic sort, ascending.  Exchange partners less than 64 positions apart are handled by lanes of ONE wavefront
+  // (element i belongs to thread i mod 1024, its partner i ^ j to a thread of the same 64-thread group), whose LDS
+  // accesses execute in order: those stages need no workgroup barrier.
+  const int Pi = static_cast<int>(P);
+  for (int k = 2; k <= Pi; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      // compare-exchange number c of this stage works on (i, i + j), i = c with a 0 bit inserted at bit log2(j)
+      for (int c = threadIdx.x; c < Pi / 2; c += kPrepThreads) {
+        const int i = ((c & ~(j - 1)) << 1) | (c & (j - 1));
+        const int l = i | j;
+        const double a = xs[i], b = xs[l];
+        const bool up = (i & k) == 0;
+        if ((a > b) == up) { xs[i] = b; xs[l] = a; }
+      }
+      __syncthreads();
+    }
+  int depth = 0;
+  while ((int64_t(1) << depth) < N) ++depth;  // the deepest level that can hold a node
+  double vmin = INFINITY;
+  for (int dd = depth; dd >= 0; --dd) {
+    double *c0 = cen + (dd & 1) * P, *h0 = hal + (dd & 1) * P;
+    const double *c1 = cen + ((dd + 1) & 1) * P, *h1 = hal + ((dd + 1) & 1) * P;
+    const int64_t cnt = int64_t(1) << dd;
+    for (int64_t t = threadIdx.x; t < cnt && t < P; t += kPrepThreads) {
+      int64_t low, high;
+      if (!node_interval(N, dd, static_cast<int>(t), low, high)) continue;
+      if (low == high) { c0[t] = xs[low]; h0[t] = 0.0; continue; }
+      const double cL = c1[2 * t], rL = h1[2 * t], cR = c1[2 * t + 1], rR = h1[2 * t + 1];
+      const double upA = cL + rL, upB = cR + rR, dnA = cL - rL, dnB = cR - rR;
+      const double top = (upA > upB) ? upA : upB, bottom = (dnA < dnB) ? dnA : dnB;
+      const double half = (top - bottom) / 2.0;
+      h0[t] = half;
+      c0[t] = bottom + half;
+      const double v = sqrt((2.0 * half) * (2.0 * half));
+      if (v < vmin) vmin = v;
+    }
+    __syncthreads();
+  }
+  for (int off = 32; off > 0; off >>= 1) vmin = fmin(vmin, __shfl_down(vmin, off));
+  if ((threadIdx.x & 63) == 0) s_min[threadIdx.x >> 6] = vmin;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double m = s_min[0];
+    for (int i = 1; i < kPrepThreads / 64; ++i) m = fmin(m, s_min[i]);
+    const double half_root = hal[0];
+    Golden g;
+    golden_init(g, m, sqrt((2.0 * half_root) * (2.0 * half_root)));
+    state[d] = g;
+  }
+}
+
+constexpr int kLooThreads = 256;  // queries per block
+constexpr int kLooChunk = 128;    // source points per staged chunk
+
+struct LooRound {
+  const double *x;        // [D][N] marginals, original order
+  double *partial;        // [D][ngroups][N]
+  double *hpart;          // [2][D][nfb] block partials of W*log p of the evaluation in flight (by round parity)
+  Golden *state;          // [2][D]
+  int64_t N;
+  double w;               // the common weight of every point (kde!(points) has none of its own)
+  double sqrt_2pi;        // pow(2 pi, 1/2) as the host's libm rounds it
+  int chunks_per_group, ngroups, nfb, D, round;
+};
+
+// Round, first launch: advance the search of this block's dimension, then the all-pairs leave-one-out sums
+// partial[g][q] = sum_{i in group g, i != q} exp(-1/2 (x_q - x_i)^2 / bw)   (weights are uniform: applied later)
+__global__ __launch_bounds__(kLooThreads) void loo_round_partial_kernel(const LooRound r) {
+  __shared__ double sSrc[2][kLooChunk];
+  __shared__ double sExpTab[32];
+  __shared__ Golden sh;
+  const int d = blockIdx.z;
+  if (threadIdx.x < 32) sExpTab[threadIdx.x] = kExp2Tab[threadIdx.x];
+  if (threadIdx.x == 0) {
+    Golden s = r.state[(r.round & 1) * r.D + d];
+    golden_book(s, r.hpart + (static_cast<int64_t>(r.round & 1) * r.D + d) * r.nfb, r.nfb);
+    golden_decide(s);
+    sh = s;
+    if (blockIdx.x == 0 && blockIdx.y == 0) r.state[((r.round + 1) & 1) * r.D + d] = s;
+  }
+  __syncthreads();
+  if (sh.phase == 3) return;  // this dimension's search is over
+  const double nhib = -0.5 / sh.bw_eval;
+  const double *x = r.x + static_cast<int64_t>(d) * r.N;
+  const int64_t q = static_cast<int64_t>(blockIdx.x) * kLooThreads + threadIdx.x;
+  const int64_t nchunks = (r.N + kLooChunk - 1) / kLooChunk;
+  const int64_t c_begin = static_cast<int64_t>(blockIdx.y) * r.chunks_per_group;
+  int64_t c_end = c_begin + r.chunks_per_group;
+  if (c_end > nchunks) c_end = nchunks;
+  const double xq = q < r.N ? x[q] : 0.0;
+  auto stage = [&](int64_t c, int buf) {
+    const int64_t i = c * kLooChunk + threadIdx.x;
+    if (threadIdx.x < kLooChunk) sSrc[buf][threadIdx.x] = i < r.N ? x[i] : INFINITY;  // (a point at infinity contributes exp(-inf) = 0)
+  };
+  if (c_begin < c_end) stage(c_begin, 0);
+  double total = 0.0;
+  for (int64_t c = c_begin; c < c_end; ++c) {
+    const int buf = static_cast<int>((c - c_begin) & 1);
+    __syncthreads();
+    if (c + 1 < c_end) stage(c + 1, buf ^ 1);
+    const int64_t i0 = c * kLooChunk;
+    double sum = 0.0;
+#pragma unroll 4
+    for (int i = 0; i < kLooChunk; ++i) {
+      const double dlt = xq - sSrc[buf][i];
+      double v = exp_nonpos((dlt * dlt) * nhib, sExpTab);
+      if (i0 + i == q) v = 0.0;  // leave-one-out: skip the self term (:141)
+      sum += v;
+    }
+    total += sum;
+  }
+  if (q < r.N) r.partial[(static_cast<int64_t>(d) * r.ngroups + blockIdx.y) * r.N + q] = total;
+}
+
+// A whole round in ONE launch (marginals up to kFusedMaxN points): a workgroup of 8 wavefronts owns the 64 queries
+// of tile I -- every wavefront holds the same queries, lane t query I*64+t -- and wavefront w sums over the source
+// tiles J = w, w+8, ...: the 64 sources of a tile travel around the wavefront one lane per step (DPP wave rotate),
+// so every lane meets every source without any LDS traffic besides the exp table.  The 8 partial sums per query
+// are added in wavefront order, turned into W*log p and reduced to the block's share of the log-likelihood
+// (evalAvgLogL, src/DualTree01.jl:450-474): no second launch, no intermediate array.
+constexpr int kTile = 64;
+constexpr int kFusedWaves = 16;
+constexpr int64_t kFusedMaxN = 4096;
+__device__ __forceinline__ double wave_rotate(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x13C, 0xF, 0xF, false);  // wave_ror:1
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x13C, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+__global__ __launch_bounds__(kTile *kFusedWaves) void loo_round_fused_kernel(const LooRound r) {
+  __shared__ double sExpTab[256];
+  __shared__ double sRow[kFusedWaves][kTile];
+  __shared__ Golden sh;
+  const int d = blockIdx.z, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int I = blockIdx.x;
+  if (threadIdx.x < 256) sExpTab[threadIdx.x] = kExp2Tab256[threadIdx.x];
+  if (threadIdx.x == 0) {
+    Golden s = r.state[(r.round & 1) * r.D + d];
+    golden_book(s, r.hpart + (static_cast<int64_t>(r.round & 1) * r.D + d) * r.nfb, r.nfb);
+    golden_decide(s);
+    sh = s;
+    if (I == 0) r.state[((r.round + 1) & 1) * r.D + d] = s;
+  }
+  __syncthreads();
+  if (sh.phase == 3) return;  // this dimension's search is over
+  const double nhib = -0.5 / sh.bw_eval;
+  const double *x = r.x + static_cast<int64_t>(d) * r.N;
+  const int64_t qi = static_cast<int64_t>(I) * kTile + lane;
+  const double xi = qi < r.N ? x[qi] : INFINITY;
+  const int ntiles = r.ngroups;
+  double rowsum = 0.0;
+  for (int J = wave; J < ntiles; J += kFusedWaves) {
+    const int64_t qj = static_cast<int64_t>(J) * kTile + lane;
+    double xj = qj < r.N ? x[qj] : -INFINITY;  // (a point at infinity contributes exp(-inf) = 0; opposite signs: no inf - inf)
+    double acc = 0.0;
+    int s0 = 0;
+    if (J == I) { xj = wave_rotate(xj); s0 = 1; }  // the own tile: the first rotation skips the self term (:141)
+#pragma unroll 4
+    for (int s = s0; s < kTile; ++s) {
+      const double dlt = xi - xj;
+      acc += exp256_nonpos((dlt * dlt) * nhib, sExpTab);
+      xj = wave_rotate(xj);
+    }
+    rowsum += acc;
+  }
+  sRow[wave][lane] = rowsum;
+  __syncthreads();
+  if (wave != 0) return;
+  double tot = 0.0;
+#pragma unroll
+  for (int w = 0; w < kFusedWaves; ++w) tot += sRow[w][lane];
+  const double inv_norm = 1.0 / (r.sqrt_2pi * sqrt(sh.bw_eval));  // norm = (2 pi)^(1/2) * sqrt(bw), :325-330
+  double term = 0.0;
+  if (qi < r.N) {
+    const double w = r.w;
+    const double p = (tot * w) * inv_norm / (1.0 - w);
+    if (p == 0.0) term = (w != 0.0) ? -INFINITY : 0.0;  // a zero likelihood that carries weight: -Inf (:460-463)
+    else term = log(p) * w;
+  }
+  for (int off = 32; off > 0; off >>= 1) term += __shfl_down(term, off);  // fixed order
+  if (lane == 0) r.hpart[(static_cast<int64_t>((r.round + 1) & 1) * r.D + d) * r.nfb + I] = term;
+}
+
+// Round, second launch: p_q = w * (sum over groups) / norm / (1 - w); block partial of W_q * log p_q
+// (evalAvgLogL, src/DualTree01.jl:450-474; a zero likelihood that carries weight makes it -Inf, :460-463).
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void loo_round_entropy_kernel(const LooRound r) {
+  __shared__ double red[THREADS];
+  const int d = blockIdx.y;
+  const Golden &s = r.state[((r.round + 1) & 1) * r.D + d];  // as advanced by this round's first launch
+  if (s.phase == 3) return;
+  const double inv_norm = 1.0 / (r.sqrt_2pi * sqrt(s.bw_eval));  // norm = (2 pi)^(1/2) * sqrt(bw), :325-330
+  const int64_t q = static_cast<int64_t>(blockIdx.x) * THREADS + threadIdx.x;
+  double term = 0.0;
+  if (q < r.N) {
+    double acc = 0.0;
+    for (int g = 0; g < r.ngroups; ++g) acc += r.partial[(static_cast<int64_t>(d) * r.ngroups + g) * r.N + q];
+    const double w = r.w;
+    const double p = (acc * w) * inv_norm / (1.0 - w);
+    if (p == 0.0) term = (w != 0.0) ? -INFINITY : 0.0;
+    else term = log(p) * w;
+  }
+  red[threadIdx.x] = term;
+  __syncthreads();
+  for (int off = THREADS / 2; off > 0; off >>= 1) {
+    if (static_cast<int>(threadIdx.x) < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) r.hpart[(static_cast<int64_t>((r.round + 1) & 1) * r.D + d) * r.nfb + blockIdx.x] = red[0];
+}
+
+// After the last round of a batch: book its evaluation; a search that thereby converges is finished here, one that
+// goes on keeps the booked state (no evaluation pending) and decides again in the next batch's first round.
+__global__ void loo_finalize_kernel(const LooRound r) {
+  const int d = threadIdx.x;
+  if (d >= r.D) return;
+  Golden s = r.state[(r.round & 1) * r.D + d];
+  golden_book(s, r.hpart + (static_cast<int64_t>(r.round & 1) * r.D + d) * r.nfb, r.nfb);
+  Golden next = s;
+  golden_decide(next);
+  r.state[(r.round & 1) * r.D + d] = (next.phase == 3) ? next : s;
 }
 
 }  // namespace
@@ -334,151 +617,118 @@ extern "C" int kdehip_auto_bandwidth(int64_t D64, int64_t N, const double *point
   auto tnow = [] { return std::chrono::steady_clock::now(); };
   auto t_begin = tnow();
 
-  // Per dimension d: the marginal's tree ranges give neighborMinMax; the search density is
-  // kde!(x_d, (minm+maxm)/2) (ksize, src/CrossValidation.jl:110-120).  The GPU evaluates the
-  // leave-one-out likelihood over the points in their ORIGINAL order (the tree order only fixes the
-  // reference's summation order), so no tree is built here.
-  std::vector<Golden> g(D);
-  std::vector<double> xo(static_cast<size_t>(D) * N), wts(static_cast<size_t>(D) * N);
-  {
-    // weights: ones -> /N (kde!(points,[1.0])) -> renormalised by the marginal's kde! (src/KDE01.jl:46,152)
-    std::vector<double> w0(N), w1(N);
-    for (int64_t i = 0; i < N; ++i) w0[i] = 1.0 / static_cast<double>(N);
-    double t = 0.0;
-    for (int64_t i = 0; i < N; ++i) t += w0[i];
-    for (int64_t i = 0; i < N; ++i) w1[i] = w0[i] / t;
-    // the D marginals are independent: one host thread each (the sort dominates this phase)
+  // weights: ones -> /N (kde!(points,[1.0])) -> renormalised by the marginal's kde! (src/KDE01.jl:46,152): every
+  // point ends up with the same weight w1
+  const double w0 = 1.0 / static_cast<double>(N);
+  double t = 0.0;
+  for (int64_t i = 0; i < N; ++i) t += w0;
+  const double w1 = w0 / t;
+
+  const int64_t nchunks = (N + kLooChunk - 1) / kLooChunk;
+  const int64_t qblocks = (N + kLooThreads - 1) / kLooThreads;
+  int64_t want = (int64_t(8) * device_cu_count() + qblocks * D - 1) / (qblocks * D);  // ~8 blocks per CU
+  if (want < 1) want = 1;
+  if (want > kEvalMaxGroups) want = kEvalMaxGroups;
+  if (want > nchunks) want = nchunks;
+  LooRound r{};
+  const bool pairs = N <= kFusedMaxN;  // one fused launch per round
+  const int ntiles = static_cast<int>((N + kTile - 1) / kTile);
+  r.chunks_per_group = static_cast<int>((nchunks + want - 1) / want);
+  r.ngroups = pairs ? ntiles : static_cast<int>((nchunks + r.chunks_per_group - 1) / r.chunks_per_group);
+  r.nfb = pairs ? ntiles : static_cast<int>(qblocks);  // blocks of the log-likelihood reduction (64 / 256 queries each)
+  r.N = N; r.D = D; r.w = w1; r.round = 0;
+  r.sqrt_2pi = std::pow(2.0 * M_PI, 1 / 2.0);
+
+  // one device block: [points N*D | xo D*N | partial D*ngroups*N | hpart D*nfb | state 2*D]
+  auto al = [](size_t x) { return (x + 255) & ~static_cast<size_t>(255); };
+  const size_t off_x = al(sizeof(double) * N * D);
+  const size_t off_part = al(off_x + sizeof(double) * N * D);
+  const size_t off_h = al(off_part + sizeof(double) * D * r.ngroups * N);
+  const size_t off_state = al(off_h + sizeof(double) * 2 * D * r.nfb);
+  const size_t total = off_state + sizeof(Golden) * 2 * D;
+  DevBuf dev;
+  KDEHIP_CHECK(dev.alloc(total));
+  unsigned char *base = dev.as<unsigned char>();
+  double *d_pts = reinterpret_cast<double *>(base);
+  r.x = reinterpret_cast<double *>(base + off_x);
+  r.partial = reinterpret_cast<double *>(base + off_part);
+  r.hpart = reinterpret_cast<double *>(base + off_h);
+  r.state = reinterpret_cast<Golden *>(base + off_state);
+  struct Pinned {
+    void *p = nullptr;
+    size_t n = 0;
+    ~Pinned() { if (p) cached_host_free(p, n); }
+  } pin;
+  pin.n = std::max(sizeof(double) * N * D, sizeof(Golden) * 2 * D);
+  KDEHIP_CHECK(cached_host_malloc(&pin.p, pin.n));
+  Golden *h_state = static_cast<Golden *>(pin.p);
+
+  if (N <= kPrepMaxN) {
+    std::memcpy(pin.p, points, sizeof(double) * N * D);
+    KDEHIP_CHECK(hipMemcpyAsync(d_pts, pin.p, sizeof(double) * N * D, hipMemcpyHostToDevice, nullptr));
+    int64_t P = 1;
+    while (P < N) P <<= 1;
+    hipLaunchKernelGGL(loocv_prep_kernel, dim3(D), dim3(kPrepThreads), sizeof(double) * 5 * P, nullptr, d_pts, N, D,
+                       const_cast<double *>(r.x), r.state);
+    KDEHIP_CHECK(hipGetLastError());
+  } else {
+    // large marginals: sort and interval arithmetic on the host (one thread per dimension), same state afterwards
+    std::vector<double> xo(static_cast<size_t>(D) * N);
+    std::vector<Golden> g(D);
     auto prep = [&](int d) {
       std::vector<double> xs(static_cast<size_t>(N));
-      for (int64_t i = 0; i < N; ++i) {
-        xo[static_cast<size_t>(d) * N + i] = points[i * D + d];
-        wts[static_cast<size_t>(d) * N + i] = w1[i];
-        xs[i] = points[i * D + d];
-      }
+      for (int64_t i = 0; i < N; ++i) xs[i] = xo[static_cast<size_t>(d) * N + i] = points[i * D + d];
       std::sort(xs.begin(), xs.end());
       double centre, half, minm = INFINITY;
       interval_stats(xs.data(), N + 1, 2 * N, N + 1, centre, half, minm);
-      const double maxm = std::sqrt((2.0 * half) * (2.0 * half));  // root
-      if (minm < 1e-6) minm = 1e-6;
-      Golden &s = g[d];
-      const double mid = (minm + maxm) / 2.0;
-      s.minm = minm; s.maxm = maxm; s.bcur = mid * mid;
-      const double ax = 2.0 * minm / (minm + maxm), bx = 1.0, cx = 2.0 * maxm / (minm + maxm);
-      const double C = (3.0 - std::sqrt(5.0)) / 2.0;
-      s.x0 = ax; s.x3 = cx;
-      if (std::fabs(cx - bx) > std::fabs(bx - ax)) { s.x1 = bx; s.x2 = bx + C * (cx - bx); }
-      else { s.x1 = bx - C * (bx - ax); s.x2 = bx; }
-      s.phase = 0; s.nevals = 0; s.pending = 0; s.alpha = 0; s.f1 = s.f2 = 0; s.result = 0;
+      golden_init(g[d], minm, std::sqrt((2.0 * half) * (2.0 * half)));
     };
-    if (D > 1 && N >= 512) {
-      std::vector<std::thread> th;
-      for (int d = 1; d < D; ++d) th.emplace_back(prep, d);
-      prep(0);
-      for (auto &t2 : th) t2.join();
-    } else {
-      for (int d = 0; d < D; ++d) prep(d);
-    }
+    std::vector<std::thread> th;
+    for (int d = 1; d < D; ++d) th.emplace_back(prep, d);
+    prep(0);
+    for (auto &t2 : th) t2.join();
+    KDEHIP_CHECK(hipMemcpy(const_cast<double *>(r.x), xo.data(), sizeof(double) * D * N, hipMemcpyHostToDevice));
+    KDEHIP_CHECK(hipMemcpy(r.state, g.data(), sizeof(Golden) * D, hipMemcpyHostToDevice));
   }
+  auto t_prep = tnow();
 
-  auto t_host = tnow();
-  const GroupSplit gs = split_chunks(N, N, D);
-  const int nchunks = gs.ngroups;  // partial sums per query
-  const int nfb = static_cast<int>((N + kFinishThreads - 1) / kFinishThreads);
-  DevBuf d_x, d_w, d_part;
-  KDEHIP_CHECK(d_x.alloc(sizeof(double) * D * N));
-  KDEHIP_CHECK(d_w.alloc(sizeof(double) * D * N));
-  KDEHIP_CHECK(d_part.alloc(sizeof(double) * D * nchunks * N));
-  // the per-round result (D x nfb partial log-likelihoods) is written by the kernel straight into
-  // pinned host memory: no device buffer, no copy, one stream synchronisation per round
-  struct Pinned {
-    double *p = nullptr;
-    size_t n = 0;
-    ~Pinned() { if (p) cached_host_free(p, n); }
-  } h_pin;
-  h_pin.n = sizeof(double) * D * nfb;
-  KDEHIP_CHECK(cached_host_malloc(reinterpret_cast<void **>(&h_pin.p), h_pin.n));
-  KDEHIP_CHECK(hipMemcpy(d_x.p, xo.data(), sizeof(double) * D * N, hipMemcpyHostToDevice));
-  KDEHIP_CHECK(hipMemcpy(d_w.p, wts.data(), sizeof(double) * D * N, hipMemcpyHostToDevice));
-
-  auto t_upload = tnow();
-  int rounds = 0;
-  EvalBatch eb{};
-  FinishBatch fb{};
-  const double C = (3.0 - std::sqrt(5.0)) / 2.0, R = 1.0 - C;
-  const double tol = 1e-2;  // ksize, src/CrossValidation.jl:116
-
-  for (;;) {
-    // decide what every unfinished search evaluates in this round
-    std::vector<int> active;
-    for (int d = 0; d < D; ++d) {
-      Golden &s = g[d];
-      if (s.phase == 3) continue;
-      if (s.phase == 0) { s.alpha = s.x1; s.pending = 1; }
-      else if (s.phase == 1) { s.alpha = s.x2; s.pending = 2; }
-      else {
-        if (!(std::fabs(s.x3 - s.x0) > tol * (std::fabs(s.x1) + std::fabs(s.x2)))) {
-          s.result = (s.f1 < s.f2) ? s.x1 : s.x2;
-          s.phase = 3;
-          continue;
-        }
-        if (s.f2 < s.f1) { s.x0 = s.x1; s.x1 = s.x2; s.x2 = R * s.x1 + C * s.x3; s.f1 = s.f2; s.alpha = s.x2; s.pending = 2; }
-        else { s.x3 = s.x2; s.x2 = s.x1; s.x1 = R * s.x2 + C * s.x0; s.f2 = s.f1; s.alpha = s.x1; s.pending = 1; }
+  // rounds in batches; the host looks at the searches only between batches
+  int rounds = 0, batches = 0;
+  const dim3 gridA(static_cast<unsigned>(qblocks), static_cast<unsigned>(r.ngroups), static_cast<unsigned>(D));
+  const dim3 gridB(static_cast<unsigned>(r.nfb), static_cast<unsigned>(D));
+  const dim3 gridP(static_cast<unsigned>(ntiles), 1, static_cast<unsigned>(D));
+  for (int batch = 20; batches < 16; batch = 8) {
+    for (int k = 0; k < batch; ++k) {
+      if (pairs) {
+        hipLaunchKernelGGL(loo_round_fused_kernel, gridP, dim3(kTile * kFusedWaves), 0, nullptr, r);
+      } else {
+        hipLaunchKernelGGL(loo_round_partial_kernel, gridA, dim3(kLooThreads), 0, nullptr, r);
+        hipLaunchKernelGGL(loo_round_entropy_kernel<kLooThreads>, gridB, dim3(kLooThreads), 0, nullptr, r);
       }
-      active.push_back(d);
+      ++r.round;
+      ++rounds;
     }
-    if (active.empty()) break;
-    ++rounds;
-    // nLOO_LL (src/CrossValidation.jl:15-24): bandwidth *= alpha^2 for the evaluation, /= alpha^2 after
-    const int na = static_cast<int>(active.size());
-    std::vector<double> a2(na), bw_eval(na);
-    for (int a = 0; a < na; ++a) {
-      const int d = active[a];
-      a2[a] = g[d].alpha * g[d].alpha;
-      bw_eval[a] = g[d].bcur * a2[a];
-      EvalProblem &pb = eb.p[a];
-      std::memset(&pb, 0, sizeof(pb));
-      pb.src = d_x.as<double>() + static_cast<size_t>(d) * N;
-      pb.qry = pb.src;
-      pb.w = d_w.as<double>() + static_cast<size_t>(d) * N;
-      pb.partial = d_part.as<double>() + static_cast<size_t>(d) * nchunks * N;
-      pb.nhib[0] = -0.5 / bw_eval[a];
-      pb.N = N; pb.Nq = N; pb.chunks_per_group = gs.chunks_per_group;
-      FinishProblem &fp = fb.p[a];
-      std::memset(&fp, 0, sizeof(fp));
-      fp.partial = pb.partial; fp.w = pb.w;
-      fp.inv_norm = 1.0 / gauss_norm(&bw_eval[a], 1);
-      fp.Nq = N; fp.nchunks = nchunks;
-    }
-    rc = launch_partial_dims(1, eb, na, N, gs.ngroups, 1, nullptr);
-    if (rc != KDEHIP_OK) return rc;
-    hipLaunchKernelGGL(loo_entropy_kernel, dim3(static_cast<unsigned>(nfb), static_cast<unsigned>(na)),
-                       dim3(kFinishThreads), 0, nullptr, fb, h_pin.p, nfb);
+    hipLaunchKernelGGL(loo_finalize_kernel, dim3(1), dim3(64), 0, nullptr, r);
     KDEHIP_CHECK(hipGetLastError());
+    KDEHIP_CHECK(hipMemcpyAsync(h_state, r.state + (r.round & 1) * D, sizeof(Golden) * D, hipMemcpyDeviceToHost, nullptr));
     KDEHIP_CHECK(hipStreamSynchronize(nullptr));
-    const double *h_host = h_pin.p;
-    for (int a = 0; a < na; ++a) {
-      const int d = active[a];
-      Golden &s = g[d];
-      double ll = 0.0;
-      for (int b = 0; b < nfb; ++b) ll += h_host[static_cast<size_t>(a) * nfb + b];
-      const double H = -ll;  // entropy = -evalAvgLogL (src/DualTree01.jl:505-508); -(-Inf) = +Inf
-      s.bcur = (s.bcur * a2[a]) / a2[a];
-      s.nevals += 1;
-      if (s.pending == 1) s.f1 = H; else s.f2 = H;
-      if (s.phase < 2) s.phase += 1;
-    }
+    ++batches;
+    bool done = true;
+    for (int d = 0; d < D; ++d) done = done && h_state[d].phase == 3;
+    if (done) break;
   }
-  int total = 0;
+  int total_evals = 0;
   for (int d = 0; d < D; ++d) {
-    double ks = g[d].result * (g[d].minm + g[d].maxm) / 2.0;  // ksize, src/CrossValidation.jl:117
-    bw_out[d] = std::sqrt(ks * ks);                            // getBW of kde!(.., [ks]) (src/KDE01.jl:45,118)
-    total += g[d].nevals;
+    if (h_state[d].phase != 3) return set_error(KDEHIP_ERR_HIP, "bandwidth search did not converge");
+    const double ks = h_state[d].result * (h_state[d].minm + h_state[d].maxm) / 2.0;  // ksize, src/CrossValidation.jl:117
+    bw_out[d] = std::sqrt(ks * ks);                                                    // getBW of kde!(.., [ks]) (src/KDE01.jl:45,118)
+    total_evals += h_state[d].nevals;
   }
-  if (nevals_out) *nevals_out = total;
+  if (nevals_out) *nevals_out = total_evals;
   if (timing) {
     auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
-    std::fprintf(stderr, "kdehip_auto_bandwidth D=%d N=%lld: host prep %.0f us, alloc+upload %.0f us, %d rounds %.0f us\n", D,
-                 static_cast<long long>(N), us(t_begin, t_host), us(t_host, t_upload), rounds, us(t_upload, tnow()));
+    std::fprintf(stderr, "kdehip_auto_bandwidth D=%d N=%lld: upload + prep enqueue %.0f us, %d rounds in %d batches %.0f us\n", D,
+                 static_cast<long long>(N), us(t_begin, t_prep), rounds, batches, us(t_prep, tnow()));
   }
   return KDEHIP_OK;
 }

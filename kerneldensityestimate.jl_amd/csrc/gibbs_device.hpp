@@ -601,15 +601,23 @@ __device__ __forceinline__ int draw_label_kept(P rows, const DS &ds, int lane, c
   const int last_lane = ds.last_lane;
   int lstar = hit ? (__ffsll(hit) - 1) : last_lane;
   if (lstar > last_lane) lstar = last_lane;
-  // second pass, in every lane on its own block: first row r with target <= exclusive prefix + v[0..r]
-  // (the running sums never decrease, so the first row that reaches the target = the number of rows below it)
-  T run = incl - S;
-  int first = 0;
+  // second pass, in every lane on its own block: first row r with target <= exclusive prefix + (v[0] + .. + v[r]).
+  // The partial sums are formed in the association order of the wavefront scan that select_from_scan applies to
+  // the same values when they are spread over lanes (x[i] += x[i-1]; += x[i-2]; += x[i-4]), so both forms of the
+  // second pass -- and with them every workgroup width, rank count and staging mode -- compare the very same
+  // numbers: which label a uniform draw selects never depends on a scheduling choice.
+  const T base = incl - S;
+  T ps[BMAX];
 #pragma unroll
-  for (int r = 0; r < BMAX; ++r) {
-    run += v[r];
-    first += (target <= run) ? 0 : 1;
+  for (int r = 0; r < BMAX; ++r) ps[r] = v[r];
+#pragma unroll
+  for (int sh = 1; sh < BMAX; sh *= 2) {
+#pragma unroll
+    for (int r = BMAX - 1; r >= sh; --r) ps[r] = ps[r] + ps[r - sh];
   }
+  int first = BMAX;
+#pragma unroll
+  for (int r = BMAX - 1; r >= 0; --r) first = (target <= base + ps[r]) ? r : first;
   int len = n - lstar * B;
   if (len > B) len = B;
   int istar = __builtin_amdgcn_readlane(first, lstar);

@@ -73,7 +73,7 @@ function gibbs1(Ndens::Int, trees::Array{BallTreeDensity,1}, Np::Int, Niter::Int
                 glbs=KDE.makeEmptyGbGlb(), addEntropy::Bool=true,
                 ndims::Int=maximum(Ndim.(trees)),
                 partialDimMask::AbstractVector{<:BitVector}=[ones(Int, ndims) .== 1 for i in 1:Ndens],
-                device::Int=0)
+                device::Int=0, ngpus::Int=1)
   fallback() = reference_gibbs1(Ndens, trees, Np, Niter, pts, ind, randU, randN; addop=addop, diffop=diffop,
                                 getMu=getMu, getLambda=getLambda, glbs=glbs, addEntropy=addEntropy, ndims=ndims,
                                 partialDimMask=partialDimMask)
@@ -84,11 +84,12 @@ function gibbs1(Ndens::Int, trees::Array{BallTreeDensity,1}, Np::Int, Niter::Int
   Nlevels = floor(Int, log(Float64(maximum(Npts.(trees)))) / log(2.0) + 1.0)   # :568
   labels = glbs.recordChoosen ? zeros(Int32, Nlevels, Ndens, Np) : Int32[]
   GC.@preserve trees cds mask labels begin
-    rc = ccall((:kdehip_gibbs1_trace, libkdehip), Cint,
+    # chains split over `ngpus` devices (device .. device+ngpus-1) in contiguous ranges; ngpus = 1: one GPU
+    rc = ccall((:kdehip_gibbs1_multi, libkdehip), Cint,
                (Cint, Ptr{CDensity}, Int64, Cint, Ptr{Float64}, Ptr{Int64}, Ptr{Float64}, Int64, Ptr{Float64},
-                Int64, Cint, Cint, Ptr{UInt8}, Cint, Ptr{Int32}),
+                Int64, Cint, Cint, Ptr{UInt8}, Cint, Cint, Ptr{Int32}),
                Ndens, cds, Np, Niter, pts, ind, randU, length(randU), randN, length(randN),
-               addEntropy ? 1 : 0, ndims, mask, device, glbs.recordChoosen ? pointer(labels) : C_NULL)
+               addEntropy ? 1 : 0, ndims, mask, device, ngpus, glbs.recordChoosen ? pointer(labels) : C_NULL)
   end
   # shapes beyond the compiled limits (ndims > 8, Ndens > 16) stay on the reference path: the caller sees the
   # same behaviour as without this package, only slower (nothing has been written to pts / ind yet)
@@ -120,7 +121,7 @@ function prodAppxMSGibbsS(npd0::BallTreeDensity, trees::Array{BallTreeDensity,1}
                           ndims::Integer=maximum(Ndim.(trees)), Ndens=length(trees), Np=Npts(npd0),
                           randU=nothing, randN=nothing,
                           partialDimMask::AbstractVector{<:BitVector}=[ones(Int, ndims) .== 1 for i in 1:length(trees)],
-                          seed::Union{Nothing,UInt64}=nothing, device::Int=0)
+                          seed::Union{Nothing,UInt64}=nothing, device::Int=0, ngpus::Int=1)
   if !isEuclid(addop, diffop, getMu, getLambda)
     kw = (randU === nothing) ? NamedTuple() : (randU=randU, randN=randN)
     return KDE.prodAppxMSGibbsS(npd0, trees, anFcns, anParams; Niter=Niter, addop=addop, diffop=diffop,
@@ -139,30 +140,24 @@ function prodAppxMSGibbsS(npd0::BallTreeDensity, trees::Array{BallTreeDensity,1}
       ccall((:kdehip_philox_fill_normal, libkdehip), Cvoid, (UInt64, Int64, Int64, Int64, Ptr{Float64}), s, 0, Np, R, randN)
     end
     gibbs1(Ndens, trees, Np, Niter, points, indices, randU, randN; glbs=glbs, addEntropy=addEntropy,
-           ndims=Int(ndims), partialDimMask=partialDimMask, device=device)
+           ndims=Int(ndims), partialDimMask=partialDimMask, device=device, ngpus=ngpus)
     return reshape(points, ndims, Np), indices
   end
   cds = CDensity[CDensity(t) for t in trees]
   mask = maskbytes(partialDimMask, Ndens, ndims)
-  plan = Ref{Ptr{Cvoid}}(C_NULL)
+  s = seed === nothing ? rand(UInt64) : seed
   GC.@preserve trees cds mask begin
-    rc = ccall((:kdehip_product_create, libkdehip), Cint,
-               (Ref{Ptr{Cvoid}}, Cint, Ptr{CDensity}, Cint, Ptr{UInt8}, Cint, Cint),
-               plan, Ndens, cds, ndims, mask, 64, device)
+    # one-shot: pack, upload, run (device Philox stream keyed by `s`), copy back; chains split over `ngpus` devices
+    rc = ccall((:kdehip_prod_philox, libkdehip), Cint,
+               (Cint, Ptr{CDensity}, Int64, Cint, Ptr{Float64}, Ptr{Int64}, UInt64, Cint, Cint, Ptr{UInt8}, Cint, Cint,
+                Cint, Ptr{Int32}),
+               Ndens, cds, Np, Niter, points, indices, s, addEntropy ? 1 : 0, ndims, mask, 64, device, ngpus, C_NULL)
   end
   if rc == KDEHIP_ERR_UNSUPPORTED   # beyond the compiled limits: the reference's own front end and engine
     return KDE.prodAppxMSGibbsS(npd0, trees, anFcns, anParams; Niter=Niter, glbs=glbs, addEntropy=addEntropy,
                                 ndims=ndims, Ndens=Ndens, Np=Np, partialDimMask=partialDimMask)
   end
   check(rc)
-  try
-    s = seed === nothing ? rand(UInt64) : seed
-    check(ccall((:kdehip_product_sample_philox_host, libkdehip), Cint,
-                (Ptr{Cvoid}, Int64, Cint, UInt64, Int64, Cint, Ptr{Float64}, Ptr{Int64}, Ptr{Int32}),
-                plan[], Np, Niter, s, 0, addEntropy ? 1 : 0, points, indices, C_NULL))
-  finally
-    ccall((:kdehip_product_destroy, libkdehip), Cvoid, (Ptr{Cvoid},), plan[])
-  end
   return reshape(points, ndims, Np), indices
 end
 
