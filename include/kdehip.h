@@ -198,6 +198,22 @@ int kdehip_make_density(int64_t D, int64_t N, const double *points, const double
                         int64_t *highest_leaf, int64_t *permutation, double *means,
                         double *bandwidth, double *bandwidthMin, double *bandwidthMax);
 
+/* The same construction on the GPU, for a batch of `nb` densities of one dimension count (one workgroup per
+ * density, level-synchronous; csrc/treebuild.hip): bit-identical arrays -- same node numbering, leaf order and
+ * statistics as kdehip_make_density and the reference.  Every pointer argument is an array of nb pointers to
+ * caller-allocated host arrays shaped as in kdehip_make_density (ks[j]: nks values; weights_in may be NULL, or hold
+ * NULL entries, for unit weights).  Densities the device builder cannot hold in LDS are refused with
+ * KDEHIP_ERR_UNSUPPORTED (kdehip_make_density_device_supported tells beforehand; callers then use
+ * kdehip_make_density). */
+int kdehip_make_density_device_supported(int64_t D, int64_t N);
+int kdehip_make_densities_device(int nb, int64_t D, const int64_t *Ns, const double *const *points,
+                                 const double *const *ks, int64_t nks, const double *const *weights_in,
+                                 double *const *centers, double *const *ranges, double *const *weights,
+                                 int64_t *const *left_child, int64_t *const *right_child,
+                                 int64_t *const *lowest_leaf, int64_t *const *highest_leaf,
+                                 int64_t *const *permutation, double *const *means, double *const *bandwidth,
+                                 double *const *bandwidthMin, double *const *bandwidthMax, int device);
+
 /* ---- (5) direct evaluation and automatic bandwidth (the callers either side of the product) ----
  * kdehip_evaluate: `evaluateDualTree(bd, pos)` / `bd(pos)` with the reference's default
  * FORCE_EVAL_DIRECT = true (src/DualTree01.jl:130-162, 303-346, 370-446): p_out[q] = density of `bd` at

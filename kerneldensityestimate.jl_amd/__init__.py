@@ -7,7 +7,7 @@ through the top-level `kdehip` module of this repository.
 """
 from ._lib import KdeHipError, LIB_PATH, lib as _clib  # noqa: F401  (import fails loudly if the .so is missing)
 from .density import (BallTree, BallTreeDensity, Ndim, Npts, density_from_arrays, getBW, getPoints,  # noqa: F401
-                      getWeights, kde, kde_b)
+                      getWeights, kde, kde_b, kde_batch)
 from .bandwidth import auto_bandwidth, evaluateDualTree, kde_auto  # noqa: F401
 from .product import (GbGlb, MultiProductPlan, ProductPlan, gibbs1, makeEmptyGbGlb, mul, nlevels, philox_streams,  # noqa: F401
                       prodAppxMSGibbsS)

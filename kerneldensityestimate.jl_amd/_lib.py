@@ -80,6 +80,9 @@ SIGNATURES = {
     "kdehip_philox_fill_normal": (None, [C.c_uint64, C.c_int64, C.c_int64, C.c_int64, f64p]),
     "kdehip_evaluate": (C.c_int, [C.POINTER(CDensity), f64p, C.c_int64, C.c_int, f64p, C.c_int]),
     "kdehip_auto_bandwidth": (C.c_int, [C.c_int64, C.c_int64, f64p, f64p, i32p, C.c_int]),
+    "kdehip_make_density_device_supported": (C.c_int, [C.c_int64, C.c_int64]),
+    "kdehip_make_densities_device": (C.c_int, [C.c_int, C.c_int64, i64p] + [C.POINTER(C.c_void_p)] * 2 + [C.c_int64] +
+                                     [C.POINTER(C.c_void_p)] * 13 + [C.c_int]),
     "kdehip_make_density": (C.c_int, [C.c_int64, C.c_int64, f64p, f64p, C.c_int64, f64p, f64p, f64p, f64p,
                                       i64p, i64p, i64p, i64p, i64p, f64p, f64p, f64p, f64p]),
 }

@@ -27,6 +27,7 @@ def auto_bandwidth(points, device=0, return_evals=False):
 
 def kde_auto(points, device=0) -> BallTreeDensity:
     """`kde!(points)`: LOOCV bandwidth per dimension, then `kde!(points, bwds)` (src/KDE01.jl:24)."""
+    # (one density: the host builder is the faster one -- the GPU builder pays off for batches, see kde_batch)
     return kde(points, auto_bandwidth(points, device=device))
 
 

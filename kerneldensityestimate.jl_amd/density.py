@@ -43,19 +43,7 @@ class BallTreeDensity:
         return mul([self, other])
 
 
-def kde(points, ks=None, weights=None) -> BallTreeDensity:
-    """`kde!(points, ks)` / `kde!(points, ks, weights)` (reference src/KDE01.jl:34-84); with ks=None the
-    automatic LOOCV bandwidth `kde!(points)` (src/KDE01.jl:3-27, GPU).
-
-    points: (D, N) array, or a length-N vector for 1-D data (:78-84).  ks: bandwidth as STANDARD
-    DEVIATION, one entry (repeated over dimensions, :41-43) or D entries.  weights: N values,
-    normalised to sum 1 (:46); default ones (:67).
-    """
-    if ks is None:
-        if weights is not None:
-            raise ValueError("kde!(points) with automatic bandwidth takes no weights")
-        from .bandwidth import kde_auto
-        return kde_auto(points)
+def _prepare(points, ks, weights):
     pts = np.asarray(points, dtype=np.float64)
     if pts.ndim == 1:
         pts = pts.reshape(1, -1)
@@ -71,7 +59,10 @@ def kde(points, ks=None, weights=None) -> BallTreeDensity:
         if w.size != N:
             raise ValueError("weights must have one entry per point")
     flat = np.ascontiguousarray(pts.T).ravel()  # column-major D x N
+    return D, N, flat, ks, w
 
+
+def _empty_density(D, N) -> BallTreeDensity:
     bt = BallTree()
     bt.dims, bt.num_points = D, N
     bt.centers = np.empty(2 * N * D)
@@ -89,6 +80,28 @@ def kde(points, ks=None, weights=None) -> BallTreeDensity:
     bd.bandwidth = np.empty(2 * N * D)
     bd.bandwidthMin = np.empty(N * D)
     bd.bandwidthMax = np.empty(N * D)
+    return bd
+
+
+def kde(points, ks=None, weights=None, device=None) -> BallTreeDensity:
+    """`kde!(points, ks)` / `kde!(points, ks, weights)` (reference src/KDE01.jl:34-84); with ks=None the
+    automatic LOOCV bandwidth `kde!(points)` (src/KDE01.jl:3-27, GPU).
+
+    points: (D, N) array, or a length-N vector for 1-D data (:78-84).  ks: bandwidth as STANDARD
+    DEVIATION, one entry (repeated over dimensions, :41-43) or D entries.  weights: N values,
+    normalised to sum 1 (:46); default ones (:67).  device: None = the host builder (csrc/balltree.cpp);
+    a HIP ordinal = the GPU builder (csrc/treebuild.hip, bit-identical arrays) where the density fits it.
+    """
+    if ks is None:
+        if weights is not None:
+            raise ValueError("kde!(points) with automatic bandwidth takes no weights")
+        from .bandwidth import kde_auto
+        return kde_auto(points, device=0 if device is None else device)
+    if device is not None:
+        return kde_batch([(points, ks, weights)], device=device)[0]
+    D, N, flat, ks, w = _prepare(points, ks, weights)
+    bd = _empty_density(D, N)
+    bt = bd.bt
     _lib.check(_lib.lib.kdehip_make_density(
         D, N, ptr(flat, f64p), ptr(ks, f64p), ks.size, None if w is None else ptr(w, f64p),
         ptr(bt.centers, f64p), ptr(bt.ranges, f64p), ptr(bt.weights, f64p), ptr(bt.left_child, i64p),
@@ -96,6 +109,46 @@ def kde(points, ks=None, weights=None) -> BallTreeDensity:
         ptr(bt.permutation, i64p), ptr(bd.means, f64p), ptr(bd.bandwidth, f64p),
         ptr(bd.bandwidthMin, f64p), ptr(bd.bandwidthMax, f64p)))
     return bd
+
+
+def kde_batch(items, device=0):
+    """Several `kde!(points, ks[, weights])` at once on the GPU (kdehip_make_densities_device: one workgroup per
+    density).  items: (points, ks) or (points, ks, weights) tuples of ONE dimension count and ks length.  Densities
+    the device builder cannot hold (kdehip_make_density_device_supported) are built by the host builder instead."""
+    import ctypes as C
+    prepared = []
+    for it in items:
+        points, ks = it[0], it[1]
+        weights = it[2] if len(it) > 2 else None
+        prepared.append(_prepare(points, ks, weights))
+    out = [None] * len(prepared)
+    groups = {}
+    for idx, (D, N, flat, ks, w) in enumerate(prepared):
+        if N >= 2 and _lib.lib.kdehip_make_density_device_supported(D, N):
+            groups.setdefault((D, ks.size), []).append(idx)
+        else:
+            out[idx] = kde(np.asarray(items[idx][0]), items[idx][1], items[idx][2] if len(items[idx]) > 2 else None)
+    for (D, nks), idxs in groups.items():
+        for c0 in range(0, len(idxs), _lib.MAX_DENS):
+            chunk = idxs[c0:c0 + _lib.MAX_DENS]
+            nb = len(chunk)
+            dens = [_empty_density(D, prepared[i][1]) for i in chunk]
+
+            def arr(get):
+                return (C.c_void_p * nb)(*[None if get(k) is None else get(k).ctypes.data for k in range(nb)])
+            Ns = np.array([prepared[i][1] for i in chunk], dtype=np.int64)
+            any_w = any(prepared[i][4] is not None for i in chunk)
+            _lib.check(_lib.lib.kdehip_make_densities_device(
+                nb, D, ptr(Ns, i64p), arr(lambda k: prepared[chunk[k]][2]), arr(lambda k: prepared[chunk[k]][3]), nks,
+                arr(lambda k: prepared[chunk[k]][4]) if any_w else None,
+                arr(lambda k: dens[k].bt.centers), arr(lambda k: dens[k].bt.ranges), arr(lambda k: dens[k].bt.weights),
+                arr(lambda k: dens[k].bt.left_child), arr(lambda k: dens[k].bt.right_child),
+                arr(lambda k: dens[k].bt.lowest_leaf), arr(lambda k: dens[k].bt.highest_leaf),
+                arr(lambda k: dens[k].bt.permutation), arr(lambda k: dens[k].means), arr(lambda k: dens[k].bandwidth),
+                arr(lambda k: dens[k].bandwidthMin), arr(lambda k: dens[k].bandwidthMax), int(device)))
+            for k, i in enumerate(chunk):
+                out[i] = dens[k]
+    return out
 
 
 kde_b = kde  # spelling of `kde!` for callers that want the bang visible
