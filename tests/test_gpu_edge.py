@@ -83,6 +83,27 @@ def test_config4_full_batch_properties():
     assert np.isfinite(pe).all()
 
 
+def test_config4_total_chain_count_on_one_gpu():
+    """BASELINE config 4 as stated -- 3-D, 8 densities x 5000 points, Nout = 16384, Niter = 10 -- all chains on one GPU
+    (what `bench.py --strong --config c4 --gpus 1` times): properties over the whole batch, oracle parity on the
+    first chains, and the same chains drawn as eight shards (the 8-GPU split of the config) bit for bit."""
+    D, M, N, Np, Niter, seed = 3, 8, 5000, 16384, 10, 4
+    gp, op = _make_inputs(44, D, M, N)
+    with kdehip.ProductPlan(gp) as plan:
+        pn, i_n = plan.sample(Np, Niter=Niter, seed=seed, addEntropy=False)
+        K, R = plan.randu_per_sample(Niter), plan.randn_per_sample()
+        shards = [plan.sample(Np // 8, Niter=Niter, seed=seed, sample_offset=g * (Np // 8), addEntropy=False)
+                  for g in range(8)]
+    assert i_n.min() >= 2 and i_n.max() <= N + 1
+    assert np.allclose(pn, _closed_form_points(gp, i_n), rtol=1e-11, atol=1e-12)
+    assert np.array_equal(np.concatenate([s[0] for s in shards], axis=1), pn)
+    assert np.array_equal(np.concatenate([s[1] for s in shards], axis=1), i_n)
+    ns = 12
+    u, n = kdehip.philox_streams(seed, 0, ns, K, R)
+    o_pts, o_ind = oracle.gibbs1(op, ns, Niter, u, n, addEntropy=False)
+    assert np.array_equal(i_n[:, :ns], o_ind) and np.allclose(pn[:, :ns], o_pts, rtol=1e-11, atol=1e-11)
+
+
 def test_zero_chains_and_argument_errors():
     gp, _ = _make_inputs(1, 2, 2, 20)
     with kdehip.ProductPlan(gp) as plan:
