@@ -268,7 +268,8 @@ namespace {
 
 constexpr double kGoldenTol = 1e-2;  // ksize, src/CrossValidation.jl:116
 constexpr int kPrepThreads = 1024;
-constexpr int64_t kPrepMaxN = 4096;  // marginals up to this size are prepared on the device (LDS: 40 bytes per point)
+constexpr int64_t kPrepMaxN = 2048;  // marginals up to this size are prepared on the device (LDS: 40 bytes per point of the
+                                     // next power of two: 80 KiB; 4096 points would need all 160 KiB plus the statics)
 
 // State of one 1-D golden-section search (golden, src/CrossValidation.jl:44-98) + what ksize needs around it.
 struct Golden {

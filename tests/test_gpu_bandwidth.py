@@ -40,7 +40,7 @@ def test_loocv_bandwidth_reproduces_reference_golden(golden_dir):
     check_density_against_golden(_Flat(d), gold, 1e-4)
 
 
-@pytest.mark.parametrize("D,N", [(1, 100), (2, 300), (3, 64), (6, 2048), (4, 1000)])
+@pytest.mark.parametrize("D,N", [(1, 100), (2, 300), (3, 64), (6, 2048), (4, 1000), (2, 2), (3, 7), (2, 3000), (1, 5000)])
 def test_loocv_bandwidth_parity_with_oracle(D, N):
     rng = np.random.default_rng(100 + D)
     pts = rng.standard_normal((D, N)) * rng.uniform(0.3, 3.0, size=(D, 1)) + rng.uniform(-2, 2, size=(D, 1))
