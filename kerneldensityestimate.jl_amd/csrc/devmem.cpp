@@ -74,7 +74,7 @@ int DeviceGuard::enter(int device) {
   if (cur == device) return KDEHIP_OK;
   e = hipSetDevice(device);
   if (e != hipSuccess) return set_error(KDEHIP_ERR_NO_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e));
-  prev_ = cur;
+  if (!switched_) prev_ = cur;  // (a guard may be entered repeatedly -- multi-GPU loops --: it restores the FIRST device)
   switched_ = true;
   return KDEHIP_OK;
 }

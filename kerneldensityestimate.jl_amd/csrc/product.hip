@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -251,6 +252,21 @@ int instantiate(const PlanImage &im, int device, kdehip_product **out) {
   return KDEHIP_OK;
 }
 
+// Physical ordinal of logical device `d` of a multi-GPU call.  Normally the identity.  With KDEHIP_ALIAS_DEVICES=1
+// (tests on single-GPU machines) logical devices wrap around the visible ones, so that the complete N > 1 code path
+// -- slicing, per-device plans, peer copies, event waits -- runs on one GPU: several "devices" are then the same
+// physical one, which every step of that path tolerates (a peer copy becomes a device-to-device copy).
+inline bool alias_devices() {
+  static const bool on = [] { const char *e = std::getenv("KDEHIP_ALIAS_DEVICES"); return e && e[0] == '1'; }();
+  return on;
+}
+inline int phys(int d) {
+  if (!alias_devices()) return d;
+  int n = 1;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) n = 1;
+  return d % n;
+}
+
 // contiguous share of `Np` chains for device g of G
 inline int64_t share_begin(int64_t Np, int g, int G) { return Np * g / G; }
 
@@ -259,7 +275,8 @@ int check_devices(int device, int ngpus) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
     return set_error(KDEHIP_ERR_NO_DEVICE, "no HIP device available (libkdehip has no CPU fallback by design)");
-  if (device < 0 || device + ngpus > n) return set_error(KDEHIP_ERR_ARG, "device range outside the visible devices");
+  if (alias_devices() ? (device < 0 || ngpus > KDEHIP_MAX_DENS) : (device < 0 || device + ngpus > n))
+    return set_error(KDEHIP_ERR_ARG, "device range outside the visible devices");
   return KDEHIP_OK;
 }
 
@@ -443,7 +460,7 @@ int one_shot(int Ndens, const kdehip_density *trees, int64_t Np, int Niter, doub
   // launch everywhere first (uploads and kernels of different devices overlap), then collect
   for (int g = 0; g < ngpus; ++g) {
     Shard &S = sh[g];
-    S.device = device + g;
+    S.device = phys(device + g);
     S.lo = share_begin(Np, g, ngpus);
     S.hi = share_begin(Np, g + 1, ngpus);
     const int64_t n = S.hi - S.lo;
@@ -547,10 +564,10 @@ int kdehip_product_multi_create(kdehip_product_multi **out, int Ndens, const kde
   DeviceGuard guard;
   for (int g = 0; g < ngpus && rc == KDEHIP_OK; ++g) {
     kdehip_product *p = nullptr;
-    rc = instantiate(im, first_device + g, &p);
+    rc = instantiate(im, phys(first_device + g), &p);
     if (rc != KDEHIP_OK) break;
     mp->plans.push_back(p);
-    rc = guard.enter(first_device + g);
+    rc = guard.enter(phys(first_device + g));
     if (rc != KDEHIP_OK) break;
     hipEvent_t ev;
     if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { rc = set_error(KDEHIP_ERR_HIP, "hipEventCreate failed"); break; }
@@ -558,8 +575,9 @@ int kdehip_product_multi_create(kdehip_product_multi **out, int Ndens, const kde
     // direct peer writes over xGMI where the topology allows them (hipMemcpyPeerAsync stages through the host otherwise)
     for (int h = 0; h < ngpus; ++h) {
       int can = 0;
-      if (h != g && hipDeviceCanAccessPeer(&can, first_device + g, first_device + h) == hipSuccess && can)
-        (void)hipDeviceEnablePeerAccess(first_device + h, 0);  // "already enabled" is fine
+      if (phys(first_device + h) != phys(first_device + g) &&
+          hipDeviceCanAccessPeer(&can, phys(first_device + g), phys(first_device + h)) == hipSuccess && can)
+        (void)hipDeviceEnablePeerAccess(phys(first_device + h), 0);  // "already enabled" is fine
     }
     (void)hipGetLastError();
   }
@@ -572,7 +590,7 @@ void kdehip_product_multi_destroy(kdehip_product_multi *mp) {
   if (!mp) return;
   DeviceGuard guard;
   for (size_t g = 0; g < mp->done.size(); ++g)
-    if (guard.enter(mp->first_device + static_cast<int>(g)) == KDEHIP_OK) {
+    if (guard.enter(phys(mp->first_device + static_cast<int>(g))) == KDEHIP_OK) {
       (void)hipDeviceSynchronize();
       (void)hipEventDestroy(mp->done[g]);
     }
@@ -597,7 +615,7 @@ int kdehip_product_multi_sample_philox(kdehip_product_multi *mp, int64_t Np, int
   for (int g = 0; g < G; ++g) {
     const int64_t lo = share_begin(Np, g, G), hi = share_begin(Np, g + 1, G);
     if (!d_points[g] || !d_indices[g]) return set_error(KDEHIP_ERR_ARG, "null output pointer");
-    int rc = guard.enter(mp->first_device + g);
+    int rc = guard.enter(phys(mp->first_device + g));
     if (rc != KDEHIP_OK) return rc;
     hipStream_t st = static_cast<hipStream_t>(streams ? streams[g] : nullptr);
     if (hi > lo) {
@@ -609,17 +627,17 @@ int kdehip_product_multi_sample_philox(kdehip_product_multi *mp, int64_t Np, int
       // the all-gather of [pGM | indices]: device g writes its slice into every other device's arrays
       for (int h = 0; h < G; ++h) {
         if (h == g) continue;
-        KDEHIP_CHECK(hipMemcpyPeerAsync(d_points[h] + lo * D, mp->first_device + h, d_points[g] + lo * D,
-                                        mp->first_device + g, sizeof(double) * D * (hi - lo), st));
-        KDEHIP_CHECK(hipMemcpyPeerAsync(d_indices[h] + lo * M, mp->first_device + h, d_indices[g] + lo * M,
-                                        mp->first_device + g, sizeof(int64_t) * M * (hi - lo), st));
+        KDEHIP_CHECK(hipMemcpyPeerAsync(d_points[h] + lo * D, phys(mp->first_device + h), d_points[g] + lo * D,
+                                        phys(mp->first_device + g), sizeof(double) * D * (hi - lo), st));
+        KDEHIP_CHECK(hipMemcpyPeerAsync(d_indices[h] + lo * M, phys(mp->first_device + h), d_indices[g] + lo * M,
+                                        phys(mp->first_device + g), sizeof(int64_t) * M * (hi - lo), st));
       }
     }
     KDEHIP_CHECK(hipEventRecord(mp->done[g], st));
   }
   // every device's stream continues only once all slices have arrived in its arrays
   for (int h = 0; h < G; ++h) {
-    int rc = guard.enter(mp->first_device + h);
+    int rc = guard.enter(phys(mp->first_device + h));
     if (rc != KDEHIP_OK) return rc;
     hipStream_t st = static_cast<hipStream_t>(streams ? streams[h] : nullptr);
     for (int g = 0; g < G; ++g)

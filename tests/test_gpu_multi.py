@@ -96,3 +96,57 @@ def test_two_devices_equal_one_device():
             torch.cuda.synchronize(d)
             assert np.array_equal(Ps[d].cpu().numpy().reshape(Np, D).T, one[0])   # every device holds everything
             assert np.array_equal(Is[d].cpu().numpy().reshape(Np, M).T, one[1])
+
+
+_ALIAS_SCRIPT = r'''
+import numpy as np, torch, kdehip
+from oracle import oracle
+from tests.helpers import silverman_bw, synth_mixture
+rng = np.random.default_rng(11)
+D, M, N, Np, Niter, seed = 3, 3, 400, 1001, 3, 21
+pts = [synth_mixture(rng, D, N) for _ in range(M)]
+g = [kdehip.kde(p, silverman_bw(p)) for p in pts]
+one = kdehip.prodAppxMSGibbsS(None, g, None, None, Niter=Niter, Np=Np, seed=seed, ngpus=1)
+for G in (2, 3, 8):
+    many = kdehip.prodAppxMSGibbsS(None, g, None, None, Niter=Niter, Np=Np, seed=seed, ngpus=G)
+    assert np.array_equal(one[0], many[0]) and np.array_equal(one[1], many[1]), G
+# caller streams + label trace over 3 logical devices
+K, R, nU, nN = oracle.rng_sizes(M, D, Np, Niter, [N] * M)
+randU, randN = rng.random(nU), rng.standard_normal(nN)
+res = []
+for G in (1, 3):
+    glbs = kdehip.makeEmptyGbGlb(recordChoosen=True)
+    p = np.zeros(D * Np); i = np.ones((M, Np), dtype=np.int64)
+    kdehip.gibbs1(M, g, Np, Niter, p, i, randU, randN, glbs=glbs, ngpus=G)
+    res.append((p.copy(), i.copy(), glbs.labelsChoosen))
+assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and res[0][2] == res[1][2]
+o = oracle.gibbs1([oracle.OracleDensity(p, silverman_bw(p)) for p in pts], Np, Niter, randU, randN)
+assert np.array_equal(res[1][1], o[1])
+# resident plans on 4 logical devices, a stream each: afterwards EVERY device array holds the complete result
+dev = torch.device("cuda", 0)
+with kdehip.MultiProductPlan(g, first_device=0, ngpus=4) as mp:
+    assert mp.ngpus == 4
+    Ps = [torch.zeros(D * Np, dtype=torch.float64, device=dev) for _ in range(4)]
+    Is = [torch.zeros(M * Np, dtype=torch.int64, device=dev) for _ in range(4)]
+    sts = [torch.cuda.Stream(device=dev) for _ in range(4)]
+    for rep in range(2):
+        mp.sample_philox_device(Np, Niter, seed, 0, True, Ps, Is, [s.cuda_stream for s in sts])
+    for k in range(4):
+        sts[k].synchronize()
+        assert np.array_equal(Ps[k].cpu().numpy().reshape(Np, D).T, one[0]), k
+        assert np.array_equal(Is[k].cpu().numpy().reshape(Np, M).T, one[1]), k
+print("alias ok")
+'''
+
+
+def test_multi_device_code_paths_with_aliased_devices():
+    """KDEHIP_ALIAS_DEVICES=1 lets logical devices wrap around the visible ones: the complete N > 1 paths (slicing,
+    one plan per device, per-device streams, peer-copy all-gather, event waits, per-device result slices) run on one
+    GPU and must reproduce the one-device result bit for bit."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, KDEHIP_ALIAS_DEVICES="1", PYTHONPATH=root)
+    out = subprocess.run([sys.executable, "-c", _ALIAS_SCRIPT], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "alias ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
