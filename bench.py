@@ -210,6 +210,16 @@ def main():
         achieved_tf = alg_flops / (kern_ms * 1e-3) / 1e12
         peak_tf = VALU_PEAK_TFLOPS[prec]
         prof = load_traffic(args.config)
+        # The physical floor of the vector pipe: the committed instruction mix of this workload's kernel
+        # (profiles/*_valu_mix.json) priced with the issue costs measured by scripts/micro/valu_rates.hip, at the
+        # clock the chip held in that profile; frac = floor / the kernel time measured live above.
+        vf = prof.get("valu_floor")
+        valu_floor = None
+        if vf:
+            floor_ms = vf["cycles_per_chain"] * float(hi - lo) / vf["simds"] / (vf["clock_ghz"] * 1e6)
+            valu_floor = {"ms": floor_ms, "frac": floor_ms / kern_ms, "clock_ghz": vf["clock_ghz"],
+                          "valu_cycles_per_chain": vf["cycles_per_chain"], "mix_per_chain": vf["mix_per_chain"],
+                          "issue_cost_cycles": vf["issue_cost_cycles"], "source": vf["source"]}
         out = {
             "metric": "gibbs_product_samples_per_sec",
             "value": Np_total * args.steps / elapsed,
@@ -237,6 +247,7 @@ def main():
                          # issue-slot view from the committed PMC profile of this workload (profiles/): instructions the
                          # wavefronts issued per chain against the 4-cycle issue slots of their lifetime
                          "issue": prof.get("issue"),
+                         "valu_floor": valu_floor,
                          "note": "working set is LDS/L2 resident (HBM traffic ~0.1 % of peak): bound by vector issue + per-step latency"},
             # SURVEY.md 8(d)'s figure, kept for continuity: algorithmic bytes / kernel time against 8 TB/s.  NOT a roofline
             # (the bytes never come from HBM; the ratio exceeds 1).

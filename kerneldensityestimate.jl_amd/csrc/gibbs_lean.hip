@@ -433,8 +433,13 @@ int KDEHIP_CAT(launch_lean_d, KDEHIP_DIM)(int precision, int mode, const PlanDev
   hipStream_t st = static_cast<hipStream_t>(stream);
   const bool f64 = (precision == 64);
 #ifdef KDEHIP_LEAN_DEV  // development builds (scripts/dev_lean.sh): only the config-3 instantiation, compiles in seconds
+#ifdef KDEHIP_LEAN_DEV_F32  // ... or only config 5's (fp32, 16 chains per workgroup)
+  if (f64 || plan.M != 4 || chains_per_workgroup(args.Np, args.variant) != 16) return kLeanNotCovered;
+  launch_lean_waves<float, D, 4, 16>(plan, args, st);
+#else
   if (!f64 || plan.M != 4 || chains_per_workgroup(args.Np, args.variant) != 8) return kLeanNotCovered;
   launch_lean_waves<double, D, 4, 8>(plan, args, st);
+#endif
   return KDEHIP_OK;
 #else
   switch (plan.M) {

@@ -35,6 +35,9 @@ def test_bench_single_gpu_json_contract():
     assert r["bound"] == "valu" and r["peak"] == 78.6 and r["unit"] == "TFLOP/s"
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0.0 < r["frac"] < 1.0
     assert d["normalised_hbm"]["peak_GBps"] == 8000.0 and d["julia"] in ("absent", "present")
+    # the physical floor of the vector pipe (committed instruction mix x measured issue costs): below the measured time
+    vf = r["valu_floor"]
+    assert 0.2 < vf["frac"] < 1.0 and abs(vf["frac"] - vf["ms"] / r["kernel_ms"]) < 1e-12
     ci = d["call_inclusive"]
     assert ci["ms"] > d["roofline"]["kernel_ms"] and ci["gibbs1_caller_streams_ms"] > ci["ms"] * 0.8
     assert d["parity"]["label_mismatches"] == 0 and d["parity"]["moment_mean_diff"] < 1e-6
