@@ -42,7 +42,8 @@ int chains_per_workgroup(int64_t Np, int variant) {
 
 #define KDEHIP_DECL(d)                                                                  \
   int launch_gibbs_d##d(int, int, const PlanDev &, const RunArgs &, void *);           \
-  int launch_lean_d##d(int, int, const PlanDev &, const RunArgs &, void *);
+  int launch_lean_d##d(int, int, const PlanDev &, const RunArgs &, void *);             \
+  int launch_lean_hi_d##d(int, int, const PlanDev &, const RunArgs &, void *);
 KDEHIP_DECL(1) KDEHIP_DECL(2) KDEHIP_DECL(3) KDEHIP_DECL(4) KDEHIP_DECL(5) KDEHIP_DECL(6) KDEHIP_DECL(7) KDEHIP_DECL(8)
 #undef KDEHIP_DECL
 
@@ -51,7 +52,21 @@ int launch_gibbs(int precision, int mode, const PlanDev &plan, const RunArgs &ar
   const int v = args.variant % 1000;
   const bool generic_only = (v >= kVariantGenericBase && v < kVariantGenericBase + 20);
   if (generic_only) args.variant -= kVariantGenericBase;
-  if (!generic_only) {  // products of 2..4 densities, all dimensions active: the register-resident kernel
+  if (!generic_only && plan.M > 4) {  // 5..8 densities at 8 or 16 chains per workgroup: the same kernel, second set
+    int rc = kLeanNotCovered;
+    switch (plan.D) {
+      case 1: rc = launch_lean_hi_d1(precision, mode, plan, args, stream); break;
+      case 2: rc = launch_lean_hi_d2(precision, mode, plan, args, stream); break;
+      case 3: rc = launch_lean_hi_d3(precision, mode, plan, args, stream); break;
+      case 4: rc = launch_lean_hi_d4(precision, mode, plan, args, stream); break;
+      case 5: rc = launch_lean_hi_d5(precision, mode, plan, args, stream); break;
+      case 6: rc = launch_lean_hi_d6(precision, mode, plan, args, stream); break;
+      case 7: rc = launch_lean_hi_d7(precision, mode, plan, args, stream); break;
+      case 8: rc = launch_lean_hi_d8(precision, mode, plan, args, stream); break;
+      default: break;
+    }
+    if (rc != kLeanNotCovered) return rc;
+  } else if (!generic_only) {  // products of 2..4 densities, all dimensions active: the register-resident kernel
     int rc = kLeanNotCovered;
     switch (plan.D) {
       case 1: rc = launch_lean_d1(precision, mode, plan, args, stream); break;

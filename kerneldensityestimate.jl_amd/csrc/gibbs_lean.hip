@@ -29,6 +29,14 @@ __device__ __forceinline__ void static_for(F &&f) {
   }
 }
 
+// Two translation units per dimension count: products of 2..4 densities at every workgroup width and both
+// precisions, and (with -DKDEHIP_LEAN_HI) fp64 products of 5..8 densities at 8 and 16 chains per workgroup (build
+// time: the kernel is instantiated per density count, precision and width).
+#if defined(KDEHIP_LEAN_HI) || (defined(KDEHIP_LEAN_DEV_M) && KDEHIP_LEAN_DEV_M > 4)
+constexpr int kLeanMinDens = 5, kLeanMaxDens = 8;
+#else
+constexpr int kLeanMinDens = 2, kLeanMaxDens = 4;
+#endif
 constexpr int kLeanMaxNormals = 128;  // D*(L+1) normals of a chain kept in LDS (1 KiB per wavefront)
 
 // A scalar copied through an opaque move: the copy is a register of its own.  The level descriptors arrive as one
@@ -423,24 +431,59 @@ static int launch_lean_m(const PlanDev &plan, const RunArgs &args, hipStream_t s
 #define KDEHIP_CAT2(a, b) a##b
 #define KDEHIP_CAT(a, b) KDEHIP_CAT2(a, b)
 
+template <typename T, int D, int M>
+static int launch_lean_m_hi(const PlanDev &plan, const RunArgs &args, hipStream_t stream) {
+  const int waves = chains_per_workgroup(args.Np, args.variant);
+  if (waves == 16) launch_lean_waves<T, D, M, 16>(plan, args, stream);
+  else if (waves == 8) launch_lean_waves<T, D, M, 8>(plan, args, stream);
+  else return kLeanNotCovered;
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess)
+    return set_error(KDEHIP_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString(e));
+  return KDEHIP_OK;
+}
+
+#ifdef KDEHIP_LEAN_HI
+#define KDEHIP_LEAN_ENTRY launch_lean_hi_d
+#else
+#define KDEHIP_LEAN_ENTRY launch_lean_d
+#endif
+
 // Returns kLeanNotCovered when the run is outside this kernel's domain (the caller then uses gibbs_kernel.hip).
-int KDEHIP_CAT(launch_lean_d, KDEHIP_DIM)(int precision, int mode, const PlanDev &plan, const RunArgs &args,
-                                          void *stream) {
+int KDEHIP_CAT(KDEHIP_LEAN_ENTRY, KDEHIP_DIM)(int precision, int mode, const PlanDev &plan, const RunArgs &args,
+                                              void *stream) {
   constexpr int D = KDEHIP_DIM;
-  if (mode != kModeFast || args.table_build || plan.M < 2 || plan.M > 4 || D * (plan.L + 1) > kLeanMaxNormals)
+  if (mode != kModeFast || args.table_build || plan.M < kLeanMinDens || plan.M > kLeanMaxDens ||
+      D * (plan.L + 1) > kLeanMaxNormals)
     return kLeanNotCovered;
   if (args.Np <= 0) return KDEHIP_OK;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const bool f64 = (precision == 64);
-#ifdef KDEHIP_LEAN_DEV  // development builds (scripts/dev_lean.sh): only the config-3 instantiation, compiles in seconds
-#ifdef KDEHIP_LEAN_DEV_F32  // ... or only config 5's (fp32, 16 chains per workgroup)
-  if (f64 || plan.M != 4 || chains_per_workgroup(args.Np, args.variant) != 16) return kLeanNotCovered;
-  launch_lean_waves<float, D, 4, 16>(plan, args, st);
-#else
-  if (!f64 || plan.M != 4 || chains_per_workgroup(args.Np, args.variant) != 8) return kLeanNotCovered;
-  launch_lean_waves<double, D, 4, 8>(plan, args, st);
+#ifdef KDEHIP_LEAN_DEV  // development builds (scripts/dev_lean.sh): ONE instantiation, compiles in seconds
+#ifndef KDEHIP_LEAN_DEV_M
+#define KDEHIP_LEAN_DEV_M 4
 #endif
+#ifndef KDEHIP_LEAN_DEV_W
+#define KDEHIP_LEAN_DEV_W 8
+#endif
+#ifdef KDEHIP_LEAN_DEV_F32
+  using DevT = float;
+#else
+  using DevT = double;
+#endif
+  if (f64 != (sizeof(DevT) == 8) || plan.M != KDEHIP_LEAN_DEV_M ||
+      chains_per_workgroup(args.Np, args.variant) != KDEHIP_LEAN_DEV_W)
+    return kLeanNotCovered;
+  launch_lean_waves<DevT, D, KDEHIP_LEAN_DEV_M, KDEHIP_LEAN_DEV_W>(plan, args, st);
   return KDEHIP_OK;
+#elif defined(KDEHIP_LEAN_HI)
+  if (!f64) return kLeanNotCovered;  // (fp32 products of more than 4 densities run the general kernel: build time)
+  switch (plan.M) {
+    case 5: return launch_lean_m_hi<double, D, 5>(plan, args, st);
+    case 6: return launch_lean_m_hi<double, D, 6>(plan, args, st);
+    case 7: return launch_lean_m_hi<double, D, 7>(plan, args, st);
+    default: return launch_lean_m_hi<double, D, 8>(plan, args, st);
+  }
 #else
   switch (plan.M) {
     case 2: return f64 ? launch_lean_m<double, D, 2>(plan, args, st) : launch_lean_m<float, D, 2>(plan, args, st);

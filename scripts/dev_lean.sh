@@ -1,13 +1,14 @@
 #!/bin/bash
-# Development build of the lean sampler: compiles ONLY the config-3 instantiation (fp64, D = 6, M = 4, 8 chains per
-# workgroup) of gibbs_lean.hip with extra flags and links it with the objects of the regular build into
+# Development build of the lean sampler: compiles ONE instantiation of gibbs_lean.hip (default: config 3's -- fp64,
+# D = 6, M = 4, 8 chains per workgroup) with extra flags and links it with the objects of the regular build into
 # kerneldensityestimate.jl_amd/libkdehip_<tag>.so, for interleaved A/B runs with scripts/ab_libs.py.
-#   scripts/dev_lean.sh <tag> [extra hipcc flags...]
+#   [DIM=6] scripts/dev_lean.sh <tag> [extra hipcc flags...]
+#   other instantiations: -DKDEHIP_LEAN_DEV_F32, -DKDEHIP_LEAN_DEV_M=<densities>, -DKDEHIP_LEAN_DEV_W=<chains per workgroup>
 set -e
 TAG=$1; shift
 cd "$(dirname "$0")/../kerneldensityestimate.jl_amd/csrc"
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wextra -Wno-unused-parameter --offload-arch=gfx950 \
-  -munsafe-fp-atomics -mllvm -disable-vector-combine -DKDEHIP_DIM=6 -DKDEHIP_LEAN_DEV "$@" -c gibbs_lean.hip -o build/dev_lean_$TAG.o
-OBJS=$(ls build/*.o | grep -v "gibbs_lean_d6.o" | grep -v "dev_lean_")
+  -munsafe-fp-atomics -mllvm -disable-vector-combine -DKDEHIP_DIM=${DIM:-6} -DKDEHIP_LEAN_DEV "$@" -c gibbs_lean.hip -o build/dev_lean_$TAG.o
+OBJS=$(ls build/*.o | grep -v "gibbs_lean_d${DIM:-6}.o" | grep -v "dev_lean_")
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../libkdehip_$TAG.so $OBJS build/dev_lean_$TAG.o
 ls -la ../libkdehip_$TAG.so

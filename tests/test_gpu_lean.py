@@ -1,4 +1,4 @@
-"""The register-resident kernel for products of 2..4 densities (csrc/gibbs_lean.hip) against the general kernel
+"""The register-resident kernel for products of 2..4 (fp64: 2..8) densities (csrc/gibbs_lean.hip) against the general kernel
 (csrc/gibbs_kernel.hip, forced with plan variants 30+): same labels, bit-identical points, every staging mode,
 both precisions, with and without conditional tables; plus oracle parity through the lean path."""
 import numpy as np
@@ -53,6 +53,34 @@ def test_lean_kernel_equals_general_kernel(D, Ns, Np, Niter, weighted, prec):
         op, oi, ol = oracle.gibbs1(o, Np, Niter, u, n, want_labels=True)
         assert np.array_equal(res[0][1], oi) and np.array_equal(res[0][2], ol)
         assert np.allclose(res[0][0], op, rtol=1e-11, atol=1e-11)
+
+
+@pytest.mark.parametrize("D,Ns,Np,Niter,weighted", [
+    (3, [5000] * 8, 48, 2, False),                     # BASELINE config 4's shape: chunked staging, 8 densities
+    (2, [120, 80, 200, 64, 33], 64, 3, True),          # 5 ragged, weighted densities
+    (6, [300] * 6, 50, 2, False),
+    (1, [50, 64, 65, 7, 100, 128, 90], 80, 3, False),  # 7 densities
+])
+def test_lean_kernel_5_to_8_densities(D, Ns, Np, Niter, weighted):
+    """fp64 products of 5..8 densities take the lean kernel at 8 and 16 chains per workgroup (variants 8, 16) and the
+    general kernel otherwise (default width for these chain counts; variants 38, 46 force it at the same widths):
+    identical labels and points, equal to the oracle's."""
+    g, o = _trees(900 + D + len(Ns), D, Ns, weighted)
+    seed = 78
+    with kdehip.ProductPlan(g) as plan:
+        assert plan.fast_math_path
+        res = {}
+        for variant in (8, 16, 0, 38, 46):
+            plan.set_variant(variant)
+            res[variant] = plan.sample(Np, Niter=Niter, seed=seed, want_labels=True)
+        K, R = plan.randu_per_sample(Niter), plan.randn_per_sample()
+    for variant in (16, 0, 38, 46):
+        for a, b in zip(res[8], res[variant]):
+            assert np.array_equal(a, b), variant
+    u, n = kdehip.philox_streams(seed, 0, Np, K, R)
+    op, oi, ol = oracle.gibbs1(o, Np, Niter, u, n, want_labels=True)
+    assert np.array_equal(res[8][1], oi) and np.array_equal(res[8][2], ol)
+    assert np.allclose(res[8][0], op, rtol=1e-11, atol=1e-11)
 
 
 @pytest.mark.parametrize("width", [2, 8, 12, 16])
