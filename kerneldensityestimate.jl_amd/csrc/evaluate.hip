@@ -217,41 +217,59 @@ extern "C" int kdehip_evaluate(const kdehip_density *bd, const double *pos, int6
 
   const GroupSplit gs = split_chunks(N, Nq, 1);
   const int nchunks = gs.ngroups;  // partial sums per query
-  DevBuf d_src, d_w, d_q, d_part, d_out, d_idx;
-  KDEHIP_CHECK(d_src.alloc(sizeof(double) * N * D));
-  KDEHIP_CHECK(d_w.alloc(sizeof(double) * N));
+  // ONE pinned image [points | weights | queries or output positions] goes up in one DMA, the results come back in
+  // one; everything is enqueued on the null stream and the host waits once (pageable hipMemcpy calls, one per
+  // array, cost more than the kernel for anything below ~10^8 kernel evaluations).
+  const size_t o_src = 0;
+  const size_t o_w = o_src + sizeof(double) * N * D;
+  const size_t o_q = o_w + sizeof(double) * N;
+  const size_t up_bytes = o_q + (leave_one_out ? sizeof(int64_t) * N : sizeof(double) * Nq * D);
+  const size_t o_out = (up_bytes + 255) & ~size_t(255);
+  const size_t pin_bytes = o_out + sizeof(double) * Nq;
+  struct Pinned {
+    void *p = nullptr; size_t n = 0;
+    ~Pinned() { if (p) cached_host_free(p, n); }
+  } pin;
+  pin.n = pin_bytes;
+  KDEHIP_CHECK(cached_host_malloc(&pin.p, pin.n));
+  unsigned char *h = static_cast<unsigned char *>(pin.p);
+  std::memcpy(h + o_src, leaf_pts, sizeof(double) * N * D);
+  std::memcpy(h + o_w, bd->weights + N, sizeof(double) * N);
+  if (leave_one_out) {  // p[getIndexOf(locations, j)] (:335): results in the caller's original order
+    int64_t *idx = reinterpret_cast<int64_t *>(h + o_q);
+    for (int64_t i = 0; i < N; ++i) idx[i] = bd->permutation[N + i] - 1;
+  } else {
+    std::memcpy(h + o_q, pos, sizeof(double) * Nq * D);
+  }
+  DevBuf d_up, d_part, d_out;
+  KDEHIP_CHECK(d_up.alloc(up_bytes));
   KDEHIP_CHECK(d_part.alloc(sizeof(double) * nchunks * Nq));
   KDEHIP_CHECK(d_out.alloc(sizeof(double) * Nq));
-  KDEHIP_CHECK(hipMemcpy(d_src.p, leaf_pts, sizeof(double) * N * D, hipMemcpyHostToDevice));
-  KDEHIP_CHECK(hipMemcpy(d_w.p, bd->weights + N, sizeof(double) * N, hipMemcpyHostToDevice));
-  std::vector<int64_t> idx;
-  if (leave_one_out) {  // p[getIndexOf(locations, j)] (:335): results in the caller's original order
-    idx.resize(N);
-    for (int64_t i = 0; i < N; ++i) idx[i] = bd->permutation[N + i] - 1;
-    KDEHIP_CHECK(d_idx.alloc(sizeof(int64_t) * N));
-    KDEHIP_CHECK(hipMemcpy(d_idx.p, idx.data(), sizeof(int64_t) * N, hipMemcpyHostToDevice));
-  } else {
-    KDEHIP_CHECK(d_q.alloc(sizeof(double) * Nq * D));
-    KDEHIP_CHECK(hipMemcpy(d_q.p, pos, sizeof(double) * Nq * D, hipMemcpyHostToDevice));
-  }
+  unsigned char *du = d_up.as<unsigned char>();
+  KDEHIP_CHECK(hipMemcpyAsync(du, h, up_bytes, hipMemcpyHostToDevice, nullptr));
+  const double *d_src = reinterpret_cast<const double *>(du + o_src);
+  const double *d_w = reinterpret_cast<const double *>(du + o_w);
   EvalBatch eb{};
   FinishBatch fb{};
   EvalProblem &pb = eb.p[0];
-  pb.src = d_src.as<double>(); pb.w = d_w.as<double>();
-  pb.qry = leave_one_out ? d_src.as<double>() : d_q.as<double>();
+  pb.src = d_src; pb.w = d_w;
+  pb.qry = leave_one_out ? d_src : reinterpret_cast<const double *>(du + o_q);
   pb.partial = d_part.as<double>(); pb.N = N; pb.Nq = Nq; pb.chunks_per_group = gs.chunks_per_group;
   for (int k = 0; k < D; ++k) pb.nhib[k] = -0.5 / bw[k];
   FinishProblem &fp = fb.p[0];
-  fp.partial = d_part.as<double>(); fp.w = d_w.as<double>();
-  fp.out_idx = leave_one_out ? d_idx.as<int64_t>() : nullptr;
+  fp.partial = d_part.as<double>(); fp.w = d_w;
+  fp.out_idx = leave_one_out ? reinterpret_cast<const int64_t *>(du + o_q) : nullptr;
   fp.out = d_out.as<double>(); fp.inv_norm = 1.0 / gauss_norm(bw, D); fp.Nq = Nq; fp.nchunks = nchunks;
   rc = launch_partial_dims(D, eb, 1, Nq, gs.ngroups, leave_one_out ? 1 : 0, nullptr);
-  if (rc != KDEHIP_OK) return rc;
+  if (rc != KDEHIP_OK) { (void)hipDeviceSynchronize(); return rc; }
   hipLaunchKernelGGL(eval_finish_kernel, dim3(static_cast<unsigned>((Nq + 255) / 256), 1), dim3(256), 0, nullptr,
                      fb, leave_one_out ? 1 : 0);
-  KDEHIP_CHECK(hipGetLastError());
-  KDEHIP_CHECK(hipDeviceSynchronize());
-  KDEHIP_CHECK(hipMemcpy(p_out, d_out.p, sizeof(double) * Nq, hipMemcpyDeviceToHost));
+  hipError_t le = hipGetLastError();
+  if (le == hipSuccess) le = hipMemcpyAsync(h + o_out, d_out.p, sizeof(double) * Nq, hipMemcpyDeviceToHost, nullptr);
+  const hipError_t se = hipStreamSynchronize(nullptr);  // (also before the scratch goes back to the cache on an error)
+  KDEHIP_CHECK(le);
+  KDEHIP_CHECK(se);
+  std::memcpy(p_out, h + o_out, sizeof(double) * Nq);
   return KDEHIP_OK;
 }
 
