@@ -30,6 +30,25 @@ def test_evaluate_direct_parity(D, N, Nq, weighted):
         kdehip.evaluateDualTree(g, np.zeros((D + 1, 3)))
 
 
+def test_evaluate_large_batch_against_oracle_sample_and_split_invariance():
+    """10000 sources x 65536 queries (the grouped, multi-block path with one pinned image each way): a sample of the
+    queries against the oracle, and the same queries evaluated in two halves (another grouping of the source
+    chunks) to rounding."""
+    D, N, Nq = 6, 10000, 65536
+    rng = np.random.default_rng(99)
+    pts = rng.standard_normal((D, N))
+    bw = rng.uniform(0.3, 0.6, D)
+    g, o = kdehip.kde(pts, bw), oracle.OracleDensity(pts, bw)
+    pos = rng.standard_normal((D, Nq)) * 1.2
+    full = kdehip.evaluateDualTree(g, pos)
+    assert full.shape == (Nq,) and np.all(np.isfinite(full)) and np.all(full >= 0)
+    pick = rng.choice(Nq, size=96, replace=False)
+    assert np.allclose(full[pick], oracle.eval_direct(o, pos[:, pick]), rtol=1e-12, atol=1e-300)
+    halves = np.concatenate([kdehip.evaluateDualTree(g, pos[:, :Nq // 2]), kdehip.evaluateDualTree(g, pos[:, Nq // 2:])])
+    assert np.allclose(full, halves, rtol=1e-13, atol=1e-300)
+    assert np.array_equal(full, kdehip.evaluateDualTree(g, pos))   # deterministic
+
+
 def test_loocv_bandwidth_reproduces_reference_golden(golden_dir):
     """UnitTest1Dlcv01 (reference test/runtests.jl:104-116) through the GPU path."""
     from tests.test_host_cpu import _Flat
