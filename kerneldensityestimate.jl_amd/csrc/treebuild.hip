@@ -198,6 +198,13 @@ __device__ void lane_quick_select(double *K, uint16_t *S, int n, int pos) {
 __global__ __launch_bounds__(kTB) void tree_build_kernel(const TreeBatch batch, const TreeLds L) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ int s_nr, s_nnext, s_depth_off[kMaxDepth + 1];
+#ifdef KDEHIP_TREE_STAMPS
+  unsigned long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t_last = __builtin_amdgcn_s_memtime();
+#define TSTAMP(k) do { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); t_acc[k] += t_now - t_last; t_last = t_now; } while (0)
+#else
+#define TSTAMP(k) do {} while (0)
+#endif
   const TreeJob &J = batch.job[blockIdx.x];
   const int N = static_cast<int>(J.N), D = J.D;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -231,6 +238,7 @@ __global__ __launch_bounds__(kTB) void tree_build_kernel(const TreeBatch batch, 
     s_depth_off[0] = 0;
   }
   __syncthreads();
+  TSTAMP(0);
 
   int depth = 0;
   for (;; ++depth) {
@@ -244,6 +252,7 @@ __global__ __launch_bounds__(kTB) void tree_build_kernel(const TreeBatch batch, 
       U[i] = J.pts[static_cast<int64_t>(S[p]) * D + k];
     }
     __syncthreads();
+    TSTAMP(1);
     // widest dimension (most_spread_coord, :142-173): 8 lanes per range, lane k sums dimension k sequentially; the
     // reference leaves the LAST leaf of the range out of both sums while scaling by 1/(last - first)
     for (int r = tid >> 3; r < ((nr + 127) / 128) * 128; r += kTB / 8) {
@@ -274,12 +283,14 @@ __global__ __launch_bounds__(kTB) void tree_build_kernel(const TreeBatch batch, 
       if (r < nr && k == 0) dimv[r] = static_cast<uint8_t>(best);
     }
     __syncthreads();
+    TSTAMP(2);
     // keys of every range along its dimension
     for (int r = wave; r < nr; r += kTB / 64) {
       const int first = cur[r].first, n = cur[r].last - first + 1, k = dimv[r];
       for (int i = lane; i < n; i += 64) K[first + i] = U[static_cast<size_t>(first + i) * D + k];
     }
     __syncthreads();  // (the union region now belongs to the select phase)
+    TSTAMP(3);
     // quick-select around the median leaf (select!, :223-242): large ranges by wavefronts, small ones by lanes
     for (int r = wave; r < nr; r += kTB / 64) {
       const int first = cur[r].first, n = cur[r].last - first + 1;
@@ -293,6 +304,7 @@ __global__ __launch_bounds__(kTB) void tree_build_kernel(const TreeBatch batch, 
       if (n <= kSeqMax) lane_quick_select(K + first, S + first, n, ((first + cur[r].last) >> 1) - first);
     }
     __syncthreads();
+    TSTAMP(4);
     // buildBall! bookkeeping (:342-411): child ids handed out left, then right, before either subtree is built; a
     // one-leaf side points straight at the leaf; the left subtree uses (leaves - 2) more ids before the right one
     for (int r = tid; r < nr; r += kTB) {
@@ -323,6 +335,7 @@ __global__ __launch_bounds__(kTB) void tree_build_kernel(const TreeBatch batch, 
     if (tid == 0) s_nr = s_nnext;
     Range *t = cur; cur = nxt; nxt = t;
     __syncthreads();
+    TSTAMP(5);
   }
 
   // ---- leaves in their final order (buildTree! :419-429 after all swaps) ----
@@ -338,6 +351,7 @@ __global__ __launch_bounds__(kTB) void tree_build_kernel(const TreeBatch batch, 
     }
   }
   __syncthreads();
+  TSTAMP(6);
   // ---- node statistics bottom-up (calcStatsBall! :282-336, calcStatsDensity! BallTreeDensity01.jl:141-187) ----
   for (int dd = depth - 1; dd >= 0; --dd) {
     const int begin = s_depth_off[dd], end = s_depth_off[dd + 1];
@@ -368,6 +382,12 @@ __global__ __launch_bounds__(kTB) void tree_build_kernel(const TreeBatch batch, 
     __threadfence_block();
     __syncthreads();
   }
+  TSTAMP(7);
+#ifdef KDEHIP_TREE_STAMPS
+  if (tid == 0 && blockIdx.x == 0)
+    printf("tree stamps (shader cycles): init %llu | gather %llu | widest %llu | keys %llu | select %llu | children %llu | leaves %llu | stats %llu | depths %d\n",
+           t_acc[0], t_acc[1], t_acc[2], t_acc[3], t_acc[4], t_acc[5], t_acc[6], t_acc[7], depth);
+#endif
 }
 
 }  // namespace
