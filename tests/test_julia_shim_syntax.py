@@ -1,0 +1,109 @@
+"""Julia is absent from the build image, so the shim (`julia/KernelDensityEstimateHIP.jl`) and the cross-check script
+(`oracle/julia_crosscheck.jl`) cannot be executed here.  What can be checked without Julia: block structure
+(every `function/if/for/while/begin/let/struct/module/try/do/quote` closed by an `end`, brackets balanced, strings
+terminated), and that every `ccall` in the shim names a symbol that `include/kdehip.h` declares with the same number
+of arguments."""
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SHIM = os.path.join(ROOT, "kerneldensityestimate.jl_amd", "julia", "KernelDensityEstimateHIP.jl")
+CROSS = os.path.join(ROOT, "oracle", "julia_crosscheck.jl")
+HEADER = os.path.join(ROOT, "include", "kdehip.h")
+
+OPENERS = {"function", "if", "for", "while", "begin", "let", "struct", "module", "try", "do", "quote", "macro"}
+
+
+def strip_code(text):
+    """Julia source with comments removed and string / char literals blanked (docstrings included)."""
+    out, i, n = [], 0, len(text)
+    while i < n:
+        c = text[i]
+        if text.startswith('"""', i):
+            j = text.index('"""', i + 3)
+            out.append('""' + "\n" * text.count("\n", i, j))
+            i = j + 3
+        elif c == '"':
+            j = i + 1
+            while text[j] != '"':
+                if text[j] == "\\":
+                    j += 1
+                assert text[j] != "\n", f"unterminated string near offset {i}"
+                j += 1
+            out.append('""')
+            i = j + 1
+        elif c == "#":
+            j = text.find("\n", i)
+            i = n if j < 0 else j
+        else:
+            out.append(c)
+            i += 1
+    return "".join(out)
+
+
+def check_blocks(path):
+    code = strip_code(open(path).read())
+    depth, stack = 0, []
+    brackets = {"(": ")", "[": "]", "{": "}"}
+    bstack = []
+    for lineno, line in enumerate(code.split("\n"), 1):
+        for tok in re.finditer(r"[A-Za-z_@!][A-Za-z_0-9!]*|[()\[\]{}]", line):
+            t = tok.group(0)
+            if t in brackets:
+                bstack.append((brackets[t], lineno))
+            elif t in brackets.values():
+                assert bstack and bstack[-1][0] == t, f"{path}:{lineno}: unbalanced '{t}'"
+                bstack.pop()
+            elif t in OPENERS and not bstack:  # (a keyword inside brackets is a generator / comprehension `for`, `if`)
+                stack.append((t, lineno))
+            elif t == "end" and not bstack:
+                assert stack, f"{path}:{lineno}: 'end' without an opener"
+                stack.pop()
+    assert not bstack, f"{path}: bracket opened at line {bstack[-1][1]} never closed"
+    assert not stack, f"{path}: '{stack[-1][0]}' at line {stack[-1][1]} never closed"
+    return depth
+
+
+def header_arity():
+    text = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    decls = {}
+    for m in re.finditer(r"\b(kdehip_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+        args = m.group(2).strip()
+        decls[m.group(1)] = 0 if args in ("", "void") else len([a for a in args.split(",")])
+    return decls
+
+
+def test_julia_files_are_block_balanced():
+    check_blocks(SHIM)
+    check_blocks(CROSS)
+
+
+def test_every_ccall_matches_the_header():
+    decls = header_arity()
+    code = strip_code(open(SHIM).read())
+    calls = list(re.finditer(r"ccall\(\(:(kdehip_[a-z0-9_]+),\s*libkdehip\),\s*([A-Za-z0-9_{}]+),\s*\(", code))
+    assert len(calls) >= 8
+    for m in calls:
+        name = m.group(1)
+        assert name in decls, f"{name} is not declared in include/kdehip.h"
+        # the argument-type tuple: from the '(' that ends the match to its closing ')'
+        i, depth = m.end(), 1
+        while depth:
+            depth += {"(": 1, ")": -1}.get(code[i], 0)
+            i += 1
+        types = code[m.end():i - 1].strip()
+        items, d, cur = [], 0, ""
+        for ch in types:
+            if ch in "({":
+                d += 1
+            if ch in ")}":
+                d -= 1
+            if ch == "," and d == 0:
+                items.append(cur)
+                cur = ""
+            else:
+                cur += ch
+        if cur.strip():
+            items.append(cur)
+        assert len(items) == decls[name], f"{name}: ccall passes {len(items)} argument types, header declares {decls[name]}"
