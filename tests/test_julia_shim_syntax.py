@@ -64,14 +64,35 @@ def check_blocks(path):
     return depth
 
 
-def header_arity():
+def header_params():
+    """symbol -> list of C parameter types (normalised: no names, no const, single spaces)"""
     text = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
     text = re.sub(r"//[^\n]*", "", text)
     decls = {}
     for m in re.finditer(r"\b(kdehip_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
         args = m.group(2).strip()
-        decls[m.group(1)] = 0 if args in ("", "void") else len([a for a in args.split(",")])
+        params = []
+        if args not in ("", "void"):
+            for a in args.split(","):
+                a = re.sub(r"\bconst\b", "", a).strip()
+                mm = re.match(r"(.*?)([A-Za-z_][A-Za-z_0-9]*)?$", a)          # drop the parameter name
+                typ = mm.group(1).strip() if mm.group(1).strip() else a
+                params.append(re.sub(r"\s+", " ", typ).replace(" *", "*"))
+        decls[m.group(1)] = params
     return decls
+
+
+def header_arity():
+    return {k: len(v) for k, v in header_params().items()}
+
+
+# what a Julia ccall argument type may be bound to
+JULIA_TO_C = {
+    "Cint": {"int"}, "Int64": {"int64_t"}, "UInt64": {"uint64_t"},
+    "Ptr{Float64}": {"double*"}, "Ptr{Int64}": {"int64_t*"}, "Ptr{Int32}": {"int32_t*"}, "Ref{Int32}": {"int32_t*"},
+    "Ptr{UInt8}": {"uint8_t*"}, "Ptr{CDensity}": {"kdehip_density*"}, "Ref{CDensity}": {"kdehip_density*"},
+    "Cstring": {"char*"}, "Cvoid": {"void"},
+}
 
 
 def test_julia_files_are_block_balanced():
@@ -107,3 +128,7 @@ def test_every_ccall_matches_the_header():
         if cur.strip():
             items.append(cur)
         assert len(items) == decls[name], f"{name}: ccall passes {len(items)} argument types, header declares {decls[name]}"
+        cparams = header_params()[name]
+        for pos, (jt, ct) in enumerate(zip((x.strip() for x in items), cparams)):
+            assert jt in JULIA_TO_C, f"{name}: argument {pos}: unknown Julia type {jt}"
+            assert ct in JULIA_TO_C[jt], f"{name}: argument {pos}: Julia passes {jt}, header declares {ct}"
