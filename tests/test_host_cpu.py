@@ -43,6 +43,25 @@ def test_library_exports_every_declared_symbol():
     assert kdehip.version() == 200
 
 
+def test_ctypes_signatures_match_the_header():
+    """The Python mirror's ctypes prototypes against include/kdehip.h: same arity, integer widths and pointer-ness
+    position by position (a 32-bit integer bound where the header says int64_t is the classic silent FFI fault)."""
+    import ctypes as C
+    from importlib import import_module
+    from tests.test_julia_shim_syntax import header_params
+    sigs = import_module("kdehip._lib").SIGNATURES
+    ints = {"int": C.c_int, "int64_t": C.c_int64, "uint64_t": C.c_uint64, "int32_t": C.c_int32}
+    for name, params in header_params().items():
+        res, args = sigs[name]
+        assert len(args) == len(params), f"{name}: ctypes binds {len(args)} arguments, the header declares {len(params)}"
+        for pos, (a, ct) in enumerate(zip(args, params)):
+            if ct.endswith("*"):
+                is_ptr = a is C.c_void_p or a is C.c_char_p or hasattr(a, "_type_") and hasattr(a, "contents")
+                assert is_ptr, f"{name}: argument {pos} is {ct} in the header but bound as {a}"
+            else:
+                assert ct in ints and a is ints[ct], f"{name}: argument {pos} is {ct} in the header but bound as {a}"
+
+
 def test_product_tree_builder_matches_reference_goldens(golden_dir):
     d = kdehip.kde([0.1, 0.45, 0.55, 3.8], [0.08])
     check_density_against_golden(_Flat(d), parse_mat_print_kde(os.path.join(golden_dir, "test1DResult.txt")), 1e-5)
