@@ -1,5 +1,7 @@
 """Randomised parity sweep: many small random products (dimension, density count, sizes, weights, masks,
 Niter, chain counts around the workgroup/table thresholds) through the HIP path vs the oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -28,7 +30,7 @@ def _random_case(rng):
     return D, M, Ns, Np, Niter, weighted, mask
 
 
-@pytest.mark.parametrize("seed", range(60))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("KDEHIP_FUZZ_N", 60))))  # soak: KDEHIP_FUZZ_N=3000
 def test_random_products_match_oracle(seed):
     rng = np.random.default_rng(1000 + seed)
     D, M, Ns, Np, Niter, weighted, mask = _random_case(rng)
@@ -52,6 +54,33 @@ def test_random_products_match_oracle(seed):
         gp_, gi_, gl_ = plan.sample(Np, Niter=Niter, seed=seed, want_labels=True)
         u, n = kdehip.philox_streams(seed, 0, Np, plan.randu_per_sample(Niter), plan.randn_per_sample())
     op_, oi_, ol_ = oracle.gibbs1(op, Np, Niter, u, n, partialDimMask=mask, want_labels=True)
+    _compare((gp_, gi_), (op_, oi_), tol=1e-11)
+    if Niter > 0:
+        assert np.array_equal(gl_, ol_)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("KDEHIP_FUZZ_N", 40))))
+def test_random_products_every_width_up_to_nine_densities(seed):
+    """the same sweep with 2..9 densities at a random workgroup width (4, 8, 12, 16 chains): products of 5..8 densities
+    take the lean kernel at 8 and 16, the general kernel at 4 and 12; 9 densities always the general kernel"""
+    rng = np.random.default_rng(5000 + seed)
+    D, _, _, Np, Niter, weighted, _ = _random_case(rng)
+    M = int(rng.integers(2, 10))
+    Ns = [int(rng.choice([1, 3, 16, 33, 64, 65, 100, 128, 200, 257, 300, 513])) for _ in range(M)]
+    variant = int(rng.choice([2, 8, 12, 16]))
+    gp, op = [], []
+    for n in Ns:
+        pts = rng.standard_normal((D, n)) * rng.uniform(0.3, 2.0, size=(D, 1)) + rng.uniform(-1, 1, size=(D, 1))
+        ks = rng.uniform(0.15, 0.8, size=D)
+        w = rng.uniform(0.1, 1.0, size=n) if weighted else None
+        a, b = _pair(pts, ks, w)
+        gp.append(a)
+        op.append(b)
+    with kdehip.ProductPlan(gp) as plan:
+        plan.set_variant(variant)
+        gp_, gi_, gl_ = plan.sample(Np, Niter=Niter, seed=seed, want_labels=True)
+        u, n = kdehip.philox_streams(seed, 0, Np, plan.randu_per_sample(Niter), plan.randn_per_sample())
+    op_, oi_, ol_ = oracle.gibbs1(op, Np, Niter, u, n, want_labels=True)
     _compare((gp_, gi_), (op_, oi_), tol=1e-11)
     if Niter > 0:
         assert np.array_equal(gl_, ol_)
