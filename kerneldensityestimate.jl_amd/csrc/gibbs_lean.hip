@@ -1,4 +1,4 @@
-// gibbs_lean.hip -- the multiscale-Gibbs product sampler for products of 2..4 densities with every dimension
+// gibbs_lean.hip -- the multiscale-Gibbs product sampler for products of 2..4 (fp64: 2..8) densities with every dimension
 // active (the common case: BASELINE configs 1, 2, 3 and 5), gfx950 only.
 //
 // Same algorithm, tiles, staging modes, conditional tables and random streams as gibbs_kernel.hip (the kernel
