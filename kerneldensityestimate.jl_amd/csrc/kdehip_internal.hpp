@@ -134,9 +134,12 @@ int pack_levels(int Ndens, const kdehip_density *trees, int ndims, const uint8_t
                 PackedProduct &out);
 // The same in two steps, for callers that own the destination (product.hip packs straight into the pinned upload
 // buffer): geometry, descriptors and frontier ids; then the payload in the layout's precision.
+// kPackChecked decides fast vs generic arithmetic by looking at every node; kPackOptimistic lays out the fast form
+// and leaves the conditions to pack_fill (false = they do not hold: lay out again with kPackGeneric and refill).
+enum PackMode : int { kPackChecked = 0, kPackOptimistic = 1, kPackGeneric = 2 };
 int pack_layout(int Ndens, const kdehip_density *trees, int ndims, const uint8_t *mask, int precision,
-                PackedProduct &out);
-void pack_fill(const PackedProduct &pp, const kdehip_density *trees, void *data, int32_t *perm);
+                PackedProduct &out, PackMode pmode = kPackChecked);
+bool pack_fill(const PackedProduct &pp, const kdehip_density *trees, void *data, int32_t *perm);
 
 // floor(log(maxNp)/log(2) + 1), reference src/MSGibbs01.jl:568
 int nlevels_for(int64_t maxNp);

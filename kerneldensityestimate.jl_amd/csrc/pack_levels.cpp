@@ -26,8 +26,28 @@ int nlevels_for(int64_t maxNp) {
   return static_cast<int>(std::floor(std::log(static_cast<double>(maxNp)) / std::log(2.0) + 1.0));
 }
 
+namespace {
+// The product/rsqrt form multiplies up to D variances c_d in [bw_lo, 2*bw_hi] (bandwidth plus a
+// leave-one-out product variance that is never larger than the largest bandwidth).  It is used
+// only when no partial product can leave the comfortable range of T; otherwise the per-dimension
+// divide+log form (the reference's own arithmetic) runs.
+bool variances_in_range(const double *bw_lo, const double *bw_hi, int D, int precision) {
+  double up = 1.0, dn = 1.0;
+  for (int d = 0; d < D; ++d) {
+    const double hi = 2.0 * bw_hi[d], lo = bw_lo[d];
+    if (hi > 1.0) up *= hi;
+    if (lo < 1.0) dn *= lo;
+  }
+  return (precision == 64) ? (up < 1e120 && dn > 1e-120) : (up < 1e15 && dn > 1e-15);
+}
+}  // namespace
+
+// mode: kPackChecked looks at every node first (finiteness, bandwidth range) and decides between the fast and the
+// generic arithmetic form; kPackOptimistic assumes the fast form and leaves those checks to pack_fill, which reads
+// every value anyway (the checks are random accesses into the tree arrays: as expensive as the fill itself);
+// kPackGeneric is the layout of the generic form without looking.
 int pack_layout(int Ndens, const kdehip_density *trees, int ndims, const uint8_t *mask, int precision,
-                PackedProduct &out) {
+                PackedProduct &out, PackMode pmode) {
   if (Ndens < 1 || !trees) return set_error(KDEHIP_ERR_ARG, "need at least one density");
   if (Ndens > KDEHIP_MAX_DENS)
     return set_error(KDEHIP_ERR_UNSUPPORTED, "more than KDEHIP_MAX_DENS densities in one product");
@@ -76,55 +96,73 @@ int pack_layout(int Ndens, const kdehip_density *trees, int ndims, const uint8_t
     const kdehip_density &t = trees[j];
     const int64_t N = t.npts;
     out.front.reserve(out.front.size() + static_cast<size_t>(N) * (L + 1) / 2 + 64);
+    double lo[KDEHIP_MAX_DIMS], hi[KDEHIP_MAX_DIMS];
+    for (int d = 0; d < KDEHIP_MAX_DIMS; ++d) { lo[d] = INFINITY; hi[d] = 0.0; }
+    bool bad = false;
     for (int l = 0; l <= L; ++l) {
       const size_t idx = static_cast<size_t>(j) * (L + 1) + l;
       const size_t begin = out.front.size();
       out.front_off[idx] = static_cast<int64_t>(begin);
-      if (l == 0) {
-        out.front.push_back(1);  // levelInit!: frontier = {root()}
-      } else {
-        const size_t pb = static_cast<size_t>(out.front_off[idx - 1]), pe = begin;
-        for (size_t z = pb; z < pe; ++z) {
-          const int64_t node = out.front[z];
-          const int64_t a = t.left_child[node - 1], b = t.right_child[node - 1];
-          if (a > 0 && a <= 2 * N) out.front.push_back(static_cast<int32_t>(a));  // validIndex, BallTree01.jl:83
-          if (b > 0 && b <= 2 * N) out.front.push_back(static_cast<int32_t>(b));
-        }
-        const int64_t n = static_cast<int64_t>(out.front.size() - begin);
-        if (n == 0 || n > N) return set_error(KDEHIP_ERR_ARG, "malformed tree: frontier empty or larger than Npts");
-        out.nodes_per_sweep += n;
-      }
-      const double *bw0 = t.bandwidth + (static_cast<int64_t>(out.front[begin]) - 1) * D;
-      bool uni = true;
-      for (size_t z = begin; z < out.front.size(); ++z) {
-        const int64_t node = out.front[z];
+      // every node is looked at ONCE, at the level where it enters the frontier (a leaf re-enters the next frontier
+      // as its own left child: not new): finiteness and the bandwidth range of the arithmetic-form decision
+      auto look = [&](int64_t node) {  // (branch-free: minima / maxima / one sticky flag in locals of the density loop)
         const double *mu = t.means + (node - 1) * D, *v = t.bandwidth + (node - 1) * D;
         for (int d = 0; d < D; ++d) {
           // (means beyond 1e100 would overflow the squared distances of the product/rsqrt forms)
-          if (!(std::fabs(mu[d]) < 1e100 && std::isfinite(v[d]) && v[d] > 0.0)) finite_ok = false;
-          if (v[d] < bw_lo[d]) bw_lo[d] = v[d];
-          if (v[d] > bw_hi[d]) bw_hi[d] = v[d];
-          if (v[d] != bw0[d]) uni = false;
+          bad |= !(std::fabs(mu[d]) < 1e100) | !(v[d] > 0.0) | !(v[d] < INFINITY);
+          lo[d] = v[d] < lo[d] ? v[d] : lo[d];
+          hi[d] = v[d] > hi[d] ? v[d] : hi[d];
         }
         const double w = t.weights[node - 1];
-        if (!(std::isfinite(w) && w >= 0.0)) finite_ok = false;
+        bad |= !(w >= 0.0) | !(w < INFINITY);
+      };
+      if (l == 0) {
+        out.front.push_back(1);  // levelInit!: frontier = {root()}
+        if (pmode == kPackChecked) look(1);
+      } else {
+        const size_t pb = static_cast<size_t>(out.front_off[idx - 1]), pe = begin;
+        out.front.resize(begin + 2 * (pe - pb));  // (at most two children per node; trimmed below)
+        int32_t *dst = out.front.data() + begin;
+        const int32_t *src = out.front.data() + pb;
+        size_t cnt = 0;
+        for (size_t z = 0; z < pe - pb; ++z) {
+          const int64_t node = src[z];
+          const int64_t a = t.left_child[node - 1], b = t.right_child[node - 1];
+          if (a > 0 && a <= 2 * N) {  // validIndex, BallTree01.jl:83
+            dst[cnt++] = static_cast<int32_t>(a);
+            if (a != node && pmode == kPackChecked) look(a);
+          }
+          if (b > 0 && b <= 2 * N) {
+            dst[cnt++] = static_cast<int32_t>(b);
+            if (b != node && pmode == kPackChecked) look(b);
+          }
+        }
+        out.front.resize(begin + cnt);
+        const int64_t n = static_cast<int64_t>(cnt);
+        if (n == 0 || n > N) return set_error(KDEHIP_ERR_ARG, "malformed tree: frontier empty or larger than Npts");
+        out.nodes_per_sweep += n;
+      }
+      // one bandwidth vector shared by the whole frontier?  (stops at the first node that differs: frontiers with
+      // internal nodes are decided after a node or two, only the all-leaf frontiers are scanned in full)
+      const double *bw0 = t.bandwidth + (static_cast<int64_t>(out.front[begin]) - 1) * D;
+      bool uni = true;
+      for (size_t z = begin + 1; z < out.front.size() && uni; ++z) {
+        const double *v = t.bandwidth + (static_cast<int64_t>(out.front[z]) - 1) * D;
+        for (int d = 0; d < D; ++d)
+          if (v[d] != bw0[d]) uni = false;
       }
       level_uniform[idx] = uni ? 1 : 0;
+    }
+    if (bad) finite_ok = false;
+    for (int d = 0; d < D; ++d) {
+      if (lo[d] < bw_lo[d]) bw_lo[d] = lo[d];
+      if (hi[d] > bw_hi[d]) bw_hi[d] = hi[d];
     }
   }
   out.front_off.back() = static_cast<int64_t>(out.front.size());
 
-  // The product/rsqrt form multiplies up to D variances c_d in [bw_lo, 2*bw_hi] (bandwidth plus a
-  // leave-one-out product variance that is never larger than the largest bandwidth).  It is used
-  // only when no partial product can leave the comfortable range of T; otherwise the per-dimension
-  // divide+log form (the reference's own arithmetic) runs.
-  double up = 1.0, dn = 1.0;
-  for (int d = 0; d < D; ++d) {
-    const double hi = 2.0 * bw_hi[d], lo = bw_lo[d];
-    if (hi > 1.0) up *= hi;
-    if (lo < 1.0) dn *= lo;
-  }
-  const bool in_range = (precision == 64) ? (up < 1e120 && dn > 1e-120) : (up < 1e15 && dn > 1e-15);
+  const bool in_range = (pmode == kPackChecked) ? variances_in_range(bw_lo, bw_hi, D, precision) : true;
+  if (pmode == kPackGeneric) finite_ok = false;
   // the fast forms evaluate every dimension: they need every dimension of every density to be informed by
   // some OTHER density too (a one-density "product" or a partialDimMask leaves dimensions inactive: masked fast form)
   out.all_active = true;
@@ -232,9 +270,15 @@ int pack_layout(int Ndens, const kdehip_density *trees, int ndims, const uint8_t
 
 // Writes the payload of a layout: tiles (element type by `precision` of the layout) and permutation rows.
 // Row by row, field by field, 64 contiguous lanes at a time (the sources are gathered through the frontier ids).
+// Returns whether every value met the conditions of the fast arithmetic form (finite means below 1e100, positive
+// finite variances whose products stay in range, finite non-negative weights): what pack_layout's kPackChecked mode
+// establishes beforehand, found here on the values that are being copied anyway.
 template <typename T>
-static void fill_tiles(const PackedProduct &pp, const kdehip_density *trees, T *data, int32_t *perm) {
+static bool fill_tiles(const PackedProduct &pp, const kdehip_density *trees, T *data, int32_t *perm) {
   const int D = pp.D, M = pp.M, L = pp.L;
+  bool bad = false;
+  double lo[KDEHIP_MAX_DIMS], hi[KDEHIP_MAX_DIMS];
+  for (int d = 0; d < KDEHIP_MAX_DIMS; ++d) { lo[d] = INFINITY; hi[d] = 0.0; }
   for (int j = 0; j < M; ++j) {
     const kdehip_density &t = trees[j];
     for (int l = 0; l <= L; ++l) {
@@ -248,6 +292,12 @@ static void fill_tiles(const PackedProduct &pp, const kdehip_density *trees, T *
       T *hdr = data + ds.hdr_off;
       for (int d = 0; d < kTileHeader; ++d)
         hdr[d] = d < D ? static_cast<T>(t.bandwidth[(static_cast<int64_t>(cur[0]) - 1) * D + d]) : T(0);
+      for (int d = 0; d < D; ++d) {  // (the one bandwidth vector of a uniform tile; entry 0's otherwise)
+        const double v = t.bandwidth[(static_cast<int64_t>(cur[0]) - 1) * D + d];
+        bad |= !(v > 0.0) | !(v < INFINITY);
+        lo[d] = v < lo[d] ? v : lo[d];
+        hi[d] = v > hi[d] ? v : hi[d];
+      }
       T *tile = hdr + kTileHeader;
       int32_t *prow = perm + ds.perm_off;
       for (int64_t i = 0; i < B; ++i) {
@@ -260,14 +310,40 @@ static void fill_tiles(const PackedProduct &pp, const kdehip_density *trees, T *
         for (int d = 0; d < D; ++d) {
           T *dst = row + d * 64;
           for (int ln = 0; ln < 64; ++ln) dst[ln] = src[ln] >= 0 ? static_cast<T>(t.means[src[ln] * D + d]) : T(0);
+          // (checked on the 64 contiguous values just written: vectorisable, unlike the gather above)
+          T amax = T(0), nan_acc = T(0);
+          for (int ln = 0; ln < 64; ++ln) {
+            const T a = dst[ln] < T(0) ? -dst[ln] : dst[ln];
+            amax = a > amax ? a : amax;
+            nan_acc += dst[ln] * T(0);  // 0 for a finite value, NaN otherwise
+          }
+          bad |= !(static_cast<double>(amax) < 1e100) | !(nan_acc == T(0));
         }
         if (!uni)
           for (int d = 0; d < D; ++d) {
             T *dst = row + (D + d) * 64;
             for (int ln = 0; ln < 64; ++ln) dst[ln] = src[ln] >= 0 ? static_cast<T>(t.bandwidth[src[ln] * D + d]) : T(1);
+            T l = dst[0], h = dst[0], nan_acc = T(0);  // (padding entries carry variance 1: neutral for the range test)
+            for (int ln = 0; ln < 64; ++ln) {
+              l = dst[ln] < l ? dst[ln] : l;
+              h = dst[ln] > h ? dst[ln] : h;
+              nan_acc += dst[ln] * T(0);
+            }
+            bad |= !(l > T(0)) | !(static_cast<double>(h) < INFINITY) | !(nan_acc == T(0));
+            lo[d] = static_cast<double>(l) < lo[d] ? static_cast<double>(l) : lo[d];
+            hi[d] = static_cast<double>(h) > hi[d] ? static_cast<double>(h) : hi[d];
           }
         T *wdst = row + (F - 1) * 64;
         for (int ln = 0; ln < 64; ++ln) wdst[ln] = src[ln] >= 0 ? static_cast<T>(t.weights[src[ln]]) : T(0);
+        {
+          T wl = wdst[0], wh = wdst[0], nan_acc = T(0);
+          for (int ln = 0; ln < 64; ++ln) {
+            wl = wdst[ln] < wl ? wdst[ln] : wl;
+            wh = wdst[ln] > wh ? wdst[ln] : wh;
+            nan_acc += wdst[ln] * T(0);
+          }
+          bad |= !(wl >= T(0)) | !(static_cast<double>(wh) < INFINITY) | !(nan_acc == T(0));
+        }
         row[F * 64] = T(0);  // the pad element
         int32_t *pdst = prow + i * 64;
         for (int ln = 0; ln < 64; ++ln) pdst[ln] = src[ln] >= 0 ? static_cast<int32_t>(t.permutation[src[ln]]) : 0;
@@ -278,11 +354,13 @@ static void fill_tiles(const PackedProduct &pp, const kdehip_density *trees, T *
       for (int64_t e = end; e < next; ++e) data[e] = T(0);
     }
   }
+  return !bad && variances_in_range(lo, hi, D, pp.precision);
 }
 
-void pack_fill(const PackedProduct &pp, const kdehip_density *trees, void *data, int32_t *perm) {
-  if (pp.precision == 64) fill_tiles<double>(pp, trees, static_cast<double *>(data), perm);
-  else fill_tiles<float>(pp, trees, static_cast<float *>(data), perm);
+bool pack_fill(const PackedProduct &pp, const kdehip_density *trees, void *data, int32_t *perm) {
+  const bool ok = (pp.precision == 64) ? fill_tiles<double>(pp, trees, static_cast<double *>(data), perm)
+                                       : fill_tiles<float>(pp, trees, static_cast<float *>(data), perm);
+  return ok || !pp.fast;  // (a generic-form layout has no conditions to meet)
 }
 
 // Layout + payload in host vectors (fp64 payload whatever the precision of the layout): tests and tools.

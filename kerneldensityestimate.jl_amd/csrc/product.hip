@@ -5,6 +5,9 @@
 
 #include <atomic>
 #include <cstdlib>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -172,44 +175,65 @@ struct PlanImage {
   void *h_blob = nullptr;
   size_t off_lev = 0, off_count = 0, off_tab = 0, off_perm = 0, off_data = 0, off_tables = 0, total = 0;
   int precision = 64;
-  ~PlanImage() { if (h_blob) cached_host_free(h_blob, off_tables); }
+  size_t blob_bytes = 0;
+  ~PlanImage() { if (h_blob) cached_host_free(h_blob, blob_bytes); }
 };
 
 int build_image(PlanImage &im, int Ndens, const kdehip_density *trees, int ndims, const uint8_t *partialDimMask,
                 int precision) {
   if (precision != 64 && precision != 32) return set_error(KDEHIP_ERR_ARG, "precision must be 64 or 32");
-  int rc = pack_layout(Ndens, trees, ndims, partialDimMask, precision, im.host);
-  if (rc != KDEHIP_OK) return rc;
-  im.precision = precision;
-  const size_t nelem = static_cast<size_t>(im.host.data_elems);
-  const size_t esz = (precision == 64) ? sizeof(double) : sizeof(float);
-  const size_t nperm = static_cast<size_t>(im.host.perm_elems);
-  const size_t nlev = im.host.levels.size();
-  const size_t ntab = im.host.tabdesc.size();
-  im.off_lev = 256;                                        // the fallback counter sits in the 8 bytes before it
-  im.off_count = im.off_lev - sizeof(unsigned long long);
-  im.off_tab = align256(im.off_lev + nlev * sizeof(LevelDesc));
-  im.off_perm = align256(im.off_tab + ntab * sizeof(TabDesc));
-  im.off_data = align256(im.off_perm + nperm * sizeof(int32_t));
-  im.off_tables = align256(im.off_data + nelem * esz);
-  im.total = im.off_tables + static_cast<size_t>(im.host.tab_entries) * esz;
-  // (pinned memory needs a HIP runtime with a device: a host without one fails here, loudly, as it must)
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-    return set_error(KDEHIP_ERR_NO_DEVICE, "no HIP device available (libkdehip has no CPU fallback by design)");
-  KDEHIP_CHECK(cached_host_malloc(&im.h_blob, im.off_tables));
-  unsigned char *hb = static_cast<unsigned char *>(im.h_blob);
-  std::memset(hb, 0, im.off_lev);
-  std::memcpy(hb + im.off_lev, im.host.levels.data(), nlev * sizeof(LevelDesc));
-  std::memcpy(hb + im.off_tab, im.host.tabdesc.data(), ntab * sizeof(TabDesc));
-  pack_fill(im.host, trees, hb + im.off_data, reinterpret_cast<int32_t *>(hb + im.off_perm));
+  static const bool timing = std::getenv("KDEHIP_TIMING") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
+  auto us = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); };
+  // First the layout of the fast arithmetic form WITHOUT looking at the node values: whether they allow that form
+  // (finite, variances in range) is established by pack_fill on the values it copies anyway -- looking first costs
+  // as much as the fill (random accesses into the tree arrays).  The rare density set that does not qualify is laid
+  // out again in the generic form and refilled.
+  for (PackMode pmode : {kPackOptimistic, kPackGeneric}) {
+    int rc = pack_layout(Ndens, trees, ndims, partialDimMask, precision, im.host, pmode);
+    if (rc != KDEHIP_OK) return rc;
+    const double us_layout = us();
+    im.precision = precision;
+    const size_t nelem = static_cast<size_t>(im.host.data_elems);
+    const size_t esz = (precision == 64) ? sizeof(double) : sizeof(float);
+    const size_t nperm = static_cast<size_t>(im.host.perm_elems);
+    const size_t nlev = im.host.levels.size();
+    const size_t ntab = im.host.tabdesc.size();
+    im.off_lev = 256;                                        // the fallback counter sits in the 8 bytes before it
+    im.off_count = im.off_lev - sizeof(unsigned long long);
+    im.off_tab = align256(im.off_lev + nlev * sizeof(LevelDesc));
+    im.off_perm = align256(im.off_tab + ntab * sizeof(TabDesc));
+    im.off_data = align256(im.off_perm + nperm * sizeof(int32_t));
+    im.off_tables = align256(im.off_data + nelem * esz);
+    im.total = im.off_tables + static_cast<size_t>(im.host.tab_entries) * esz;
+    // (pinned memory needs a HIP runtime with a device: a host without one fails here, loudly, as it must)
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+      return set_error(KDEHIP_ERR_NO_DEVICE, "no HIP device available (libkdehip has no CPU fallback by design)");
+    KDEHIP_CHECK(cached_host_malloc(&im.h_blob, im.off_tables));
+    im.blob_bytes = im.off_tables;
+    const double us_alloc = us();
+    unsigned char *hb = static_cast<unsigned char *>(im.h_blob);
+    std::memset(hb, 0, im.off_lev);
+    std::memcpy(hb + im.off_lev, im.host.levels.data(), nlev * sizeof(LevelDesc));
+    std::memcpy(hb + im.off_tab, im.host.tabdesc.data(), ntab * sizeof(TabDesc));
+    const bool ok = pack_fill(im.host, trees, hb + im.off_data, reinterpret_cast<int32_t *>(hb + im.off_perm));
+    if (timing)
+      std::fprintf(stderr, "kdehip image%s: layout %.0f us | pinned block %.0f us | tiles filled %.0f us\n",
+                   ok ? "" : " (fast form refused: again in the generic form)", us_layout, us_alloc, us());
+    if (ok) break;
+    cached_host_free(im.h_blob, im.blob_bytes);
+    im.h_blob = nullptr;
+  }
   std::vector<int32_t>().swap(im.host.front);  // (only the descriptors are needed from here on)
   return KDEHIP_OK;
 }
 
 // A plan on `device` from an image: one device allocation, one DMA transfer (hipMalloc / hipFree cost tens of
 // microseconds each and would dominate a one-shot small product; blocks come from the library's cache).
-int instantiate(const PlanImage &im, int device, kdehip_product **out) {
+// wait = false (one-shot calls, whose image outlives the work they enqueue): the upload is left in flight on the
+// null stream; everything the caller enqueues there afterwards is ordered behind it.
+int instantiate(const PlanImage &im, int device, kdehip_product **out, bool wait = true) {
   *out = nullptr;
   kdehip_product *p = new (std::nothrow) kdehip_product();
   if (!p) return set_error(KDEHIP_ERR_ALLOC, "out of host memory");
@@ -224,7 +248,7 @@ int instantiate(const PlanImage &im, int device, kdehip_product **out) {
   hipError_t e = cached_malloc(&p->d_blob, im.total);
   if (e == hipSuccess) p->blob_bytes = im.total;
   if (e == hipSuccess) e = hipMemcpyAsync(p->d_blob, im.h_blob, im.off_tables, hipMemcpyHostToDevice, nullptr);
-  if (e == hipSuccess) e = hipStreamSynchronize(nullptr);  // (the pinned image may be recycled after this call)
+  if (e == hipSuccess && wait) e = hipStreamSynchronize(nullptr);  // (the pinned image may be recycled after this call)
   if (e != hipSuccess) {
     const std::string m = std::string("plan upload: ") + hipGetErrorString(e);
     kdehip_product_destroy(p);
@@ -435,9 +459,24 @@ int one_shot(int Ndens, const kdehip_density *trees, int64_t Np, int Niter, doub
     const int prc = pack_layout(Ndens, trees, ndims, partialDimMask, precision == 32 ? 32 : 64, probe);
     return prc != KDEHIP_OK ? prc : rc;
   }
+  // KDEHIP_TIMING=1: host-side phase times of this call on stderr (scripts/call_breakdown.py)
+  static const bool timing = std::getenv("KDEHIP_TIMING") != nullptr;
+  using clk = std::chrono::steady_clock;
+  const auto t_begin = clk::now();
+  auto us_since = [&](clk::time_point t) { return std::chrono::duration<double, std::micro>(clk::now() - t).count(); };
   PlanImage im;
+  // (declared after the image, before the shards: on an early error return the plans go back to the cache first,
+  // then every device touched is drained, and only then is the pinned image recycled)
+  struct DrainOnExit {
+    std::vector<int> devs;
+    ~DrainOnExit() {
+      DeviceGuard g;
+      for (int d : devs) if (g.enter(d) == KDEHIP_OK) (void)hipStreamSynchronize(nullptr);
+    }
+  } drain;
   rc = build_image(im, Ndens, trees, ndims, partialDimMask, precision);
   if (rc != KDEHIP_OK) return rc;
+  const double us_pack = us_since(t_begin);
   if (Np < 0) return set_error(KDEHIP_ERR_ARG, "Np must be >= 0");
   if (Niter < 0) return set_error(KDEHIP_ERR_ARG, "Niter must be >= 0");
   if (Np > 0 && (!pts || !ind)) return set_error(KDEHIP_ERR_ARG, "null output pointer");
@@ -464,7 +503,8 @@ int one_shot(int Ndens, const kdehip_density *trees, int64_t Np, int Niter, doub
     S.lo = share_begin(Np, g, ngpus);
     S.hi = share_begin(Np, g + 1, ngpus);
     const int64_t n = S.hi - S.lo;
-    rc = instantiate(im, S.device, &S.plan);
+    drain.devs.push_back(S.device);
+    rc = instantiate(im, S.device, &S.plan, /*wait=*/false);  // the upload overlaps the host side of the launches
     if (rc != KDEHIP_OK) return rc;
     rc = guard.enter(S.device);
     if (rc != KDEHIP_OK) return rc;
@@ -494,17 +534,24 @@ int one_shot(int Ndens, const kdehip_density *trees, int64_t Np, int Niter, doub
     KDEHIP_CHECK(cached_host_malloc(&S.h_out, S.span));
     KDEHIP_CHECK(hipMemcpyAsync(S.h_out, w + S.off_p, S.span, hipMemcpyDeviceToHost, nullptr));
   }
+  const double us_enqueue = us_since(t_begin);
+  double us_wait = 0.0;
   for (int g = 0; g < ngpus; ++g) {
     Shard &S = sh[g];
     rc = guard.enter(S.device);
     if (rc != KDEHIP_OK) return rc;
     KDEHIP_CHECK(hipStreamSynchronize(nullptr));
+    if (g == ngpus - 1) us_wait = us_since(t_begin);
     const int64_t n = S.hi - S.lo;
     const unsigned char *h = static_cast<const unsigned char *>(S.h_out);
     std::memcpy(pts + S.lo * D, h, sizeof(double) * D * n);
     std::memcpy(ind + S.lo * M, h + (S.off_i - S.off_p), sizeof(int64_t) * M * n);
     if (trace) std::memcpy(labels + S.lo * M * L, h + (S.off_l - S.off_p), sizeof(int32_t) * M * L * n);
   }
+  drain.devs.clear();  // every device has been waited for
+  if (timing)
+    std::fprintf(stderr, "kdehip one-shot: pack %.0f us | upload + launches enqueued %.0f us | device done %.0f us | results copied %.0f us\n",
+                 us_pack, us_enqueue, us_wait, us_since(t_begin));
   return KDEHIP_OK;
 }
 
