@@ -43,7 +43,8 @@ int chains_per_workgroup(int64_t Np, int variant) {
 #define KDEHIP_DECL(d)                                                                  \
   int launch_gibbs_d##d(int, int, const PlanDev &, const RunArgs &, void *);           \
   int launch_lean_d##d(int, int, const PlanDev &, const RunArgs &, void *);             \
-  int launch_lean_hi_d##d(int, int, const PlanDev &, const RunArgs &, void *);
+  int launch_lean_hi_d##d(int, int, const PlanDev &, const RunArgs &, void *);          \
+  int launch_lean_f32_d##d(int, int, const PlanDev &, const RunArgs &, void *);
 KDEHIP_DECL(1) KDEHIP_DECL(2) KDEHIP_DECL(3) KDEHIP_DECL(4) KDEHIP_DECL(5) KDEHIP_DECL(6) KDEHIP_DECL(7) KDEHIP_DECL(8)
 #undef KDEHIP_DECL
 
@@ -68,15 +69,16 @@ int launch_gibbs(int precision, int mode, const PlanDev &plan, const RunArgs &ar
     if (rc != kLeanNotCovered) return rc;
   } else if (!generic_only) {  // products of 2..4 densities, all dimensions active: the register-resident kernel
     int rc = kLeanNotCovered;
+    const bool f32 = (precision == 32);
     switch (plan.D) {
-      case 1: rc = launch_lean_d1(precision, mode, plan, args, stream); break;
-      case 2: rc = launch_lean_d2(precision, mode, plan, args, stream); break;
-      case 3: rc = launch_lean_d3(precision, mode, plan, args, stream); break;
-      case 4: rc = launch_lean_d4(precision, mode, plan, args, stream); break;
-      case 5: rc = launch_lean_d5(precision, mode, plan, args, stream); break;
-      case 6: rc = launch_lean_d6(precision, mode, plan, args, stream); break;
-      case 7: rc = launch_lean_d7(precision, mode, plan, args, stream); break;
-      case 8: rc = launch_lean_d8(precision, mode, plan, args, stream); break;
+      case 1: rc = f32 ? launch_lean_f32_d1(precision, mode, plan, args, stream) : launch_lean_d1(precision, mode, plan, args, stream); break;
+      case 2: rc = f32 ? launch_lean_f32_d2(precision, mode, plan, args, stream) : launch_lean_d2(precision, mode, plan, args, stream); break;
+      case 3: rc = f32 ? launch_lean_f32_d3(precision, mode, plan, args, stream) : launch_lean_d3(precision, mode, plan, args, stream); break;
+      case 4: rc = f32 ? launch_lean_f32_d4(precision, mode, plan, args, stream) : launch_lean_d4(precision, mode, plan, args, stream); break;
+      case 5: rc = f32 ? launch_lean_f32_d5(precision, mode, plan, args, stream) : launch_lean_d5(precision, mode, plan, args, stream); break;
+      case 6: rc = f32 ? launch_lean_f32_d6(precision, mode, plan, args, stream) : launch_lean_d6(precision, mode, plan, args, stream); break;
+      case 7: rc = f32 ? launch_lean_f32_d7(precision, mode, plan, args, stream) : launch_lean_d7(precision, mode, plan, args, stream); break;
+      case 8: rc = f32 ? launch_lean_f32_d8(precision, mode, plan, args, stream) : launch_lean_d8(precision, mode, plan, args, stream); break;
       default: break;
     }
     if (rc != kLeanNotCovered) return rc;

@@ -29,9 +29,9 @@ __device__ __forceinline__ void static_for(F &&f) {
   }
 }
 
-// Two translation units per dimension count: products of 2..4 densities at every workgroup width and both
-// precisions, and (with -DKDEHIP_LEAN_HI) fp64 products of 5..8 densities at 8 and 16 chains per workgroup (build
-// time: the kernel is instantiated per density count, precision and width).
+// Three translation units per dimension count (build time: the kernel is instantiated per density count, precision
+// and width, and the units compile in parallel): fp64 products of 2..4 densities at every workgroup width, the same
+// in fp32 (-DKDEHIP_LEAN_F32), and fp64 products of 5..8 densities at 8 and 16 chains per workgroup (-DKDEHIP_LEAN_HI).
 #if defined(KDEHIP_LEAN_HI) || (defined(KDEHIP_LEAN_DEV_M) && KDEHIP_LEAN_DEV_M > 4)
 constexpr int kLeanMinDens = 5, kLeanMaxDens = 8;
 #else
@@ -443,8 +443,10 @@ static int launch_lean_m_hi(const PlanDev &plan, const RunArgs &args, hipStream_
   return KDEHIP_OK;
 }
 
-#ifdef KDEHIP_LEAN_HI
+#if defined(KDEHIP_LEAN_HI)
 #define KDEHIP_LEAN_ENTRY launch_lean_hi_d
+#elif defined(KDEHIP_LEAN_F32)
+#define KDEHIP_LEAN_ENTRY launch_lean_f32_d
 #else
 #define KDEHIP_LEAN_ENTRY launch_lean_d
 #endif
@@ -484,11 +486,19 @@ int KDEHIP_CAT(KDEHIP_LEAN_ENTRY, KDEHIP_DIM)(int precision, int mode, const Pla
     case 7: return launch_lean_m_hi<double, D, 7>(plan, args, st);
     default: return launch_lean_m_hi<double, D, 8>(plan, args, st);
   }
-#else
+#elif defined(KDEHIP_LEAN_F32)
+  if (f64) return kLeanNotCovered;
   switch (plan.M) {
-    case 2: return f64 ? launch_lean_m<double, D, 2>(plan, args, st) : launch_lean_m<float, D, 2>(plan, args, st);
-    case 3: return f64 ? launch_lean_m<double, D, 3>(plan, args, st) : launch_lean_m<float, D, 3>(plan, args, st);
-    default: return f64 ? launch_lean_m<double, D, 4>(plan, args, st) : launch_lean_m<float, D, 4>(plan, args, st);
+    case 2: return launch_lean_m<float, D, 2>(plan, args, st);
+    case 3: return launch_lean_m<float, D, 3>(plan, args, st);
+    default: return launch_lean_m<float, D, 4>(plan, args, st);
+  }
+#else
+  if (!f64) return kLeanNotCovered;
+  switch (plan.M) {
+    case 2: return launch_lean_m<double, D, 2>(plan, args, st);
+    case 3: return launch_lean_m<double, D, 3>(plan, args, st);
+    default: return launch_lean_m<double, D, 4>(plan, args, st);
   }
 #endif
 }

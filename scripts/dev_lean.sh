@@ -6,9 +6,15 @@
 #   other instantiations: -DKDEHIP_LEAN_DEV_F32, -DKDEHIP_LEAN_DEV_M=<densities>, -DKDEHIP_LEAN_DEV_W=<chains per workgroup>
 set -e
 TAG=$1; shift
+# which of the regular build's translation units the development object replaces (same entry point name)
+REPL="gibbs_lean_d${DIM:-6}.o"; EXTRA=""
+case " $* " in
+  *KDEHIP_LEAN_DEV_F32*) REPL="gibbs_lean_f32_d${DIM:-6}.o"; EXTRA="-DKDEHIP_LEAN_F32" ;;
+  *KDEHIP_LEAN_DEV_M=[5-8]*) REPL="gibbs_lean_hi_d${DIM:-6}.o"; EXTRA="-DKDEHIP_LEAN_HI" ;;
+esac
 cd "$(dirname "$0")/../kerneldensityestimate.jl_amd/csrc"
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wextra -Wno-unused-parameter --offload-arch=gfx950 \
-  -munsafe-fp-atomics -mllvm -disable-vector-combine -DKDEHIP_DIM=${DIM:-6} -DKDEHIP_LEAN_DEV "$@" -c gibbs_lean.hip -o build/dev_lean_$TAG.o
-OBJS=$(ls build/*.o | grep -v "gibbs_lean_d${DIM:-6}.o" | grep -v "dev_lean_")
+  -munsafe-fp-atomics -mllvm -disable-vector-combine -DKDEHIP_DIM=${DIM:-6} -DKDEHIP_LEAN_DEV $EXTRA "$@" -c gibbs_lean.hip -o build/dev_lean_$TAG.o
+OBJS=$(ls build/*.o | grep -v "/$REPL" | grep -v "dev_lean_")
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../libkdehip_$TAG.so $OBJS build/dev_lean_$TAG.o
 ls -la ../libkdehip_$TAG.so
