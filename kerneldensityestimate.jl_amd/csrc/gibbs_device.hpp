@@ -663,6 +663,76 @@ __device__ __forceinline__ int select_or_raise(T S, P rows, const DS &ds, int la
   }
 }
 
+// ---- chunked tiles (rows streamed through LDS, the second pass reads global memory) ------------------------------
+// The first pass notes the lane's running sum at segment boundaries (a segment = a whole number of chunks, at most 64
+// rows): the second pass then finds the winning lane's segment from those few numbers and evaluates only its <= 64
+// entries -- ONE round of global-memory loads instead of the two or three of the general narrowing (which costs a
+// quarter of config 5's kernel time: every round is a dependent L2 round trip per step).
+constexpr int kMaxSeg = 8;
+template <typename T>
+struct SegSums {
+  T v[kMaxSeg];   // v[k] = the lane's sum over rows [0, (k+1) * seg_rows)
+  int k = 0;
+  __device__ __forceinline__ void note(T S) {  // (k is wave-uniform; compile-time indices keep v in registers)
+#pragma unroll
+    for (int q = 0; q < kMaxSeg; ++q) v[q] = (q == k) ? S : v[q];
+    ++k;
+  }
+};
+// rows per segment / whether the segment form applies to a tile of B rows in chunks of rc rows
+__device__ __forceinline__ int seg_chunks(int rc) { return rc >= 64 ? 1 : 64 / rc; }
+__device__ __forceinline__ bool seg_applies(int B, int rc) {
+  const int sr = seg_chunks(rc) * rc;
+  return rc <= 64 && (B + sr - 1) / sr <= kMaxSeg;
+}
+
+template <typename T, typename P, typename Eval, typename DS>
+__device__ __forceinline__ int select_or_raise_seg(T S, const SegSums<T> &seg, int seg_rows, P rows, const DS &ds,
+                                                   int lane, const Eval &ev, double u, const void *fb
+#ifdef KDEHIP_STAMPS
+                                                   , unsigned long long *stamp_acc, bool stamp_on
+#endif
+) {
+  const int n = ds.n, B = ds.B;
+  const int RS = ds.F * 64 + 1;
+  const T incl = wave_inclusive_scan(S);
+  const T total = lane_read(incl, 63);
+  // underflow (uniform fallback, fp32 raised repeats): the general path
+  if (!(total >= Num<T>::tiny_total())) return select_or_raise<T, P>(S, rows, ds, lane, ev, u, fb KSTAMP_ARGS);
+  const T target = static_cast<T>(u) * total;
+  const unsigned long long hit = __ballot(target <= incl);
+  const int last_lane = ds.last_lane;
+  int lstar = hit ? (__ffsll(hit) - 1) : last_lane;
+  if (lstar > last_lane) lstar = last_lane;
+  const T base = lane_read(incl - S, lstar);  // exclusive prefix of the winning lane's block
+  int lenl = n - lstar * B;                   // entries of that block
+  if (lenl > B) lenl = B;
+  const int nseg = (B + seg_rows - 1) / seg_rows;
+  int sidx = nseg - 1;
+  T before = T(0), run = T(0);
+  bool found = false;
+#pragma unroll
+  for (int k = 0; k < kMaxSeg - 1; ++k) {
+    if (k < nseg - 1) {  // wave-uniform
+      const T pk = lane_read(seg.v[k], lstar);
+      if (!found && target <= base + pk) { found = true; sidx = k; before = run; }
+      run = pk;
+    }
+  }
+  if (!found) before = run;
+  int r0 = sidx * seg_rows;
+  if (r0 >= lenl) return (lenl - 1) * 64 + lstar;  // (rounding pushed the target beyond the block's last entry)
+  int len = lenl - r0;
+  if (len > seg_rows) len = seg_rows;
+  P col = rows + lstar;
+  T p2 = T(0);
+  if (lane < len) p2 = ev(col + (r0 + lane) * RS);
+  const T inc3 = wave_inclusive_scan(p2);
+  const unsigned long long h3 = __ballot((target <= (base + before) + inc3) && (lane < len));
+  const int istar = h3 ? (__ffsll(h3) - 1) : (len - 1);
+  return (r0 + istar) * 64 + lstar;
+}
+
 template <typename T, typename P, bool PREFETCH, bool kKeptRows, typename Eval, typename DS>
 __device__ __forceinline__ int draw_label(P rows, const DS &ds, int lane, const Eval &ev, double u,
                                           const void *fb

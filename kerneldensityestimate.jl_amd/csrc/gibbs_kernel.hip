@@ -230,6 +230,10 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan,
     const int pos = draw(ds, hdr, mean, cov, [&](const auto &ev) {
       const int RS = ds.F * 64 + 1, rc = chunk_rows(ds);
       T S = T(0);
+      SegSums<T> seg;
+      const int cps = seg_chunks(rc);
+      const bool use_seg = seg_applies(ds.B, rc);
+      int cin = 0;
       for (int r0 = 0; r0 < ds.B; r0 += rc, ++gchunk) {
         __syncthreads();  // this chunk has landed for every wavefront; the other half is free again
         if (r0 + rc < ds.B) stage_chunk(ds, r0 + rc, (gchunk + 1) & 1);
@@ -237,8 +241,11 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan,
         const int nrows = (ds.B - r0 < rc) ? (ds.B - r0) : rc;
         S += lane_sum_rows<T, LdsPtr<T>, std::decay_t<decltype(ev)>, kPrefetchRows>(
             (LdsPtr<T>)(pool + (gchunk & 1) * (kLdsPoolBytes / 2)), nrows, RS, lane, ev);
+        if (use_seg && ++cin == cps) { seg.note(S); cin = 0; }  // the lane's running sum at a segment boundary
       }
       // (a raised repeat of the evaluation reads the tile from global memory: no staging, no barriers)
+      if (use_seg)
+        return select_or_raise_seg<T, const T *>(S, seg, cps * rc, hdr + kTileHeader, ds, lane, ev, u, plan.levels KSTAMP_ARGS);
       return select_or_raise<T, const T *>(S, hdr + kTileHeader, ds, lane, ev, u, plan.levels KSTAMP_ARGS);
     });
     wave_sync();
