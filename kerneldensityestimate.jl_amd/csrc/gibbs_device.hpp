@@ -511,6 +511,9 @@ __device__ __forceinline__ int select_from_scan(T incl, T S, P rows, const DS &d
   KSTAMP(tp2);
   KSTAMP_ADD(3, tp1, tp2);
   if (B == 1) return lstar;
+#ifdef KDEHIP_X_NOPASS2  // timing ablation only (wrong labels): what the second pass costs
+  return lstar;
+#endif
 
   // pass 2: narrow inside the winning lane's block until a single node is left
   T base = lane_read(incl - S, lstar);  // exclusive prefix of the block
