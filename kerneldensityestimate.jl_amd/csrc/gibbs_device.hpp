@@ -674,7 +674,7 @@ __device__ __forceinline__ int select_or_raise(T S, P rows, const DS &ds, int la
 constexpr int kMaxSeg = 8;
 template <typename T>
 struct SegSums {
-  T v[kMaxSeg];   // v[k] = the lane's sum over rows [0, (k+1) * seg_rows)
+  T v[kMaxSeg] = {};  // v[k] = the lane's sum over rows [0, (k+1) * seg_rows)
   int k = 0;
   __device__ __forceinline__ void note(T S) {  // (k is wave-uniform; compile-time indices keep v in registers)
 #pragma unroll
