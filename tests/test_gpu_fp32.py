@@ -65,6 +65,24 @@ def test_headline_shape_fp32_gates():
     assert (ia != ib).mean() < 0.05
 
 
+@pytest.mark.parametrize("width", [0, 8, 16])
+def test_fp32_products_of_more_than_four_densities(width):
+    """fp32 with 5..8 densities has no lean instantiation (build time): the general kernel runs it at every width --
+    same gates against the fp64 run (which takes the lean kernel at 8 and 16 chains per workgroup)."""
+    import bench
+    rng = np.random.default_rng(17)
+    D, M, N, Nout, Niter = 3, 6, 400, 1024, 4
+    pts, bws = bench.synth_inputs(kdehip, D, M, N, 7)
+    trees = [kdehip.kde(p, b) for p, b in zip(pts, bws)]
+    with kdehip.ProductPlan(trees, precision=32) as p32, kdehip.ProductPlan(trees, precision=64) as p64:
+        p32.set_variant(width)
+        p64.set_variant(width)
+        b, ib = p32.sample(Nout, Niter=Niter, seed=11)
+        a, ia = p64.sample(Nout, Niter=Niter, seed=11)
+    _gates(a, b, Nout)
+    assert (ia != ib).mean() < 0.05
+
+
 def _two_clusters(sep, seed=5):
     rng = np.random.default_rng(seed)
     pa = rng.standard_normal((2, 200)) * 0.05
