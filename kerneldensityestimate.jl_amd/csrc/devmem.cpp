@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstddef>
+#include <cstdlib>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -79,8 +80,15 @@ int DeviceGuard::enter(int device) {
   return KDEHIP_OK;
 }
 
+// KDEHIP_NO_CACHE=1 (diagnostics): every block straight from / back to the driver
+static bool no_cache() {
+  static const bool on = [] { const char *e = std::getenv("KDEHIP_NO_CACHE"); return e && e[0] == '1'; }();
+  return on;
+}
+
 hipError_t cached_malloc(void **out, size_t bytes) {
   *out = nullptr;
+  if (no_cache()) return hipMalloc(out, bytes ? bytes : 1);
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
@@ -92,6 +100,7 @@ hipError_t cached_malloc(void **out, size_t bytes) {
 
 void cached_free(void *p, size_t bytes) {
   if (!p) return;
+  if (no_cache()) { (void)hipFree(p); return; }
   int dev = 0;
   const int cls = size_class(bytes);
   if (hipGetDevice(&dev) == hipSuccess && cls < kClasses && dev >= 0 && dev < kMaxDevices && give(g_dev[dev], cls, p))

@@ -803,6 +803,18 @@ struct TabTable {
 
 using LdsVoidPtr = __attribute__((address_space(3))) void *;
 
+// The workgroup barrier of the staging protocols.  Direct-to-LDS copies are ordered for ANOTHER wavefront's ds_read
+// only by the ISSUING wavefront's vmcnt wait followed by a barrier that the reader passes (MI355X_MICROARCH.md,
+// co-residence item 7; cdna_hip_programming.md "read a staged buffer one phase after the wait that retires it").
+// __syncthreads() alone does not give that: for the MUBUF `buffer_load ... lds` form the compiler's fence emitted
+// `s_waitcnt lgkmcnt(0)` only at the loop-carried barriers of the streamed and chunked levels, so a copy that took
+// longer than the evaluation of the previous tile or chunk (freshly uploaded plans: cold TLB / HBM) was read before it
+// had landed -- one wrong workgroup in a few thousand one-shot calls (found by scripts/soak_multi.py).
+__device__ __forceinline__ void staging_barrier() {
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wavefront's own copies have landed
+  __syncthreads();
+}
+
 // Cooperative, asynchronous copy of one tile image (bytes is a multiple of 1 KiB) into the pool: every
 // wavefront issues direct-to-LDS loads for its share of 1-KiB pieces (16 bytes per lane).
 // The MUBUF form (buffer_load_dwordx4 ... lds) is used rather than global_load_lds: the compiler counts the

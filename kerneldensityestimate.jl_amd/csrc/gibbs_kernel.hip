@@ -235,7 +235,7 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan,
       const bool use_seg = seg_applies(ds.B, rc);
       int cin = 0;
       for (int r0 = 0; r0 < ds.B; r0 += rc, ++gchunk) {
-        __syncthreads();  // this chunk has landed for every wavefront; the other half is free again
+        staging_barrier();  // this chunk has landed for every wavefront; the other half is free again
         if (r0 + rc < ds.B) stage_chunk(ds, r0 + rc, (gchunk + 1) & 1);
         else if (has_next) stage_chunk(dn, 0, (gchunk + 1) & 1);
         const int nrows = (ds.B - r0 < rc) ? (ds.B - r0) : rc;
@@ -370,19 +370,19 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan,
     const int mode = vlev == 1 ? int(kStageGlobal) : levels[l].stage_mode;
 
     if (mode == kStageResident) {
-      __syncthreads();  // every wavefront is done reading the previous level's images
+      staging_barrier();  // every wavefront is done reading the previous level's images
       for (int j = 0; j < M; ++j) {
         const LevelDesc ds = levels[j * (L + 1) + l];
         stage_tile<WAVES>(reinterpret_cast<const unsigned char *>(data + ds.hdr_off), pool + ds.lds_off,
                    ds.stage_bytes, wave, lane);
       }
-      __syncthreads();  // (waits for this wavefront's copies, then for everyone's)
+      staging_barrier();  // (waits for this wavefront's copies, then for everyone's)
     } else if (mode == kStageStream) {
-      __syncthreads();
+      staging_barrier();
       const LevelDesc ds0 = levels[l];
       stage_tile<WAVES>(reinterpret_cast<const unsigned char *>(data + ds0.hdr_off), pool, ds0.stage_bytes, wave, lane);
     } else if (mode == kStageChunked) {
-      __syncthreads();
+      staging_barrier();
       stage_chunk(levels[l], 0, gchunk & 1);
     }
 
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan,
           // tile t has been copied by all wavefronts once everyone passes this barrier; buffer
           // (t+1)&1 was last read in step t-1, which everyone has left -> start the next copy
           KSTAMP(tb0);
-          __syncthreads();
+          staging_barrier();
           KSTAMP(tb1);
           KSTAMP_ADD(6, tb0, tb1);
           if (t + 1 < nsteps)

@@ -257,19 +257,19 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan, Ru
     const int npass = tabulated ? 1 : a.Niter + 1;  // tabulated levels: only the sampleIndices! pass runs here
 
     if (mode == kStageResident) {
-      __syncthreads();  // every wavefront is done reading the previous level's images
+      staging_barrier();  // every wavefront is done reading the previous level's images
       static_for<M>([&](auto jc) {
         const LeanTile<D> &ds = dsc[decltype(jc)::value];
         stage_tile<WAVES>(reinterpret_cast<const unsigned char *>(data + ds.hdr_off()), pool + ds.lds_off, ds.stage_bytes, wave, lane);
       });
-      __syncthreads();
+      staging_barrier();
       for (int p = 0; p < npass; ++p)
         static_for<M>([&](auto jc) {
           const LeanTile<D> &ds = dsc[decltype(jc)::value];
           step(jc, ds, (LdsPtr<T>)(pool + ds.lds_off), p == 0, x);
         });
     } else if (mode == kStageStream) {
-      __syncthreads();
+      staging_barrier();
       stage_tile<WAVES>(reinterpret_cast<const unsigned char *>(data + dsc[0].hdr_off()), pool, dsc[0].stage_bytes, wave, lane);
       int t = 0;
       const int nsteps = npass * M;
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan, Ru
           const double u = next_uniform();
           // tile t has been copied by all wavefronts once everyone passes this barrier; buffer (t+1)&1 was last
           // read in step t-1, which everyone has left -> start the next copy
-          __syncthreads();
+          staging_barrier();
           if (t + 1 < nsteps)
             stage_tile<WAVES>(reinterpret_cast<const unsigned char *>(data + dsc[jn].hdr_off()),
                               pool + ((t + 1) & 1) * (kLdsPoolBytes / 2), dsc[jn].stage_bytes, wave, lane);
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan, Ru
       // tiles larger than half the pool: pass 1 streams the rows through the two pool halves (one barrier per
       // chunk, the copy of chunk g+1 overlaps the evaluation of chunk g); the second pass and the new kernel are
       // read from global memory
-      __syncthreads();
+      staging_barrier();
       stage_chunk(dsc[0], 0, gchunk & 1);
       int t = 0;
       const int nsteps = npass * M;
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan, Ru
             const bool use_seg = seg_applies(ds.B, rc);
             int cin = 0;
             for (int r0 = 0; r0 < ds.B; r0 += rc, ++gchunk) {
-              __syncthreads();  // this chunk has landed for every wavefront; the other half is free again
+              staging_barrier();  // this chunk has landed for every wavefront; the other half is free again
               if (r0 + rc < ds.B) stage_chunk(ds, r0 + rc, (gchunk + 1) & 1);
               else if (t + 1 < nsteps) stage_chunk(dsc[jn], 0, (gchunk + 1) & 1);
               const int nrows = (ds.B - r0 < rc) ? (ds.B - r0) : rc;
