@@ -47,5 +47,21 @@ for c in range(cases):
             print(f"MISMATCH case {c}: D={D} M={M} Ns={Ns} Np={Np} Niter={Niter} fp{prec} ngpus={g}: philox diffs {dp} "
                   f"streams diffs {ds} chains {where[:10]} | repeat: ref==ref2 {eq(ref, ref2)} got==got2 {eq(got, got2)} "
                   f"ref2==got2 {eq(ref2, got2)} | streams: ref==ref2 {eq(ref_s, refs2)} got==got2 {eq(got_s, gots2)} ref2==got2 {eq(refs2, gots2)}")
+    # resident plans on several (aliased) devices: after the peer-write all-gather every device holds the whole result
+    if c % 4 == 0 and Np > 0:
+        import torch
+        dev = torch.device("cuda", 0)
+        for g in (2, 5):
+            with kdehip.MultiProductPlan(trees, precision=prec, ngpus=g) as mp:
+                P = [torch.zeros(D * Np, dtype=torch.float64, device=dev) for _ in range(mp.ngpus)]
+                I = [torch.zeros(M * Np, dtype=torch.int64, device=dev) for _ in range(mp.ngpus)]
+                mp.sample_philox_device(Np, Niter, c, 0, True, P, I)
+                torch.cuda.synchronize()
+                for k in range(mp.ngpus):
+                    gp = P[k].cpu().numpy().reshape(Np, D).T
+                    gi = I[k].cpu().numpy().reshape(Np, M).T
+                    if not (np.array_equal(gp, ref[0]) and np.array_equal(gi, ref[1])):
+                        bad += 1
+                        print(f"MISMATCH (resident multi) case {c}: D={D} M={M} Ns={Ns} Np={Np} Niter={Niter} fp{prec} ngpus={g} copy {k}")
 print(f"{cases} cases x 3 device counts x 2 random sources: {bad} mismatches, {time.time()-t0:.0f} s")
 sys.exit(1 if bad else 0)
