@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Thread-safety soak: several host threads call the blocking entry points concurrently on one device (one-shot
+products with device Philox and with caller streams, resident-plan samples, evaluation, LOOCV bandwidth); every result
+must equal the single-threaded one.   python scripts/soak_threads.py [threads] [calls per thread]"""
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import kdehip  # noqa: E402
+from oracle import oracle  # noqa: E402
+
+nthreads = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+ncalls = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+rng = np.random.default_rng(5)
+jobs = []
+for c in range(24):   # a pool of prepared problems with their single-threaded answers
+    D = int(rng.integers(1, 7))
+    M = int(rng.integers(2, 6))
+    Ns = [int(rng.choice([20, 300, 1000, 2500])) for _ in range(M)]
+    Np, Niter = int(rng.choice([7, 64, 500])), int(rng.integers(0, 3))
+    trees = [kdehip.kde(rng.standard_normal((D, n)), rng.uniform(0.1, 0.6, size=D)) for n in Ns]
+    K, R, nU, nN = oracle.rng_sizes(M, D, Np, Niter, Ns)
+    randU, randN = rng.random(nU), rng.standard_normal(nN)
+    pos = rng.standard_normal((D, 300))
+    x = rng.standard_normal((D, 400))
+    jobs.append(dict(trees=trees, Np=Np, Niter=Niter, randU=randU, randN=randN, pos=pos, x=x, seed=c,
+                     a=kdehip.prodAppxMSGibbsS(None, trees, None, None, Niter=Niter, Np=Np, seed=c),
+                     b=kdehip.prodAppxMSGibbsS(None, trees, None, None, Niter=Niter, Np=Np, randU=randU, randN=randN),
+                     e=trees[0](pos), bw=kdehip.auto_bandwidth(x)))
+
+
+def worker(t):
+    r = np.random.default_rng(1000 + t)
+    bad = 0
+    for _ in range(ncalls):
+        j = jobs[int(r.integers(0, len(jobs)))]
+        kind = int(r.integers(0, 4))
+        if kind == 0:
+            got = kdehip.prodAppxMSGibbsS(None, j["trees"], None, None, Niter=j["Niter"], Np=j["Np"], seed=j["seed"])
+            ok = np.array_equal(got[0], j["a"][0]) and np.array_equal(got[1], j["a"][1])
+        elif kind == 1:
+            got = kdehip.prodAppxMSGibbsS(None, j["trees"], None, None, Niter=j["Niter"], Np=j["Np"], randU=j["randU"], randN=j["randN"])
+            ok = np.array_equal(got[0], j["b"][0]) and np.array_equal(got[1], j["b"][1])
+        elif kind == 2:
+            ok = np.array_equal(j["trees"][0](j["pos"]), j["e"])
+        else:
+            ok = np.array_equal(kdehip.auto_bandwidth(j["x"]), j["bw"])
+        bad += not ok
+    return bad
+
+
+t0 = time.time()
+with ThreadPoolExecutor(max_workers=nthreads) as ex:
+    bad = sum(ex.map(worker, range(nthreads)))
+print(f"{nthreads} threads x {ncalls} calls: {bad} wrong results, {time.time()-t0:.0f} s")
+sys.exit(1 if bad else 0)
