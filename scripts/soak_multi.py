@@ -2,7 +2,8 @@
 """Soak of the multi-device entry points on ONE GPU (KDEHIP_ALIAS_DEVICES=1: logical devices wrap around the visible
 ones): random products through kdehip_prod_philox / kdehip_gibbs1_multi with 2..8 logical devices must reproduce the
 one-device result bit for bit (contiguous chain ranges, global Philox index), in both precisions.
-    python scripts/soak_multi.py [cases]"""
+    python scripts/soak_multi.py [cases] [--resident]
+--resident also drives resident multi-device plans (kdehip_product_multi_*; needs torch for the device arrays)."""
 import os
 import sys
 import time
@@ -14,7 +15,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import kdehip  # noqa: E402
 from oracle import oracle  # noqa: E402
 
-cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+import faulthandler  # noqa: E402
+
+resident = "--resident" in sys.argv
+argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+cases = int(argv[0]) if argv else 100
+faulthandler.dump_traceback_later(int(os.environ.get("KDEHIP_SOAK_WATCHDOG", "240")), exit=True)  # a hang names its call
 rng = np.random.default_rng(31337)
 t0 = time.time()
 bad = 0
@@ -29,6 +35,7 @@ for c in range(cases):
     ref = kdehip.prodAppxMSGibbsS(None, trees, None, None, Niter=Niter, Np=Np, seed=c, precision=prec)
     K, R, nU, nN = oracle.rng_sizes(M, D, Np, Niter, Ns)
     randU, randN = rng.random(nU), rng.standard_normal(nN)
+    last = f"case {c}: D={D} M={M} Ns={Ns} Np={Np} Niter={Niter} fp{prec}"
     ref_s = kdehip.prodAppxMSGibbsS(None, trees, None, None, Niter=Niter, Np=Np, randU=randU, randN=randN)
     for g in (2, 3, 8):
         got = kdehip.prodAppxMSGibbsS(None, trees, None, None, Niter=Niter, Np=Np, seed=c, precision=prec, ngpus=g)
@@ -48,7 +55,7 @@ for c in range(cases):
                   f"streams diffs {ds} chains {where[:10]} | repeat: ref==ref2 {eq(ref, ref2)} got==got2 {eq(got, got2)} "
                   f"ref2==got2 {eq(ref2, got2)} | streams: ref==ref2 {eq(ref_s, refs2)} got==got2 {eq(got_s, gots2)} ref2==got2 {eq(refs2, gots2)}")
     # resident plans on several (aliased) devices: after the peer-write all-gather every device holds the whole result
-    if c % 4 == 0 and Np > 0:
+    if resident and c % 4 == 0 and Np > 0:
         import torch
         dev = torch.device("cuda", 0)
         for g in (2, 5):
