@@ -99,7 +99,13 @@ def main():
     ap.add_argument("--nout", type=int, default=0, help="override chains per GPU (experiments; 0 = the config's)")
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: the configuration's TOTAL chain count split over the ranks")
+    ap.add_argument("--inproc-gpus", type=int, default=0,
+                    help="ONE process driving G GPUs through the C ABI's multi-device plans (kdehip_product_multi_*: the route a "
+                         "Julia host takes; all-gather fused into the kernel epilogue as peer stores) instead of one process "
+                         "per GPU + RCCL.  With KDEHIP_ALIAS_DEVICES=1 the G logical devices wrap around the visible ones.")
     args = ap.parse_args()
+    if args.inproc_gpus > 0:
+        return inproc_multi(args)
 
     import torch
     import torch.distributed as dist
@@ -270,6 +276,60 @@ def main():
         os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
         os.dup2(2, 1)
+
+
+def inproc_multi(args):
+    """bench.py --inproc-gpus G: the multi-device route behind the C ABI, one process.  Same step as the default mode
+    (every device draws its share of the chains, afterwards EVERY device holds the complete [pGM | indices]), but the
+    gather is the kernel epilogue's peer stores over xGMI instead of an RCCL all-gather, and there is one host thread."""
+    import torch
+    import kdehip
+
+    G = args.inproc_gpus
+    D, M, N, Nout, Niter, prec, cid = CONFIGS[args.config]
+    if args.nout > 0:
+        Nout = args.nout
+    Np_total = (TOTAL_NOUT[args.config] if args.nout <= 0 else args.nout) if args.strong else Nout * G
+    alias = os.environ.get("KDEHIP_ALIAS_DEVICES") == "1"
+    nvis = torch.cuda.device_count()
+    if not alias and nvis < G:
+        raise SystemExit(f"--inproc-gpus {G} but {nvis} visible device(s) (KDEHIP_ALIAS_DEVICES=1 wraps logical devices around them)")
+    pts_all, bw_all = synth_inputs(kdehip, D, M, N, cid)
+    trees = [kdehip.kde(p, b) for p, b in zip(pts_all, bw_all)]
+    mp = kdehip.MultiProductPlan(trees, precision=prec, first_device=0, ngpus=G)
+    devs = [torch.device("cuda", g % nvis) for g in range(G)]
+    Ps = [torch.zeros(D * Np_total, dtype=torch.float64, device=d) for d in devs]
+    Is = [torch.zeros(M * Np_total, dtype=torch.int64, device=d) for d in devs]
+    sts = [torch.cuda.Stream(device=d) for d in devs]
+    handles = [s.cuda_stream for s in sts]
+    seed = 20260101
+
+    def sync_all():
+        for s in sts:
+            s.synchronize()
+    for i in range(args.warmup):
+        mp.sample_philox_device(Np_total, Niter, seed, i * Np_total, True, Ps, Is, handles)
+    sync_all()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        mp.sample_philox_device(Np_total, Niter, seed, (args.warmup + i) * Np_total, True, Ps, Is, handles)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    # every device must hold the same complete result
+    ref_p, ref_i = Ps[0].cpu(), Is[0].cpu()
+    same = all(torch.equal(ref_p, P.cpu()) and torch.equal(ref_i, I.cpu()) for P, I in zip(Ps[1:], Is[1:]))
+    out = {
+        "metric": "gibbs_product_samples_per_sec", "value": Np_total * args.steps / elapsed, "unit": "samples/s",
+        "n_gpus": G, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
+        "dtype": "f64" if prec == 64 else "f32", "data": "synthetic",
+        "config": {"workload": f"{args.config}: {D}-D, {M} densities x {N} pts, Nout={Np_total} total over {G} device(s), Niter={Niter}, fp{prec}",
+                   "parallelism": f"ONE process, {G} device(s) through kdehip_product_multi_*; all-gather = kernel-epilogue peer stores",
+                   "aliased_devices": alias, "copy_engine_transfers_per_device_per_product": mp.transfers_per_product},
+        "all_devices_hold_the_same_result": bool(same),
+    }
+    mp.close()
+    print(json.dumps(out), flush=True)
 
 
 def call_inclusive(kdehip, trees, plan, D, M, Nout, Niter, seed, prec):

@@ -156,17 +156,27 @@ int kdehip_product_sample_philox_host(kdehip_product *plan, int64_t Np, int Nite
 int64_t kdehip_product_fallback_count(kdehip_product *plan);
 /* Scheduling knob for experiments/benchmarks; results never depend on it.  0 = library default,
  * 1 = read every tile from global memory (no LDS staging), 4 = no conditional tables,
- * 2 / 8 / 12 / 16 = 4 / 8 / 12 / 16 chains per workgroup (default: chosen from the number of chains). */
+ * 2 / 8 / 12 / 16 = 4 / 8 / 12 / 16 chains per workgroup, one wavefront per chain; 52 / 54 = workgroups of 16
+ * wavefronts as 8 chains x 2 / 4 chains x 4 wavefronts (a TEAM of wavefronts shares the rows of a chain's deep
+ * levels; fp64 products of 2..8 densities).  Default: chosen from the number of chains and the depth of the trees. */
 int kdehip_product_set_variant(kdehip_product *plan, int variant);
+/* Diagnostic: the launch geometry a run of Np chains of this plan gets under its current variant -- wavefronts per
+ * workgroup and wavefronts per chain (1 = no team). */
+int kdehip_product_launch_geometry(const kdehip_product *plan, int64_t Np, int32_t *waves_per_workgroup,
+                                   int32_t *waves_per_chain);
 
 /* ---- (2b) resident plans on several GPUs of one node (one process) --------------------------------
  * One plan per device (the packed densities are replicated), chains in contiguous ranges, Philox counters keyed by
  * the GLOBAL sample index (results identical for every number of devices), and ONE all-gather of [pGM | indices]
- * at the end, done with peer writes over xGMI: after the call's work has run, EVERY device holds the complete
- * d_points[g] (double[ndims*Np]) and d_indices[g] (int64[Ndens*Np]); these are device pointers on device
- * first_device+g, streams[g] (hipStream_t, or streams == NULL for the null streams) is where device g's work is
- * enqueued.  The call only enqueues; each stream waits for the slices of all other devices before later work on
- * it runs. */
+ * fused into the sampling kernel: its epilogue stores every final point and label straight into the arrays of ALL
+ * devices (peer-mapped pointers, the stores travel over xGMI; no copy engine, no extra launch).  After the call's
+ * work has run, EVERY device holds the complete d_points[g] (double[ndims*Np]) and d_indices[g] (int64[Ndens*Np]);
+ * these are device pointers on device first_device+g, streams[g] (hipStream_t, or streams == NULL for the null
+ * streams) is where device g's work is enqueued.  The call only enqueues.  Ordering, both ways: device g's kernel
+ * starts only after the work already queued on EVERY streams[h] is over (it overwrites their arrays: consumers of
+ * the previous product on those streams are safe), and each stream continues only once the slices of all other
+ * devices have arrived.  Topologies without peer access fall back to hipMemcpyPeerAsync, one copy per array and
+ * destination (kdehip_product_multi_transfers_per_product tells: 0 = fused). */
 typedef struct kdehip_product_multi kdehip_product_multi;
 int kdehip_product_multi_create(kdehip_product_multi **out, int Ndens, const kdehip_density *trees, int ndims,
                                 const uint8_t *partialDimMask, int precision, int first_device, int ngpus);
@@ -176,6 +186,8 @@ kdehip_product *kdehip_product_multi_plan(kdehip_product_multi *mp, int g); /* t
 int kdehip_product_multi_sample_philox(kdehip_product_multi *mp, int64_t Np, int Niter, uint64_t seed,
                                        int64_t sample_offset, int addEntropy, double *const *d_points,
                                        int64_t *const *d_indices, void *const *streams);
+/* copy-engine transfers each device issues per product: 0 when the all-gather is fused into the kernel */
+int kdehip_product_multi_transfers_per_product(const kdehip_product_multi *mp);
 
 /* ---- (3) host twin of the device RNG ----------------------------------------------------------
  * Fills the arrays a caller would pass as randU / randN so that a streams-run (or the Julia

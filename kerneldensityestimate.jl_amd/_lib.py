@@ -61,6 +61,7 @@ SIGNATURES = {
     "kdehip_product_multi_sample_philox": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_uint64, C.c_int64, C.c_int,
                                                      C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                                      C.POINTER(C.c_void_p)]),
+    "kdehip_product_multi_transfers_per_product": (C.c_int, [C.c_void_p]),
     "kdehip_product_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(CDensity), C.c_int, u8p,
                                         C.c_int, C.c_int]),
     "kdehip_product_destroy": (None, [C.c_void_p]),
@@ -76,6 +77,7 @@ SIGNATURES = {
     "kdehip_product_sample_philox_host": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_uint64, C.c_int64,
                                                     C.c_int, f64p, i64p, i32p]),
     "kdehip_product_set_variant": (C.c_int, [C.c_void_p, C.c_int]),
+    "kdehip_product_launch_geometry": (C.c_int, [C.c_void_p, C.c_int64, i32p, i32p]),
     "kdehip_philox_fill_uniform": (None, [C.c_uint64, C.c_int64, C.c_int64, C.c_int64, f64p]),
     "kdehip_philox_fill_normal": (None, [C.c_uint64, C.c_int64, C.c_int64, C.c_int64, f64p]),
     "kdehip_evaluate": (C.c_int, [C.POINTER(CDensity), f64p, C.c_int64, C.c_int, f64p, C.c_int]),

@@ -681,12 +681,20 @@ extern "C" int kdehip_auto_bandwidth(int64_t D64, int64_t N, const double *point
   pin.n = std::max(sizeof(double) * N * D, sizeof(Golden) * 2 * D);
   KDEHIP_CHECK(cached_host_malloc(&pin.p, pin.n));
   Golden *h_state = static_cast<Golden *>(pin.p);
+  // Declared after the two blocks, i.e. destroyed before them: an early error return below waits for whatever has
+  // been enqueued before the device block and the pinned block go back to the caches (where another thread may be
+  // handed them at once).  On the regular path the stream is already idle.
+  struct DrainOnExit {
+    ~DrainOnExit() { (void)hipStreamSynchronize(nullptr); }
+  } drain_on_exit;
 
   if (N <= kPrepMaxN) {
     std::memcpy(pin.p, points, sizeof(double) * N * D);
     KDEHIP_CHECK(hipMemcpyAsync(d_pts, pin.p, sizeof(double) * N * D, hipMemcpyHostToDevice, nullptr));
     int64_t P = 1;
     while (P < N) P <<= 1;
+    KDEHIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(loocv_prep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     static_cast<int>(sizeof(double) * 5 * P)));  // up to 80 KiB; per call = per device
     hipLaunchKernelGGL(loocv_prep_kernel, dim3(D), dim3(kPrepThreads), sizeof(double) * 5 * P, nullptr, d_pts, N, D,
                        const_cast<double *>(r.x), r.state);
     KDEHIP_CHECK(hipGetLastError());

@@ -398,58 +398,144 @@ struct EvalGeneric {
 template <typename P> constexpr bool kIsLdsPtr = false;
 template <typename T> constexpr bool kIsLdsPtr<const __attribute__((address_space(3))) T *> = true;
 
+// ---- the lane's sum over its rows: ONE association for every kernel, width, team size and staging mode ----------
+// S = (a0 + a1) + (a2 + a3), where a_k is the sum, in increasing row order, of the lane's rows r = k (mod 4).
+// A wavefront that owns the whole chain keeps the four sums itself (lane_rows_all); when a chain is split over a
+// team of 2 (4) wavefronts, member t keeps a_{2t}, a_{2t+1} (a_t) of its rows only (lane_rows_member) and the
+// partial sums meet in LDS (team_combine): both forms add the very same numbers in the very same order, so which
+// label a uniform draw selects never depends on how many wavefronts worked on the chain.  Chunked tiles keep the
+// sums across chunks (chunk starts are multiples of 4 rows, so a row's class is its class inside the chunk).
+template <typename T>
+struct LaneAcc {
+  T a[4] = {T(0), T(0), T(0), T(0)};
+  __device__ __forceinline__ T total() const { return (a[0] + a[1]) + (a[2] + a[3]); }
+};
+
+// every row of `rows` (row 0, field 0, lane 0; LDS or global), `nrows` of them, accumulated into acc
 template <typename T, typename P, typename Eval, bool PREFETCH = true>
-__device__ __forceinline__ T lane_sum_rows(P rows, int nrows, int RS, int lane, const Eval &ev) {
+__device__ __forceinline__ void lane_rows_all(P rows, int nrows, int RS, int lane, const Eval &ev, LaneAcc<T> &acc) {
   constexpr bool kUsePairs = sizeof(T) == 4 && Eval::kPairs;
   if constexpr (kUsePairs) {
     // fp32: two rows per trip through the packed-math pipe (their 2F loads are in flight together)
-    kdehip_f2 S2 = {0.0f, 0.0f};
+    kdehip_f2 Sa = {acc.a[0], acc.a[1]}, Sb = {acc.a[2], acc.a[3]};
     P e2 = rows + lane;
     int i2 = 0;
-    for (; i2 + 2 <= nrows; i2 += 2, e2 += 2 * RS) S2 += ev.pair(e2, RS);
-    T Sp = S2.x + S2.y;
-    if (i2 < nrows) Sp += ev(e2);
-    return Sp;
-  }
-  if constexpr (!PREFETCH) {
-    T S0 = T(0);
+    for (; i2 + 4 <= nrows; i2 += 4, e2 += 4 * RS) {
+      Sa += ev.pair(e2, RS);
+      Sb += ev.pair(e2 + 2 * RS, RS);
+    }
+    if (i2 + 2 <= nrows) {
+      Sa += ev.pair(e2, RS);
+      if (i2 + 2 < nrows) Sb.x += ev(e2 + 2 * RS);
+    } else if (i2 < nrows) {
+      Sa.x += ev(e2);
+    }
+    acc.a[0] = Sa.x; acc.a[1] = Sa.y; acc.a[2] = Sb.x; acc.a[3] = Sb.y;
+    return;
+  } else if constexpr (!PREFETCH) {
     P e0 = rows + lane;
-#pragma unroll 2
-    for (int i = 0; i < nrows; ++i, e0 += RS) S0 += ev(e0);
-    return S0;
+    int i = 0;
+    for (; i + 4 <= nrows; i += 4, e0 += 4 * RS) {
+      acc.a[0] += ev(e0);
+      acc.a[1] += ev(e0 + RS);
+      __builtin_amdgcn_sched_barrier(0);  // two rows in flight, as before: the 128-register builds have no room for four
+      acc.a[2] += ev(e0 + 2 * RS);
+      acc.a[3] += ev(e0 + 3 * RS);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (i < nrows) acc.a[0] += ev(e0);
+    if (i + 1 < nrows) acc.a[1] += ev(e0 + RS);
+    if (i + 2 < nrows) acc.a[2] += ev(e0 + 2 * RS);
+    return;
+  } else {
+    // software pipelined, two rows per trip with ping-pong register sets (no copies): the fields of the
+    // next row are requested before the current row is evaluated, so the LDS (or L2) round trip overlaps
+    // ~40-100 fp64 instructions instead of stalling in front of each of them.
+    P e = rows + lane;
+    typename Eval::Row ra = ev.load(e);
+    // LDS tiles: have row 0 landed before the loop, otherwise the compiler's wait-count bookkeeping merges
+    // "row 0 pending" into the loop head and waits for every prefetch right after issuing it
+    if constexpr (kIsLdsPtr<P>) __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) only
+    int i = 0;
+    auto trip = [&](T &x, T &y, int ii) {
+      const typename Eval::Row rb = ev.load(e + RS);  // row ii+1
+      __builtin_amdgcn_sched_barrier(0);              // keep the requests above the arithmetic
+      const typename Eval::Mid ma = ev.arg(ra);       // ... ends by issuing row ii's exp table lookup
+      __builtin_amdgcn_sched_barrier(0);
+      const typename Eval::Mid mb = ev.arg(rb);       // hides the latency of row ii's lookup
+      e += (ii + 2 < nrows) ? 2 * RS : RS;            // row ii+2, or row ii+1 again (never past the tile)
+      ra = ev.load(e);
+      __builtin_amdgcn_sched_barrier(0);
+      x += ev.fin(ma);
+      y += ev.fin(mb);
+    };
+    for (; i + 4 <= nrows; i += 4) {
+      trip(acc.a[0], acc.a[1], i);
+      trip(acc.a[2], acc.a[3], i + 2);
+    }
+    if (i + 2 <= nrows) {
+      trip(acc.a[0], acc.a[1], i);
+      if (i + 2 < nrows) acc.a[2] += ev(ra);
+    } else if (i < nrows) {
+      acc.a[0] += ev(ra);
+    }
   }
-  // software pipelined, two rows per trip with ping-pong register sets (no copies): the fields of the
-  // next row are requested before the current row is evaluated, so the LDS (or L2) round trip overlaps
-  // ~40-100 fp64 instructions instead of stalling in front of each of them.
-  T S = T(0);
-  P e = rows + lane;
-  typename Eval::Row ra = ev.load(e);
-  // LDS tiles: have row 0 landed before the loop, otherwise the compiler's wait-count bookkeeping merges
-  // "row 0 pending" into the loop head and waits for every prefetch right after issuing it
-  if constexpr (kIsLdsPtr<P>) __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) only
-  int i = 0;
-  for (; i + 2 <= nrows; i += 2) {
-    const typename Eval::Row rb = ev.load(e + RS);  // row i+1
-    __builtin_amdgcn_sched_barrier(0);              // keep the requests above the arithmetic
-    const typename Eval::Mid ma = ev.arg(ra);       // ... ends by issuing row i's exp table lookup
-    __builtin_amdgcn_sched_barrier(0);
-    const typename Eval::Mid mb = ev.arg(rb);       // hides the latency of row i's lookup
-    e += (i + 2 < nrows) ? 2 * RS : RS;             // row i+2, or row i+1 again (never past the tile)
-    ra = ev.load(e);
-    __builtin_amdgcn_sched_barrier(0);
-    S += ev.fin(ma);
-    S += ev.fin(mb);
+}
+
+// the rows of ONE member of a wavefront team: trips over rows (i, i + second) for i = first, first + stride, ...
+// (team of 2: first = 2t, second = 1, stride = 4, x = a_{2t}, y = a_{2t+1}; team of 4: first = t, second = 4,
+// stride = 8, both rows of a trip go to x = a_t in row order: `same`).  All arguments but `lane` are wave-uniform.
+template <typename T, typename P, typename Eval, bool PREFETCH = true>
+__device__ __forceinline__ void lane_rows_member(P rows, int nrows, int RS, int lane, const Eval &ev, int first,
+                                                 int second, int stride, bool same, T &x, T &y) {
+  int i = first;
+  if (i >= nrows) return;
+  P e = rows + lane + first * RS;
+  if constexpr (!PREFETCH) {
+    for (; i + second < nrows; i += stride, e += stride * RS) {
+      const T va = ev(e);
+      const T vb = ev(e + second * RS);
+      x += va;
+      if (same) x += vb; else y += vb;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (i < nrows) x += ev(e);
+  } else {
+    typename Eval::Row ra = ev.load(e);
+    if constexpr (kIsLdsPtr<P>) __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) only
+    for (; i + second < nrows; i += stride) {
+      const typename Eval::Row rb = ev.load(e + second * RS);
+      __builtin_amdgcn_sched_barrier(0);
+      const typename Eval::Mid ma = ev.arg(ra);
+      __builtin_amdgcn_sched_barrier(0);
+      const typename Eval::Mid mb = ev.arg(rb);
+      e += (i + stride < nrows) ? stride * RS : second * RS;  // the next trip's first row, or stay inside the tile
+      ra = ev.load(e);
+      __builtin_amdgcn_sched_barrier(0);
+      x += ev.fin(ma);
+      const T vb = ev.fin(mb);
+      if (same) x += vb; else y += vb;
+    }
+    if (i < nrows) x += ev(ra);
   }
-  if (i < nrows) S += ev(ra);
-  return S;
+}
+
+// the canonical lane sum of a whole tile
+template <typename T, typename P, typename Eval, bool PREFETCH = true>
+__device__ __forceinline__ T lane_sum_rows(P rows, int nrows, int RS, int lane, const Eval &ev) {
+  LaneAcc<T> acc;
+  lane_rows_all<T, P, Eval, PREFETCH>(rows, nrows, RS, lane, ev, acc);
+  return acc.total();
 }
 
 // Uniform draws over the frontier that replaced an underflowed conditional (:311-315) are counted in the 8 bytes
 // in front of the plan's level table (a layout contract with product.hip: the table's address is live in scalar
 // registers anyway, so the counter costs the common path nothing): how tests compare the fp32 path's fallback
 // behaviour with fp64's and the oracle's.  `fb` = the level table's address.
+// Wavefronts whose draws must not be counted (the surplus wavefronts of the last workgroup, which replay the last chain,
+// and all but the first member of a wavefront team) pass fb = nullptr.
 __device__ __forceinline__ void count_fallback(const void *fb, int lane) {
-  if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(const_cast<void *>(fb)) - 1, 1ull);
+  if (fb != nullptr && lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(const_cast<void *>(fb)) - 1, 1ull);
 }
 
 template <typename T, typename P, typename Eval, typename DS>
@@ -583,9 +669,15 @@ __device__ __forceinline__ int draw_label_kept(P rows, const DS &ds, int lane, c
       v[i + 1] = T(0);
     }
   }
-  T S = T(0);
+  // the canonical lane sum (LaneAcc): a_k over the rows = k (mod 4); the rows beyond B add an exact +0
+  T ak[4];
 #pragma unroll
-  for (int i = 0; i < BMAX; ++i) S += v[i];  // (+0 for the rows beyond B: the first pass's sequential sum)
+  for (int k = 0; k < 4; ++k) {
+    ak[k] = v[k];
+#pragma unroll
+    for (int i = k + 4; i < BMAX; i += 4) ak[k] += v[i];
+  }
+  const T S = (ak[0] + ak[1]) + (ak[2] + ak[3]);
   const T incl = wave_inclusive_scan(S);
   const T total = lane_read(incl, 63);
   if (!(total >= Num<T>::tiny_total())) {  // uniform fallback (:311-315), as in select_from_scan
@@ -755,6 +847,121 @@ __device__ __forceinline__ int draw_label(P rows, const DS &ds, int lane, const 
   KSTAMP(tp1);
   KSTAMP_ADD(2, tp0, tp1);
   return select_or_raise<T, P>(S, rows, ds, lane, ev, u, fb KSTAMP_ARGS);
+}
+
+// ---- wavefront teams: one chain on 2 or 4 wavefronts ------------------------------------------------------------
+// With few chains per GPU (2048 per MI355X = two wavefronts per SIMD) the serial dependency chain of a step leaves the
+// vector pipes idle; on the deep levels (many rows per lane) the rows of a step are therefore shared by the wavefronts
+// of a TEAM: member t evaluates the rows whose class (row mod 4) it owns, the 64 partial lane sums of every member
+// meet in LDS (one workgroup barrier: all chains of a workgroup walk the schedule in lock step anyway), and from there
+// on every member repeats the identical selection -- same lane sums (LaneAcc's association), same scan, same second
+// pass -- so the members never diverge and need no further communication.  Every barrier below is executed by every
+// wavefront of the workgroup, whatever its chain's data look like.
+template <typename T>
+struct Team {
+  int size = 1;    // wavefronts per chain: 1, 2 or 4 (wave-uniform)
+  int member = 0;  // this wavefront's index in its team
+  int first = 0, second = 1, stride = 4;  // lane_rows_member's row walk of this member
+  bool same = false;
+  __attribute__((address_space(3))) T *xch = nullptr;    // the chain's strip [size][64]: partial lane sums
+  __attribute__((address_space(3))) T *notes = nullptr;  // the chain's strip [size][kMaxSeg]: segment sums of one lane
+  __device__ __forceinline__ void set(int size_, int member_) {
+    size = size_; member = member_;
+    same = (size_ == 4);
+    first = same ? member_ : 2 * member_;
+    second = same ? 4 : 1;
+    stride = same ? 8 : 4;
+  }
+};
+
+// LDS writes of this wavefront are complete, then the workgroup barrier (the direct-to-LDS copies that may be in
+// flight are NOT waited for: they belong to the staging protocol and its own barriers)
+__device__ __forceinline__ void team_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// the lane sums of the whole chain from the members' partial sums, LaneAcc's association.  `pre_barrier`: the strip
+// may still be read by a slower member (no other workgroup barrier since the previous exchange: resident tiles).
+template <typename T>
+__device__ __forceinline__ T team_combine(T part, int lane, const Team<T> &tm, bool pre_barrier) {
+  if (pre_barrier) team_barrier();
+  tm.xch[tm.member * 64 + lane] = part;
+  team_barrier();
+  if (tm.size == 2) return tm.xch[lane] + tm.xch[64 + lane];
+  return (tm.xch[lane] + tm.xch[64 + lane]) + (tm.xch[128 + lane] + tm.xch[192 + lane]);
+}
+
+// draw_label for a tile readable through one pointer, rows shared by the team
+template <typename T, typename P, bool PREFETCH, typename Eval, typename DS>
+__device__ __forceinline__ int draw_label_team(P rows, const DS &ds, int lane, const Eval &ev, double u,
+                                               const void *fb, const Team<T> &tm, bool pre_barrier) {
+  T x = T(0), y = T(0);
+  lane_rows_member<T, P, Eval, PREFETCH>(rows, ds.B, ds.F * 64 + 1, lane, ev, tm.first, tm.second, tm.stride, tm.same, x, y);
+  const T S = team_combine(x + y, lane, tm, pre_barrier);
+  return select_or_raise<T, P>(S, rows, ds, lane, ev, u, fb
+#ifdef KDEHIP_STAMPS
+                               , nullptr, false
+#endif
+  );
+}
+
+// select_or_raise_seg for a team: `seg` holds this member's share of the lane's running sums at the segment
+// boundaries; the shares of the winning lane meet in LDS (one more barrier) and are added in LaneAcc's association.
+template <typename T, typename P, typename Eval, typename DS>
+__device__ __forceinline__ int select_or_raise_seg_team(T S, const SegSums<T> &seg, int seg_rows, P rows, const DS &ds,
+                                                        int lane, const Eval &ev, double u, const void *fb,
+                                                        const Team<T> &tm) {
+  const int n = ds.n, B = ds.B;
+  const int RS = ds.F * 64 + 1;
+  const T incl = wave_inclusive_scan(S);
+  const T total = lane_read(incl, 63);
+  const T target = static_cast<T>(u) * total;
+  const unsigned long long hit = __ballot(target <= incl);
+  const int last_lane = ds.last_lane;
+  int lstar = hit ? (__ffsll(hit) - 1) : last_lane;
+  if (lstar > last_lane) lstar = last_lane;
+  // (the exchange comes before the underflow test: every wavefront of the workgroup must pass the barrier)
+  T mine = T(0);
+#pragma unroll
+  for (int k = 0; k < kMaxSeg - 1; ++k) {
+    const T pk = lane_read(seg.v[k], lstar);
+    mine = (lane == k) ? pk : mine;
+  }
+  if (lane < kMaxSeg) tm.notes[tm.member * kMaxSeg + lane] = mine;
+  team_barrier();
+  if (!(total >= Num<T>::tiny_total())) return select_or_raise<T, P>(S, rows, ds, lane, ev, u, fb
+#ifdef KDEHIP_STAMPS
+                                                                     , nullptr, false
+#endif
+  );
+  const T base = lane_read(incl - S, lstar);
+  int lenl = n - lstar * B;
+  if (lenl > B) lenl = B;
+  const int nseg = (B + seg_rows - 1) / seg_rows;
+  int sidx = nseg - 1;
+  T before = T(0), run = T(0);
+  bool found = false;
+#pragma unroll
+  for (int k = 0; k < kMaxSeg - 1; ++k) {
+    if (k < nseg - 1) {  // wave-uniform
+      const T pk = (tm.size == 2) ? tm.notes[k] + tm.notes[kMaxSeg + k]
+                                  : (tm.notes[k] + tm.notes[kMaxSeg + k]) + (tm.notes[2 * kMaxSeg + k] + tm.notes[3 * kMaxSeg + k]);
+      if (!found && target <= base + pk) { found = true; sidx = k; before = run; }
+      run = pk;
+    }
+  }
+  if (!found) before = run;
+  int r0 = sidx * seg_rows;
+  if (r0 >= lenl) return (lenl - 1) * 64 + lstar;
+  int len = lenl - r0;
+  if (len > seg_rows) len = seg_rows;
+  P col = rows + lstar;
+  T p2 = T(0);
+  if (lane < len) p2 = ev(col + (r0 + lane) * RS);
+  const T inc3 = wave_inclusive_scan(p2);
+  const unsigned long long h3 = __ballot((target <= (base + before) + inc3) && (lane < len));
+  const int istar = h3 ? (__ffsll(h3) - 1) : (len - 1);
+  return (r0 + istar) * 64 + lstar;
 }
 
 // ---- the sampler ----------------------------------------------------------------------------------

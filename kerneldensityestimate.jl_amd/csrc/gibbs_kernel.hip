@@ -74,6 +74,7 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan,
   // the last chain and store nothing
   const bool live = s < a.Np;
   if (!live) s = a.Np - 1;
+  const void *fb = live ? static_cast<const void *>(plan.levels) : nullptr;  // who counts uniform fallbacks (not the replays)
   const uint64_t gs = static_cast<uint64_t>(a.sample_offset + s);
 
   const int M = plan.M, L = plan.L;
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan,
     auto rows = hdr + kTileHeader;
     using P = decltype(rows);
     const int pos = (vflags & 8) ? 0 : draw(ds, hdr, mean, cov, [&](const auto &ev) {
-      return draw_label<T, P, kPrefetchRows, (WAVES <= 8)>(rows, ds, lane, ev, u, plan.levels KSTAMP_ARGS);
+      return draw_label<T, P, kPrefetchRows, (WAVES <= 8)>(rows, ds, lane, ev, u, fb KSTAMP_ARGS);
     });
     wave_sync();
     KSTAMP(ts1);
@@ -229,7 +230,7 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan,
     const T *hdr = data + ds.hdr_off;
     const int pos = draw(ds, hdr, mean, cov, [&](const auto &ev) {
       const int RS = ds.F * 64 + 1, rc = chunk_rows(ds);
-      T S = T(0);
+      LaneAcc<T> acc;  // the lane's sums over its rows, kept across the chunks (gibbs_device.hpp: one association everywhere)
       SegSums<T> seg;
       const int cps = seg_chunks(rc);
       const bool use_seg = seg_applies(ds.B, rc);
@@ -239,14 +240,15 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan,
         if (r0 + rc < ds.B) stage_chunk(ds, r0 + rc, (gchunk + 1) & 1);
         else if (has_next) stage_chunk(dn, 0, (gchunk + 1) & 1);
         const int nrows = (ds.B - r0 < rc) ? (ds.B - r0) : rc;
-        S += lane_sum_rows<T, LdsPtr<T>, std::decay_t<decltype(ev)>, kPrefetchRows>(
-            (LdsPtr<T>)(pool + (gchunk & 1) * (kLdsPoolBytes / 2)), nrows, RS, lane, ev);
-        if (use_seg && ++cin == cps) { seg.note(S); cin = 0; }  // the lane's running sum at a segment boundary
+        lane_rows_all<T, LdsPtr<T>, std::decay_t<decltype(ev)>, kPrefetchRows>(
+            (LdsPtr<T>)(pool + (gchunk & 1) * (kLdsPoolBytes / 2)), nrows, RS, lane, ev, acc);
+        if (use_seg && ++cin == cps) { seg.note(acc.total()); cin = 0; }  // the lane's running sum at a segment boundary
       }
+      const T S = acc.total();
       // (a raised repeat of the evaluation reads the tile from global memory: no staging, no barriers)
       if (use_seg)
-        return select_or_raise_seg<T, const T *>(S, seg, cps * rc, hdr + kTileHeader, ds, lane, ev, u, plan.levels KSTAMP_ARGS);
-      return select_or_raise<T, const T *>(S, hdr + kTileHeader, ds, lane, ev, u, plan.levels KSTAMP_ARGS);
+        return select_or_raise_seg<T, const T *>(S, seg, cps * rc, hdr + kTileHeader, ds, lane, ev, u, fb KSTAMP_ARGS);
+      return select_or_raise<T, const T *>(S, hdr + kTileHeader, ds, lane, ev, u, fb KSTAMP_ARGS);
     });
     wave_sync();
     set_particle(j, ds, hdr, pos);
@@ -455,7 +457,7 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan,
         const T total = lane_read(incl, n < 64 ? n : 63);  // (a 64-node row: its last scan value IS the total)
         int pos;
         if (!(total >= Num<T>::tiny_total())) {  // uniform fallback (:311-315), rare: fetch the descriptor here
-          count_fallback(plan.levels, lane);
+          count_fallback(fb, lane);
           const LevelDesc dk = levels[jt * (L + 1) + l];
           const T wl = ((LdsPtr<T>)(pool + dk.lds_off) + kTileHeader)[(dk.F - 1) * 64 + (n - 1)];
           int z = n - 1;
@@ -500,7 +502,9 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan,
   if (live && lane == 0) {
     for (int k = 0; k < M; ++k) {
       const LevelDesc ds = levels[k * (L + 1) + L];
-      a.indices[s * M + k] = static_cast<int64_t>(plan.perm[ds.perm_off + psel[k]]) + 1;
+      const int64_t label = static_cast<int64_t>(plan.perm[ds.perm_off + psel[k]]) + 1;
+      a.indices[s * M + k] = label;
+      for (int q = 0; q < a.npeers; ++q) a.peer_indices[q][s * M + k] = label;  // (multi-GPU: the all-gather)
     }
   }
   {
@@ -508,7 +512,10 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan,
     product_dim(-1, any_bits, mean, cov);
     T xf = mean;
     if (a.addEntropy) xf = mean + Num<T>::sqrt(cov) * static_cast<T>(normal_for_lane(L));
-    if (live && lane < D) a.points[s * D + lane] = static_cast<double>(xf);
+    if (live && lane < D) {
+      a.points[s * D + lane] = static_cast<double>(xf);
+      for (int q = 0; q < a.npeers; ++q) a.peer_points[q][s * D + lane] = static_cast<double>(xf);
+    }
   }
 }
 

@@ -83,10 +83,14 @@ template <typename T, int D, int M, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan, RunArgs a) {
   constexpr bool kPrefetchRows = (WAVES <= 12) || sizeof(T) == 4 || D <= 4;  // as in gibbs_kernel.hip
   constexpr bool kKeptRows = (WAVES <= 8);
-  // LDS: [exp table 2 KiB][normals: WAVES x 1 KiB][uniforms: WAVES x 1 KiB][tile pool]
+  // wavefront teams (a chain on 2 or 4 wavefronts, RunArgs.team): the 16-wavefront fp64 builds
+  constexpr bool kTeams = (WAVES == 16) && sizeof(T) == 8;
+  // LDS: [exp table 2 KiB][normals: 1 KiB per chain; teams: the partial-sum strips in the upper half][uniforms:
+  // WAVES x 1 KiB][teams: 2 KiB of segment notes][tile pool]
   constexpr int kNormOff = 2048;
   constexpr int kUnifOff = kNormOff + WAVES * kLeanMaxNormals * 8;
-  constexpr int kPoolOff = kUnifOff + WAVES * 1024;
+  constexpr int kNotesOff = kUnifOff + WAVES * 1024;
+  constexpr int kPoolOff = kNotesOff + (kTeams ? 2048 : 0);
   static_assert(kPoolOff + kLdsPoolBytes <= 160 * 1024, "LDS budget of one CU exceeded");
   __shared__ __attribute__((aligned(1024))) unsigned char smem[kPoolOff + kLdsPoolBytes];
 
@@ -95,10 +99,18 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan, Ru
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
-  int64_t s = static_cast<int64_t>(blockIdx.x) * WAVES + wave;
-  const bool live = s < a.Np;  // surplus wavefronts of the last workgroup replay the last chain and store nothing
-  if (!live) s = a.Np - 1;
+  // team geometry: chains of a workgroup = WAVES / team size; member 0 of a team owns the chain's outputs
+  int tsize = 1;
+  if constexpr (kTeams) tsize = a.team == 4 ? 4 : (a.team == 2 ? 2 : 1);
+  const int tshift = tsize >> 1;  // log2 of 1, 2, 4
+  const int tmember = wave & (tsize - 1);
+  const int chain = wave >> tshift;
+  int64_t s = static_cast<int64_t>(blockIdx.x) * (WAVES >> tshift) + chain;
+  const bool in_range = s < a.Np;  // surplus wavefronts of the last workgroup replay the last chain and store nothing
+  if (!in_range) s = a.Np - 1;
+  const bool live = in_range && tmember == 0;
   const uint64_t gs = static_cast<uint64_t>(a.sample_offset + s);
+  const void *fb = live ? static_cast<const void *>(plan.levels) : nullptr;  // who counts uniform fallbacks
 
   const int L = plan.L;
   const T *__restrict__ data = static_cast<const T *>(plan.data);
@@ -107,12 +119,22 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan, Ru
   const int dl = lane < D ? lane : D - 1;  // this lane's dimension in the "lanes = dimensions" phases
   const int vlev = a.variant % 1000;
 
+  Team<T> team;
+  if constexpr (kTeams) {
+    team.set(tsize, tmember);
+    // (teams leave the upper half of the normals region free: at most 8 chains per workgroup)
+    team.xch = (__attribute__((address_space(3))) T *)(smem + kNormOff + 8192) + chain * (tsize * 64);
+    team.notes = (__attribute__((address_space(3))) T *)(smem + kNotesOff) + chain * (tsize * kMaxSeg);
+  }
+  const int team_level = (kTeams && tsize > 1) ? a.team_level : 0;
+  const int team_min_rows = a.team_min_rows;
+
   // ---- the chain's normal deviates, once (samplePoint! consumes D per level + D at the end, :440-463) ----
-  double *sNorm = reinterpret_cast<double *>(smem + kNormOff) + wave * kLeanMaxNormals;
+  double *sNorm = reinterpret_cast<double *>(smem + kNormOff) + chain * kLeanMaxNormals;
   const int R = D * (L + 1);
-  for (int r = lane; r < R; r += 64)
+  for (int r = lane + 64 * tmember; r < R; r += 64 * tsize)
     sNorm[r] = a.rng_philox ? philox_normal(a.seed, gs, static_cast<uint32_t>(r)) : a.randN[s * a.R + r];
-  __syncthreads();  // (exp table; the strip itself is only read by its own wavefront)
+  __syncthreads();  // (exp table; the strip is only read by its own chain's wavefronts)
 
   // ---- chain state: selected kernel of every density, lanes = dimensions ----
   T lam[M], lmu[M];  // 1/variance and mean/variance
@@ -209,6 +231,17 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan, Ru
   const T *tables = static_cast<const T *>(plan.tables);
   const int Lt = (vlev == 1 || vlev == 4 || !a.use_tables) ? 0 : plan.Lt;
 
+  bool shared_level = false;  // this level's steps are walked by all members of the team
+  // the draw on a tile readable through one pointer: by this wavefront alone, or its rows shared by the team
+  auto draw_rows = [&](const auto &ds, auto rows, const auto &ev, double u, bool pre_barrier) -> int {
+    using P = decltype(rows);
+    if constexpr (kTeams) {
+      if (shared_level && ds.B >= team_min_rows)
+        return draw_label_team<T, P, kPrefetchRows>(rows, ds, lane, ev, u, fb, team, pre_barrier);
+    }
+    return draw_label<T, P, kPrefetchRows, kKeptRows>(rows, ds, lane, ev, u, fb);
+  };
+
   // one (pass, density) step on a tile readable through one pointer: leave-one-out product (sweeps) or the point
   // just drawn (sampleIndices! pass, :364-385), the draw, and the new kernel
   auto step = [&](auto jc, const auto &ds, auto hdr, bool first, T x) {
@@ -216,9 +249,8 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan, Ru
     if (!first) product(jc, mean, cov);
     const double u = next_uniform();
     auto rows = hdr + kTileHeader;
-    using P = decltype(rows);
     const int pos = __builtin_amdgcn_readfirstlane(draw(ds, hdr, mean, cov, [&](const auto &ev) {
-      return draw_label<T, P, kPrefetchRows, kKeptRows>(rows, ds, lane, ev, u, plan.levels);
+      return draw_rows(ds, rows, ev, u, /*pre_barrier=*/true);
     }));
     adopt(jc, ds, hdr, pos);
   };
@@ -238,9 +270,35 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan, Ru
   const int Lrun = L;
 #endif
   for (int l = 1; l <= Lrun; ++l) {
+    // Teams: the levels below team_level belong to member 0; the other members only take part in the staging of
+    // the tiles and in the workgroup barriers, and receive the chain's state when the shared levels begin.
+    bool active = true;
+    if constexpr (kTeams) {
+      if (team_level > 0) {
+        shared_level = (l >= team_level);
+        active = shared_level || tmember == 0;
+        if (l == team_level) {
+          auto hand = team.xch;  // [2M][8]: lam, lmu of the lanes that hold dimensions
+          team_barrier();
+          if (tmember == 0 && lane < 8)
+            static_for<M>([&](auto jc) {
+              constexpr int j = decltype(jc)::value;
+              hand[(2 * j) * 8 + lane] = lam[j];
+              hand[(2 * j + 1) * 8 + lane] = lmu[j];
+            });
+          team_barrier();
+          if (tmember != 0)
+            static_for<M>([&](auto jc) {
+              constexpr int j = decltype(jc)::value;
+              lam[j] = hand[(2 * j) * 8 + dl];
+              lmu[j] = hand[(2 * j + 1) * 8 + dl];
+            });
+        }
+      }
+    }
     // samplePoint! (:440-463): x = mean + sqrt(cov) * randn, all densities included
-    T x;
-    {
+    T x = T(0);
+    if (active) {
       T mean, cov;
       product(IC<-1>{}, mean, cov);
       x = mean + Num<T>::sqrt(cov) * static_cast<T>(sNorm[(l - 1) * D + dl]);
@@ -255,6 +313,7 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan, Ru
     const int mode = vlev == 1 ? int(kStageGlobal) : level_mode;
     const bool tabulated = (l <= Lt);
     const int npass = tabulated ? 1 : a.Niter + 1;  // tabulated levels: only the sampleIndices! pass runs here
+    if (!active) c += static_cast<uint32_t>(M * (a.Niter + 1));  // the draws member 0 makes on this level
 
     if (mode == kStageResident) {
       staging_barrier();  // every wavefront is done reading the previous level's images
@@ -263,11 +322,12 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan, Ru
         stage_tile<WAVES>(reinterpret_cast<const unsigned char *>(data + ds.hdr_off()), pool + ds.lds_off, ds.stage_bytes, wave, lane);
       });
       staging_barrier();
-      for (int p = 0; p < npass; ++p)
-        static_for<M>([&](auto jc) {
-          const LeanTile<D> &ds = dsc[decltype(jc)::value];
-          step(jc, ds, (LdsPtr<T>)(pool + ds.lds_off), p == 0, x);
-        });
+      if (active)
+        for (int p = 0; p < npass; ++p)
+          static_for<M>([&](auto jc) {
+            const LeanTile<D> &ds = dsc[decltype(jc)::value];
+            step(jc, ds, (LdsPtr<T>)(pool + ds.lds_off), p == 0, x);
+          });
     } else if (mode == kStageStream) {
       staging_barrier();
       stage_tile<WAVES>(reinterpret_cast<const unsigned char *>(data + dsc[0].hdr_off()), pool, dsc[0].stage_bytes, wave, lane);
@@ -279,26 +339,31 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan, Ru
           constexpr int jn = (j + 1 == M) ? 0 : j + 1;
           const LeanTile<D> &ds = dsc[j];
           T mean = x, cov = T(0);
-          if (p != 0) product(jc, mean, cov);
-          const double u = next_uniform();
+          double u = 0.0;
+          if (active) {
+            if (p != 0) product(jc, mean, cov);
+            u = next_uniform();
+          }
           // tile t has been copied by all wavefronts once everyone passes this barrier; buffer (t+1)&1 was last
           // read in step t-1, which everyone has left -> start the next copy
           staging_barrier();
           if (t + 1 < nsteps)
             stage_tile<WAVES>(reinterpret_cast<const unsigned char *>(data + dsc[jn].hdr_off()),
                               pool + ((t + 1) & 1) * (kLdsPoolBytes / 2), dsc[jn].stage_bytes, wave, lane);
-          auto hdr = (LdsPtr<T>)(pool + (t & 1) * (kLdsPoolBytes / 2));
-          auto rows = hdr + kTileHeader;
-          const int pos = __builtin_amdgcn_readfirstlane(draw(ds, hdr, mean, cov, [&](const auto &ev) {
-            return draw_label<T, LdsPtr<T>, kPrefetchRows, kKeptRows>(rows, ds, lane, ev, u, plan.levels);
-          }));
-          adopt(jc, ds, hdr, pos);
+          if (active) {
+            auto hdr = (LdsPtr<T>)(pool + (t & 1) * (kLdsPoolBytes / 2));
+            auto rows = hdr + kTileHeader;
+            const int pos = __builtin_amdgcn_readfirstlane(draw(ds, hdr, mean, cov, [&](const auto &ev) {
+              return draw_rows(ds, rows, ev, u, /*pre_barrier=*/false);  // (the step's staging barrier separates the exchanges)
+            }));
+            adopt(jc, ds, hdr, pos);
+          }
           ++t;
         });
     } else if (mode == kStageChunked) {
       // tiles larger than half the pool: pass 1 streams the rows through the two pool halves (one barrier per
       // chunk, the copy of chunk g+1 overlaps the evaluation of chunk g); the second pass and the new kernel are
-      // read from global memory
+      // read from global memory.  (Chunked levels are always shared by a team: lean_geometry.)
       staging_barrier();
       stage_chunk(dsc[0], 0, gchunk & 1);
       int t = 0;
@@ -313,38 +378,58 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan, Ru
           const double u = next_uniform();
           const T *hdr = data + ds.hdr_off();
           const int pos = draw(ds, hdr, mean, cov, [&](const auto &ev) {
+            using Ev = std::decay_t<decltype(ev)>;
             const int RS = ds.F * 64 + 1, rc = ds.chunk_rows;
-            T S = T(0);
+            LaneAcc<T> acc;          // a wavefront that owns its chain
+            T mx = T(0), my = T(0);  // a team member's share
             SegSums<T> seg;
             const int cps = seg_chunks(rc);
             const bool use_seg = seg_applies(ds.B, rc);
+            bool shared = false;
+            if constexpr (kTeams) shared = shared_level;
             int cin = 0;
             for (int r0 = 0; r0 < ds.B; r0 += rc, ++gchunk) {
               staging_barrier();  // this chunk has landed for every wavefront; the other half is free again
               if (r0 + rc < ds.B) stage_chunk(ds, r0 + rc, (gchunk + 1) & 1);
               else if (t + 1 < nsteps) stage_chunk(dsc[jn], 0, (gchunk + 1) & 1);
               const int nrows = (ds.B - r0 < rc) ? (ds.B - r0) : rc;
-              S += lane_sum_rows<T, LdsPtr<T>, std::decay_t<decltype(ev)>, kPrefetchRows>(
-                  (LdsPtr<T>)(pool + (gchunk & 1) * (kLdsPoolBytes / 2)), nrows, RS, lane, ev);
-              if (use_seg && ++cin == cps) { seg.note(S); cin = 0; }  // the lane's running sum at a segment boundary
+              const auto crows = (LdsPtr<T>)(pool + (gchunk & 1) * (kLdsPoolBytes / 2));
+              if (shared)
+                lane_rows_member<T, LdsPtr<T>, Ev, kPrefetchRows>(crows, nrows, RS, lane, ev, team.first, team.second,
+                                                                  team.stride, team.same, mx, my);
+              else
+                lane_rows_all<T, LdsPtr<T>, Ev, kPrefetchRows>(crows, nrows, RS, lane, ev, acc);
+              // the lane's running sum (a member: its share of it) at a segment boundary
+              if (use_seg && ++cin == cps) { seg.note(shared ? mx + my : acc.total()); cin = 0; }
             }
+            if constexpr (kTeams) {
+              if (shared) {
+                const T S = team_combine(mx + my, lane, team, /*pre_barrier=*/false);
+                if (use_seg)
+                  return __builtin_amdgcn_readfirstlane(select_or_raise_seg_team<T, const T *>(
+                      S, seg, cps * rc, hdr + kTileHeader, ds, lane, ev, u, fb, team));
+                return __builtin_amdgcn_readfirstlane(select_or_raise<T, const T *>(S, hdr + kTileHeader, ds, lane, ev, u, fb));
+              }
+            }
+            const T S = acc.total();
             if (use_seg)
               return __builtin_amdgcn_readfirstlane(
-                  select_or_raise_seg<T, const T *>(S, seg, cps * rc, hdr + kTileHeader, ds, lane, ev, u, plan.levels));
-            return __builtin_amdgcn_readfirstlane(select_or_raise<T, const T *>(S, hdr + kTileHeader, ds, lane, ev, u, plan.levels));
+                  select_or_raise_seg<T, const T *>(S, seg, cps * rc, hdr + kTileHeader, ds, lane, ev, u, fb));
+            return __builtin_amdgcn_readfirstlane(select_or_raise<T, const T *>(S, hdr + kTileHeader, ds, lane, ev, u, fb));
           });
           adopt(jc, ds, hdr, pos);
           ++t;
         });
     } else {  // kStageGlobal
-      for (int p = 0; p < npass; ++p)
-        static_for<M>([&](auto jc) {
-          const LeanTile<D> &ds = dsc[decltype(jc)::value];
-          step(jc, ds, data + ds.hdr_off(), p == 0, x);
-        });
+      if (active)
+        for (int p = 0; p < npass; ++p)
+          static_for<M>([&](auto jc) {
+            const LeanTile<D> &ds = dsc[decltype(jc)::value];
+            step(jc, ds, data + ds.hdr_off(), p == 0, x);
+          });
     }
 
-    if (tabulated) {
+    if (tabulated && active) {
       // ---- tabulated sweeps (see gibbs_kernel.hip "conditional tables"): the labels of all densities packed in
       // one scalar word, one table row load per step, the unchanged selection ----
       TabDesc td[M];
@@ -364,7 +449,7 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan, Ru
           const T total = lane_read(incl, n < 64 ? n : 63);  // (a 64-node row: its last scan value IS the total)
           int pos;
           if (!(total >= Num<T>::tiny_total())) {  // uniform fallback (:311-315), rare
-            count_fallback(plan.levels, lane);
+            count_fallback(fb, lane);
             const LeanTile<D> &dk = dsc[j];
             const T wl = ((LdsPtr<T>)(pool + dk.lds_off) + kTileHeader)[(dk.F - 1) * 64 + (n - 1)];
             int z = n - 1;
@@ -397,7 +482,9 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan, Ru
     if (l == L && live && lane == 0) {  // final labels (:612-616)
       static_for<M>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
-        a.indices[s * M + j] = static_cast<int64_t>(plan.perm[levels[j * (L + 1) + l].perm_off + psel[j]]) + 1;
+        const int64_t label = static_cast<int64_t>(plan.perm[levels[j * (L + 1) + l].perm_off + psel[j]]) + 1;
+        a.indices[s * M + j] = label;
+        for (int k = 0; k < a.npeers; ++k) a.peer_indices[k][s * M + j] = label;  // (multi-GPU: the all-gather)
       });
     }
   }
@@ -407,7 +494,10 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan, Ru
     product(IC<-1>{}, mean, cov);
     T xf = mean;
     if (a.addEntropy) xf = mean + Num<T>::sqrt(cov) * static_cast<T>(sNorm[L * D + dl]);
-    if (live && lane < D) a.points[s * D + lane] = static_cast<double>(xf);
+    if (live && lane < D) {
+      a.points[s * D + lane] = static_cast<double>(xf);
+      for (int k = 0; k < a.npeers; ++k) a.peer_points[k][s * D + lane] = static_cast<double>(xf);
+    }
   }
 }
 
@@ -415,14 +505,25 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan, Ru
 
 template <typename T, int D, int M, int WAVES>
 static void launch_lean_waves(const PlanDev &plan, const RunArgs &args, hipStream_t stream) {
-  const int64_t blocks = (args.Np + WAVES - 1) / WAVES;
+  const int chains = WAVES / (args.team > 1 ? args.team : 1);  // chains per workgroup
+  const int64_t blocks = (args.Np + chains - 1) / chains;
   hipLaunchKernelGGL((gibbs_lean_kernel<T, D, M, WAVES>), dim3(static_cast<unsigned>(blocks)), dim3(WAVES * 64), 0,
                      stream, plan, args);
 }
 
+// wavefronts per workgroup and per chain of this run (RunArgs carries the team part to the kernel)
+static int set_geometry(const PlanDev &plan, RunArgs &args, int precision) {
+  const LeanGeometry g = lean_geometry(args.Np, args.variant, precision, plan);
+  args.team = g.team;
+  args.team_level = g.team_level;
+  args.team_min_rows = g.team_min_rows;
+  return g.waves;
+}
+
 template <typename T, int D, int M>
-static int launch_lean_m(const PlanDev &plan, const RunArgs &args, hipStream_t stream) {
-  const int waves = chains_per_workgroup(args.Np, args.variant);
+static int launch_lean_m(const PlanDev &plan, const RunArgs &args_in, hipStream_t stream) {
+  RunArgs args = args_in;
+  const int waves = set_geometry(plan, args, sizeof(T) == 8 ? 64 : 32);
   if (waves == 16) launch_lean_waves<T, D, M, 16>(plan, args, stream);
   else if (waves == 12) launch_lean_waves<T, D, M, 12>(plan, args, stream);
   else if (waves == 8) launch_lean_waves<T, D, M, 8>(plan, args, stream);
@@ -440,8 +541,9 @@ static int launch_lean_m(const PlanDev &plan, const RunArgs &args, hipStream_t s
 #define KDEHIP_CAT(a, b) KDEHIP_CAT2(a, b)
 
 template <typename T, int D, int M>
-static int launch_lean_m_hi(const PlanDev &plan, const RunArgs &args, hipStream_t stream) {
-  const int waves = chains_per_workgroup(args.Np, args.variant);
+static int launch_lean_m_hi(const PlanDev &plan, const RunArgs &args_in, hipStream_t stream) {
+  RunArgs args = args_in;
+  const int waves = set_geometry(plan, args, sizeof(T) == 8 ? 64 : 32);
   if (waves == 16) launch_lean_waves<T, D, M, 16>(plan, args, stream);
   else if (waves == 8) launch_lean_waves<T, D, M, 8>(plan, args, stream);
   else return kLeanNotCovered;
@@ -481,10 +583,11 @@ int KDEHIP_CAT(KDEHIP_LEAN_ENTRY, KDEHIP_DIM)(int precision, int mode, const Pla
 #else
   using DevT = double;
 #endif
+  RunArgs dargs = args;
   if (f64 != (sizeof(DevT) == 8) || plan.M != KDEHIP_LEAN_DEV_M ||
-      chains_per_workgroup(args.Np, args.variant) != KDEHIP_LEAN_DEV_W)
+      set_geometry(plan, dargs, precision) != KDEHIP_LEAN_DEV_W)
     return kLeanNotCovered;
-  launch_lean_waves<DevT, D, KDEHIP_LEAN_DEV_M, KDEHIP_LEAN_DEV_W>(plan, args, st);
+  launch_lean_waves<DevT, D, KDEHIP_LEAN_DEV_M, KDEHIP_LEAN_DEV_W>(plan, dargs, st);
   return KDEHIP_OK;
 #elif defined(KDEHIP_LEAN_HI)
   if (!f64) return kLeanNotCovered;  // (fp32 products of more than 4 densities run the general kernel: build time)

@@ -85,8 +85,11 @@ struct PlanDev {
   const TabDesc *tabdesc;    // [M][L+1]
   int64_t tab_rows_total;
   int32_t M, L, D, Lt;       // Lt: levels 1..Lt are tabulated (0 = none)
+  int32_t deep_level[2];     // first level with a tile of >= kTeamMinRows[k] rows per lane (0 = none), see lean_geometry
+  float deep_share[2];       // share of a sweep's rows (plus a per-step overhead) that lies on those levels
 };
 
+constexpr int kMaxPeers = 7;  // other GPUs of one node
 struct RunArgs {
   int64_t Np;
   int32_t Niter;
@@ -104,6 +107,18 @@ struct RunArgs {
   double *points;
   int64_t *indices;
   int32_t *labels;
+  // Wavefront teams (gibbs_lean.hip, 16-wavefront fp64 builds): `team` = wavefronts per chain (1, 2 or 4); levels
+  // below `team_level` are walked by the first member alone, from there on a step whose tile has at least
+  // `team_min_rows` rows per lane is shared by the members (gibbs_device.hpp "wavefront teams").
+  int32_t team;
+  int32_t team_level;
+  int32_t team_min_rows;
+  // The all-gather of a multi-GPU product (kdehip_product_multi_*): the kernel stores every final point and label
+  // not only into its own device's arrays but straight into the arrays of the `npeers` other devices as well
+  // (peer-mapped pointers, stores travel over xGMI) -- no copy engines, no extra launches.
+  int32_t npeers;
+  double *peer_points[kMaxPeers];
+  int64_t *peer_indices[kMaxPeers];
 };
 
 // Host result of packing one product (precision-independent description + fp64 payload; the fp32
@@ -182,6 +197,18 @@ int launch_gibbs(int precision, int mode, const PlanDev &plan, const RunArgs &ar
 // the width with the smallest estimated time rounds(width) * cost(width) unless `variant` pins it
 // (kdehip_product_set_variant).  Shared by both sampler kernels.
 int chains_per_workgroup(int64_t Np, int variant);
+// The launch geometry of the register-resident sampler: wavefronts per workgroup and wavefronts per chain (team).
+// Teams exist in the 16-wavefront fp64 builds only; `deep_level[k]` (k = 0: teams of 2, k = 1: teams of 4) is the
+// first level with a tile of at least kTeamMinRows[k] rows per lane, 0 = the product has no such level.
+struct LeanGeometry { int waves; int team; int team_level; int team_min_rows; };
+constexpr int kTeamMinRows[2] = {8, 16};
+// Teams by default when the shared levels carry at least this share of a sweep.  2 = never: measured on MI355X
+// (round 3, DESIGN.md "wavefront teams") a team launch is SLOWER than one wavefront per chain at every BASELINE
+// shape -- 16 wavefronts per CU leave 128 registers per wavefront, and the register-resident kernel then spills in its
+// per-step code (config 4, 2048 chains: 8.3 ms against 4.7 ms) -- so teams stay a plan variant (52 / 54).
+constexpr float kTeamMinShare = 2.0f;
+constexpr int kVariantTeam2 = 52, kVariantTeam4 = 54;  // plan variants: 16 wavefronts per workgroup as 8 x 2 / 4 x 4
+LeanGeometry lean_geometry(int64_t Np, int variant, int precision, const PlanDev &plan);
 
 // Variant codes 30..49 = "gibbs_kernel.hip even where gibbs_lean.hip applies" + (code - 30) as the plain variant.
 constexpr int kVariantGenericBase = 30;

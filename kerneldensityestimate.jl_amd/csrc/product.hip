@@ -143,9 +143,16 @@ int enqueue_streams(kdehip_product *plan, int64_t Np, int Niter, const double *d
   return launch_gibbs(plan->precision, plan->mode, plan->dev, a, stream);
 }
 
+// the other devices' output arrays of a multi-GPU run (kernel epilogue stores, RunArgs.peer_*)
+struct PeerOutputs {
+  int n = 0;
+  double *points[kMaxPeers] = {};
+  int64_t *indices[kMaxPeers] = {};
+};
+
 int enqueue_philox(kdehip_product *plan, int64_t Np, int Niter, uint64_t seed, int64_t sample_offset,
                    int addEntropy, double *d_points, int64_t *d_indices, int32_t *d_labels, void *stream,
-                   bool private_plan = false) {
+                   bool private_plan = false, const PeerOutputs *peers = nullptr) {
   int rc = check_run(plan, Np, Niter, d_points, d_indices);
   if (rc != KDEHIP_OK) return rc;
   if (Np == 0) return KDEHIP_OK;
@@ -163,6 +170,10 @@ int enqueue_philox(kdehip_product *plan, int64_t Np, int Niter, uint64_t seed, i
   a.points = d_points; a.indices = d_indices; a.labels = d_labels;
   rc = maybe_build_tables(plan, Np, a, stream, private_plan);
   if (rc != KDEHIP_OK) return rc;
+  if (peers) {
+    a.npeers = peers->n;
+    for (int k = 0; k < peers->n; ++k) { a.peer_points[k] = peers->points[k]; a.peer_indices[k] = peers->indices[k]; }
+  }
   return launch_gibbs(plan->precision, plan->mode, plan->dev, a, stream);
 }
 
@@ -272,6 +283,27 @@ int instantiate(const PlanImage &im, int device, kdehip_product **out, bool wait
   p->dev.L = p->host.L;
   p->dev.D = p->host.D;
   p->dev.Lt = (p->mode == kModeGeneric) ? 0 : p->host.Lt;
+  // where a wavefront team would start sharing the rows of a step (lean_geometry): the first level with a tile of at
+  // least kTeamMinRows[k] rows per lane -- or a chunked level, whose staging every wavefront walks anyway -- and the
+  // share of a sweep's work (rows + ~4 rows' worth of per-step bookkeeping per tile) that lies from there on
+  for (int k = 0; k < 2; ++k) {
+    const int L = p->host.L, M = p->host.M;
+    int deep = 0;
+    for (int l = 1; l <= L && !deep; ++l)
+      for (int j = 0; j < M; ++j) {
+        const LevelDesc &ds = p->host.levels[static_cast<size_t>(j) * (L + 1) + l];
+        if (ds.B >= kTeamMinRows[k] || ds.stage_mode == kStageChunked) { deep = l; break; }
+      }
+    double all = 0.0, shared = 0.0;
+    for (int l = 1; l <= L; ++l)
+      for (int j = 0; j < M; ++j) {
+        const double w = p->host.levels[static_cast<size_t>(j) * (L + 1) + l].B + 4.0;
+        all += w;
+        if (deep && l >= deep) shared += w;
+      }
+    p->dev.deep_level[k] = deep;
+    p->dev.deep_share[k] = all > 0.0 ? static_cast<float>(shared / all) : 0.0f;
+  }
   *out = p;
   return KDEHIP_OK;
 }
@@ -381,6 +413,23 @@ int kdehip_product_set_variant(kdehip_product *plan, int variant) {
   return KDEHIP_OK;
 }
 
+int kdehip_product_launch_geometry(const kdehip_product *plan, int64_t Np, int32_t *waves_per_workgroup,
+                                   int32_t *waves_per_chain) {
+  if (!plan || !waves_per_workgroup || !waves_per_chain) return set_error(KDEHIP_ERR_ARG, "null argument");
+  DeviceGuard guard;
+  const int rc = guard.enter(plan->device);  // (the width heuristic asks the plan's device for its CU count)
+  if (rc != KDEHIP_OK) return rc;
+  const bool lean = plan->mode == kModeFast && plan->host.M >= 2 && plan->host.M <= 8 &&
+                    (plan->precision == 64 || plan->host.M <= 4);
+  LeanGeometry g{chains_per_workgroup(Np, plan->variant), 1, 0, 0};
+  const int v = plan->variant % 1000;
+  if (lean && !(v >= kVariantGenericBase && v < kVariantGenericBase + 20))
+    g = lean_geometry(Np, plan->variant, plan->precision, plan->dev);
+  *waves_per_workgroup = g.waves;
+  *waves_per_chain = g.team;
+  return KDEHIP_OK;
+}
+
 int kdehip_product_sample_streams(kdehip_product *plan, int64_t Np, int Niter, const double *d_randU,
                                   int64_t nU, const double *d_randN, int64_t nN, int addEntropy,
                                   double *d_points, int64_t *d_indices, int32_t *d_labels,
@@ -465,15 +514,13 @@ int one_shot(int Ndens, const kdehip_density *trees, int64_t Np, int Niter, doub
   const auto t_begin = clk::now();
   auto us_since = [&](clk::time_point t) { return std::chrono::duration<double, std::micro>(clk::now() - t).count(); };
   PlanImage im;
-  // (declared after the image, before the shards: on an early error return the plans go back to the cache first,
-  // then every device touched is drained, and only then is the pinned image recycled)
   struct DrainOnExit {
     std::vector<int> devs;
     ~DrainOnExit() {
       DeviceGuard g;
       for (int d : devs) if (g.enter(d) == KDEHIP_OK) (void)hipStreamSynchronize(nullptr);
     }
-  } drain;
+  };
   rc = build_image(im, Ndens, trees, ndims, partialDimMask, precision);
   if (rc != KDEHIP_OK) return rc;
   const double us_pack = us_since(t_begin);
@@ -495,6 +542,10 @@ int one_shot(int Ndens, const kdehip_density *trees, int64_t Np, int Niter, doub
   const bool trace = labels != nullptr && Niter > 0;
   if (ngpus > Np) ngpus = static_cast<int>(Np);
   std::vector<Shard> sh(ngpus);
+  // Declared AFTER the shards (destroyed before them) and after the image: on an early error return every device
+  // touched is drained first; only then do the shards hand their device blocks and pinned landing zones back to the
+  // caches (another thread may be given them at once), and last of all the pinned image is recycled.
+  DrainOnExit drain;
   DeviceGuard guard;
   // launch everywhere first (uploads and kernels of different devices overlap), then collect
   for (int g = 0; g < ngpus; ++g) {
@@ -592,7 +643,9 @@ int kdehip_prod_philox(int Ndens, const kdehip_density *trees, int64_t Np, int N
 struct kdehip_product_multi {
   int first_device = 0, ngpus = 0;
   std::vector<kdehip_product *> plans;
-  std::vector<hipEvent_t> done;  // per device: its slice has been written to every device
+  std::vector<hipEvent_t> done;   // per device: its slice has been written to every device
+  std::vector<hipEvent_t> ready;  // per device: the work queued on its stream before this call is over (its arrays may be overwritten)
+  bool peer_stores = true;        // every device can store into every other device's memory (else: peer copies)
 };
 
 int kdehip_product_multi_create(kdehip_product_multi **out, int Ndens, const kdehip_density *trees, int ndims,
@@ -608,6 +661,7 @@ int kdehip_product_multi_create(kdehip_product_multi **out, int Ndens, const kde
   if (!mp) return set_error(KDEHIP_ERR_ALLOC, "out of host memory");
   mp->first_device = first_device;
   mp->ngpus = ngpus;
+  if (ngpus - 1 > kMaxPeers) mp->peer_stores = false;  // (more "devices" than a node has: aliased tests)
   DeviceGuard guard;
   for (int g = 0; g < ngpus && rc == KDEHIP_OK; ++g) {
     kdehip_product *p = nullptr;
@@ -616,15 +670,21 @@ int kdehip_product_multi_create(kdehip_product_multi **out, int Ndens, const kde
     mp->plans.push_back(p);
     rc = guard.enter(phys(first_device + g));
     if (rc != KDEHIP_OK) break;
-    hipEvent_t ev;
+    hipEvent_t ev, ev2;
     if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { rc = set_error(KDEHIP_ERR_HIP, "hipEventCreate failed"); break; }
     mp->done.push_back(ev);
-    // direct peer writes over xGMI where the topology allows them (hipMemcpyPeerAsync stages through the host otherwise)
+    if (hipEventCreateWithFlags(&ev2, hipEventDisableTiming) != hipSuccess) { rc = set_error(KDEHIP_ERR_HIP, "hipEventCreate failed"); break; }
+    mp->ready.push_back(ev2);
+    // direct peer stores over xGMI where the topology allows them (else hipMemcpyPeerAsync, staged through the host)
     for (int h = 0; h < ngpus; ++h) {
+      if (phys(first_device + h) == phys(first_device + g)) continue;
       int can = 0;
-      if (phys(first_device + h) != phys(first_device + g) &&
-          hipDeviceCanAccessPeer(&can, phys(first_device + g), phys(first_device + h)) == hipSuccess && can)
-        (void)hipDeviceEnablePeerAccess(phys(first_device + h), 0);  // "already enabled" is fine
+      if (hipDeviceCanAccessPeer(&can, phys(first_device + g), phys(first_device + h)) == hipSuccess && can) {
+        const hipError_t pe = hipDeviceEnablePeerAccess(phys(first_device + h), 0);
+        if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) mp->peer_stores = false;
+      } else {
+        mp->peer_stores = false;
+      }
     }
     (void)hipGetLastError();
   }
@@ -640,6 +700,7 @@ void kdehip_product_multi_destroy(kdehip_product_multi *mp) {
     if (guard.enter(phys(mp->first_device + static_cast<int>(g))) == KDEHIP_OK) {
       (void)hipDeviceSynchronize();
       (void)hipEventDestroy(mp->done[g]);
+      if (g < mp->ready.size()) (void)hipEventDestroy(mp->ready[g]);
     }
   for (kdehip_product *p : mp->plans) kdehip_product_destroy(p);
   delete mp;
@@ -658,39 +719,68 @@ int kdehip_product_multi_sample_philox(kdehip_product_multi *mp, int64_t Np, int
   if (Np == 0) return KDEHIP_OK;
   const int G = mp->ngpus;
   const size_t D = mp->plans[0]->host.D, M = mp->plans[0]->host.M;
+  for (int g = 0; g < G; ++g)
+    if (!d_points[g] || !d_indices[g]) return set_error(KDEHIP_ERR_ARG, "null output pointer");
   DeviceGuard guard;
+  auto stream_of = [&](int g) { return static_cast<hipStream_t>(streams ? streams[g] : nullptr); };
+  // (1) Device g is about to write into EVERY device's arrays: whatever is queued on the other devices' streams --
+  // consumers of the previous product, typically -- must be over first (write after read).
+  if (G > 1) {
+    for (int h = 0; h < G; ++h) {
+      int rc = guard.enter(phys(mp->first_device + h));
+      if (rc != KDEHIP_OK) return rc;
+      KDEHIP_CHECK(hipEventRecord(mp->ready[h], stream_of(h)));
+    }
+  }
+  // (2) One launch per device.  The all-gather of [pGM | indices] is part of the kernel: its epilogue stores each
+  // final point and label into the arrays of all G devices (peer-mapped pointers, xGMI) -- no copies, no extra
+  // launches.  Topologies without peer access fall back to one peer copy per array and destination.
   for (int g = 0; g < G; ++g) {
     const int64_t lo = share_begin(Np, g, G), hi = share_begin(Np, g + 1, G);
-    if (!d_points[g] || !d_indices[g]) return set_error(KDEHIP_ERR_ARG, "null output pointer");
     int rc = guard.enter(phys(mp->first_device + g));
     if (rc != KDEHIP_OK) return rc;
-    hipStream_t st = static_cast<hipStream_t>(streams ? streams[g] : nullptr);
+    hipStream_t st = stream_of(g);
+    for (int h = 0; h < G; ++h)
+      if (h != g) KDEHIP_CHECK(hipStreamWaitEvent(st, mp->ready[h], 0));
     if (hi > lo) {
+      PeerOutputs peers;
+      if (mp->peer_stores)
+        for (int h = 0; h < G; ++h) {
+          if (h == g) continue;
+          peers.points[peers.n] = d_points[h] + lo * D;
+          peers.indices[peers.n] = d_indices[h] + lo * M;
+          ++peers.n;
+        }
       // global sample index = sample_offset + lo + s: the result does not depend on the number of devices
       rc = enqueue_philox(mp->plans[g], hi - lo, Niter, seed, sample_offset + lo, addEntropy, d_points[g] + lo * D,
-                          d_indices[g] + lo * M, nullptr, st);
+                          d_indices[g] + lo * M, nullptr, st, /*private_plan=*/false, &peers);
       if (rc != KDEHIP_OK) return rc;
       mp->plans[g]->async_pending.store(true);
-      // the all-gather of [pGM | indices]: device g writes its slice into every other device's arrays
-      for (int h = 0; h < G; ++h) {
-        if (h == g) continue;
-        KDEHIP_CHECK(hipMemcpyPeerAsync(d_points[h] + lo * D, phys(mp->first_device + h), d_points[g] + lo * D,
-                                        phys(mp->first_device + g), sizeof(double) * D * (hi - lo), st));
-        KDEHIP_CHECK(hipMemcpyPeerAsync(d_indices[h] + lo * M, phys(mp->first_device + h), d_indices[g] + lo * M,
-                                        phys(mp->first_device + g), sizeof(int64_t) * M * (hi - lo), st));
-      }
+      if (!mp->peer_stores)
+        for (int h = 0; h < G; ++h) {
+          if (h == g) continue;
+          KDEHIP_CHECK(hipMemcpyPeerAsync(d_points[h] + lo * D, phys(mp->first_device + h), d_points[g] + lo * D,
+                                          phys(mp->first_device + g), sizeof(double) * D * (hi - lo), st));
+          KDEHIP_CHECK(hipMemcpyPeerAsync(d_indices[h] + lo * M, phys(mp->first_device + h), d_indices[g] + lo * M,
+                                          phys(mp->first_device + g), sizeof(int64_t) * M * (hi - lo), st));
+        }
     }
     KDEHIP_CHECK(hipEventRecord(mp->done[g], st));
   }
-  // every device's stream continues only once all slices have arrived in its arrays
+  // (3) every device's stream continues only once all slices have arrived in its arrays
   for (int h = 0; h < G; ++h) {
     int rc = guard.enter(phys(mp->first_device + h));
     if (rc != KDEHIP_OK) return rc;
-    hipStream_t st = static_cast<hipStream_t>(streams ? streams[h] : nullptr);
+    hipStream_t st = stream_of(h);
     for (int g = 0; g < G; ++g)
       if (g != h) KDEHIP_CHECK(hipStreamWaitEvent(st, mp->done[g], 0));
   }
   return KDEHIP_OK;
+}
+
+int kdehip_product_multi_transfers_per_product(const kdehip_product_multi *mp) {
+  if (!mp) return -1;
+  return mp->peer_stores ? 0 : 2 * (mp->ngpus - 1);
 }
 
 // ---- host twin of the device RNG ------------------------------------------------------------------

@@ -493,12 +493,9 @@ extern "C" int kdehip_make_densities_device(int nb, int64_t D, const int64_t *Ns
   }
   KDEHIP_CHECK(hipMemcpyAsync(d_base, h_base, in_total, hipMemcpyHostToDevice, nullptr));
   const TreeLds L = tree_lds(maxN, static_cast<int>(D));
-  static bool attr_set = false;
-  if (!attr_set) {
-    KDEHIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(tree_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     static_cast<int>(kTreeLdsLimit)));
-    attr_set = true;
-  }
+  // (per call: the attribute belongs to the function ON THE CURRENT DEVICE, and concurrent host threads get here)
+  KDEHIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(tree_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   static_cast<int>(kTreeLdsLimit)));
   hipLaunchKernelGGL(tree_build_kernel, dim3(nb), dim3(kTB), L.total, nullptr, batch, L);
   KDEHIP_CHECK(hipGetLastError());
   KDEHIP_CHECK(hipMemcpyAsync(hb + out_begin, db + out_begin, out_end - out_begin, hipMemcpyDeviceToHost, nullptr));

@@ -9,7 +9,13 @@
 #
 # or, to route every existing caller (`*`, IncrementalInference, ...) through the GPU:
 #
-#   KernelDensityEstimateHIP.enable!()      # overrides KernelDensityEstimate.gibbs1
+#   KernelDensityEstimateHIP.enable!()      # overrides KernelDensityEstimate.prodAppxMSGibbsS and .gibbs1
+#
+# After enable!() a call of the reference's `prodAppxMSGibbsS` WITHOUT `randU=`/`randN=` (what `*` and every
+# JuliaRobotics caller does) no longer draws `rand(Np*Ndens*(Niter+2)*Nlevels)` / `randn(...)` on the host
+# (src/MSGibbs01.jl:661-662; 9.4 MB at 6-D x 4 x 1000, Np = 2048) nor uploads them: it goes to
+# `kdehip_prod_philox`, whose random numbers are drawn on the device.  Calls WITH explicit streams keep the
+# reference's consumption order through the `gibbs1` override.
 #
 # NOTE: Julia is not installed in the build container, so this file has been written against the
 # C ABI but never executed; tests/ exercise the same entry points through the Python mirror.
@@ -53,6 +59,11 @@ end
 const ORIGINAL_GIBBS1 = Ref{Any}(nothing)
 reference_gibbs1(args...; kw...) =
   ORIGINAL_GIBBS1[] === nothing ? KDE.gibbs1(args...; kw...) : ORIGINAL_GIBBS1[](args...; kw...)
+
+# the same for the front end (enable!() overwrites KDE.prodAppxMSGibbsS as well)
+const ORIGINAL_PROD = Ref{Any}(nothing)
+reference_prodAppxMSGibbsS(args...; kw...) =
+  ORIGINAL_PROD[] === nothing ? KDE.prodAppxMSGibbsS(args...; kw...) : ORIGINAL_PROD[](args...; kw...)
 
 isEuclid(addop, diffop, getMu, getLambda) =
   all(f -> f === +, addop) && all(f -> f === -, diffop) &&
@@ -109,35 +120,45 @@ function gibbs1(Ndens::Int, trees::Array{BallTreeDensity,1}, Np::Int, Niter::Int
 end
 
 """
-    prodAppxMSGibbsS(npd0, trees, anFcns, anParams; Niter=3, ..., seed=nothing, device=0)
+    prodAppxMSGibbsS(npd0, trees, anFcns, anParams; Niter=3, ..., seed=nothing, device=0, ngpus=1)
 
-Same keywords and return value as the reference (src/MSGibbs01.jl:645-703).  With `randU`/`randN`
-given they are consumed exactly like the reference consumes them; otherwise the on-device Philox
-stream keyed by `seed` replaces `rand`/`randn`.
+Same keywords and return value as the reference (src/MSGibbs01.jl:645-703), `maxNp` and `Nlevels` included
+(:659-660; they only size the random streams, the engine derives its level count from the trees, :568).
+With `randU`/`randN` given they are consumed exactly like the reference consumes them; otherwise the
+on-device Philox stream keyed by `seed` replaces `rand`/`randn`.
 """
 function prodAppxMSGibbsS(npd0::BallTreeDensity, trees::Array{BallTreeDensity,1}, anFcns, anParams;
                           Niter::Int=3, addop=(+,), diffop=(-,), getMu=(KDE.getEuclidMu,),
                           getLambda=(KDE.getEuclidLambda,), glbs=KDE.makeEmptyGbGlb(), addEntropy::Bool=true,
                           ndims::Integer=maximum(Ndim.(trees)), Ndens=length(trees), Np=Npts(npd0),
+                          maxNp=maximum([Np; Npts.(trees)]),
+                          Nlevels=floor(Int, (log(Float64(maxNp)) / log(2.0)) + 1.0),
                           randU=nothing, randN=nothing,
                           partialDimMask::AbstractVector{<:BitVector}=[ones(Int, ndims) .== 1 for i in 1:length(trees)],
                           seed::Union{Nothing,UInt64}=nothing, device::Int=0, ngpus::Int=1)
-  if !isEuclid(addop, diffop, getMu, getLambda)
-    kw = (randU === nothing) ? NamedTuple() : (randU=randU, randN=randN)
-    return KDE.prodAppxMSGibbsS(npd0, trees, anFcns, anParams; Niter=Niter, addop=addop, diffop=diffop,
-                                getMu=getMu, getLambda=getLambda, glbs=glbs, addEntropy=addEntropy,
-                                ndims=ndims, Ndens=Ndens, Np=Np, partialDimMask=partialDimMask, kw...)
-  end
+  # the reference's own front end and engine, with the streams the reference would have drawn itself
+  reference() = reference_prodAppxMSGibbsS(npd0, trees, anFcns, anParams; Niter=Niter, addop=addop, diffop=diffop,
+                                           getMu=getMu, getLambda=getLambda, glbs=glbs, addEntropy=addEntropy,
+                                           ndims=ndims, Ndens=Ndens, Np=Np, maxNp=maxNp, Nlevels=Nlevels,
+                                           randU=(randU === nothing ? rand(Int(Np * Ndens * (Niter + 2) * Nlevels)) : randU),
+                                           randN=(randN === nothing ? randn(Int(ndims * Np * (Nlevels + 1))) : randN),
+                                           partialDimMask=partialDimMask)
+  isEuclid(addop, diffop, getMu, getLambda) || return reference()
   points = zeros(ndims * Np)
   indices = ones(Int, Ndens, Np)
-  if randU !== nothing || glbs.recordChoosen
-    if randU === nothing   # label traces go through the drop-in: draw the streams from the host twin of the device RNG
+  if randU !== nothing || randN !== nothing || glbs.recordChoosen
+    if randU === nothing || randN === nothing   # (label traces go through the drop-in: streams from the host twin of the device RNG)
       s = seed === nothing ? rand(UInt64) : seed
-      Nlevels = floor(Int, log(Float64(maximum(Npts.(trees)))) / log(2.0) + 1.0)
-      K, R = Ndens * (1 + Nlevels * (Niter + 1)), ndims * (Nlevels + 1)
-      randU, randN = zeros(Np * K), zeros(Np * R)
-      ccall((:kdehip_philox_fill_uniform, libkdehip), Cvoid, (UInt64, Int64, Int64, Int64, Ptr{Float64}), s, 0, Np, K, randU)
-      ccall((:kdehip_philox_fill_normal, libkdehip), Cvoid, (UInt64, Int64, Int64, Int64, Ptr{Float64}), s, 0, Np, R, randN)
+      Ltree = floor(Int, log(Float64(maximum(Npts.(trees)))) / log(2.0) + 1.0)
+      K, R = Ndens * (1 + Ltree * (Niter + 1)), ndims * (Ltree + 1)
+      if randU === nothing
+        randU = zeros(Np * K)
+        ccall((:kdehip_philox_fill_uniform, libkdehip), Cvoid, (UInt64, Int64, Int64, Int64, Ptr{Float64}), s, 0, Np, K, randU)
+      end
+      if randN === nothing
+        randN = zeros(Np * R)
+        ccall((:kdehip_philox_fill_normal, libkdehip), Cvoid, (UInt64, Int64, Int64, Int64, Ptr{Float64}), s, 0, Np, R, randN)
+      end
     end
     gibbs1(Ndens, trees, Np, Niter, points, indices, randU, randN; glbs=glbs, addEntropy=addEntropy,
            ndims=Int(ndims), partialDimMask=partialDimMask, device=device, ngpus=ngpus)
@@ -153,12 +174,15 @@ function prodAppxMSGibbsS(npd0::BallTreeDensity, trees::Array{BallTreeDensity,1}
                 Cint, Ptr{Int32}),
                Ndens, cds, Np, Niter, points, indices, s, addEntropy ? 1 : 0, ndims, mask, 64, device, ngpus, C_NULL)
   end
-  if rc == KDEHIP_ERR_UNSUPPORTED   # beyond the compiled limits: the reference's own front end and engine
-    return KDE.prodAppxMSGibbsS(npd0, trees, anFcns, anParams; Niter=Niter, glbs=glbs, addEntropy=addEntropy,
-                                ndims=ndims, Ndens=Ndens, Np=Np, partialDimMask=partialDimMask)
-  end
+  rc == KDEHIP_ERR_UNSUPPORTED && return reference()   # beyond the compiled limits (nothing has been written yet)
   check(rc)
   return reshape(points, ndims, Np), indices
+end
+
+# the reference's deprecated positional form (src/MSGibbs01.jl:632-643)
+function prodAppxMSGibbsS(npd0::BallTreeDensity, trees::Array{BallTreeDensity,1}, anFcns, anParams, Niter::Int)
+  @warn "prodApproxMSGibbs has new keyword interface, use (..; Niter::Int=5 ) instead"
+  prodAppxMSGibbsS(npd0, trees, anFcns, anParams; Niter=Niter)
 end
 
 """
@@ -199,16 +223,24 @@ end
 """
     enable!()
 
-Route `KernelDensityEstimate.gibbs1` -- and with it `prodAppxMSGibbsS`, `*` and every downstream
-caller -- through libkdehip.so.  (Method overwrite; the Julia fallback stays reachable for
-non-Euclidean manifolds because this module calls the original through `invoke_original`.)
+Route `KernelDensityEstimate.prodAppxMSGibbsS` and `KernelDensityEstimate.gibbs1` -- and with them `*` and every
+downstream caller -- through libkdehip.so (method overwrites).  A product called without `randU`/`randN`
+takes the device-RNG one-shot entry (`kdehip_prod_philox`: no host `rand`/`randn`, no upload of the streams);
+explicit streams are consumed in the reference's order by the `gibbs1` override.  The reference's own methods
+stay reachable for non-Euclidean manifolds and for shapes beyond the compiled limits: they are invoked in the
+world age in which they were defined.
 """
 function enable!()
   devicecount() > 0 || error("libkdehip: no MI355X visible; refusing to enable (no CPU fallback in the library)")
+  ORIGINAL_GIBBS1[] === nothing || return nothing   # already enabled
   orig = KDE.gibbs1
   m = first(methods(orig))
   invoke_original(args...; kw...) = Base.invoke_in_world(m.primary_world, orig, args...; kw...)
+  origprod = KDE.prodAppxMSGibbsS
+  mp = first(mm for mm in methods(origprod) if mm.nargs == 5)   # the keyword method: 4 positional arguments
+  invoke_original_prod(args...; kw...) = Base.invoke_in_world(mp.primary_world, origprod, args...; kw...)
   ORIGINAL_GIBBS1[] = invoke_original
+  ORIGINAL_PROD[] = invoke_original_prod
   @eval KDE function gibbs1(Ndens::Int, trees::Array{BallTreeDensity,1}, Np::Int, Niter::Int,
                             pts::Array{Float64,1}, ind::Array{Int}, randU::Array{Float64,1},
                             randN::Array{Float64,1}; addop=(+,), diffop=(-,), getMu=(getEuclidMu,),
@@ -222,6 +254,21 @@ function enable!()
     return $(invoke_original)(Ndens, trees, Np, Niter, pts, ind, randU, randN; addop=addop, diffop=diffop,
                               getMu=getMu, getLambda=getLambda, glbs=glbs, addEntropy=addEntropy, ndims=ndims,
                               partialDimMask=partialDimMask)
+  end
+  # the front end: the reference's keyword list (src/MSGibbs01.jl:645-664) with `nothing` in place of the eager
+  # rand(...) / randn(...) defaults, so that "no streams given" can be told from "streams given"
+  @eval KDE function prodAppxMSGibbsS(npd0::BallTreeDensity, trees::Array{BallTreeDensity,1}, anFcns, anParams;
+                                      Niter::Int=3, addop=(+,), diffop=(-,), getMu=(getEuclidMu,),
+                                      getLambda=(getEuclidLambda,), glbs=makeEmptyGbGlb(), addEntropy::Bool=true,
+                                      ndims::Integer=maximum(Ndim.(trees)), Ndens=length(trees), Np=Npts(npd0),
+                                      maxNp=maximum([Np; Npts.(trees)]),
+                                      Nlevels=floor(Int, (log(Float64(maxNp)) / log(2.0)) + 1.0),
+                                      randU=nothing, randN=nothing,
+                                      partialDimMask::AbstractVector{<:BitVector}=[ones(Int, ndims) .== 1 for i in 1:length(trees)])
+    return $(prodAppxMSGibbsS)(npd0, trees, anFcns, anParams; Niter=Niter, addop=addop, diffop=diffop, getMu=getMu,
+                               getLambda=getLambda, glbs=glbs, addEntropy=addEntropy, ndims=ndims, Ndens=Ndens,
+                               Np=Np, maxNp=maxNp, Nlevels=Nlevels, randU=randU, randN=randN,
+                               partialDimMask=partialDimMask)
   end
   nothing
 end

@@ -97,6 +97,12 @@ class ProductPlan:
     def set_variant(self, v: int):
         _lib.check(_lib.lib.kdehip_product_set_variant(self._h, int(v)))
 
+    def launch_geometry(self, Np: int) -> dict:
+        """Wavefronts per workgroup and per chain (`team`; 1 = none) a run of Np chains gets under the current variant."""
+        w, t = C.c_int32(0), C.c_int32(0)
+        _lib.check(_lib.lib.kdehip_product_launch_geometry(self._h, int(Np), C.byref(w), C.byref(t)))
+        return {"waves": int(w.value), "team": int(t.value)}
+
     # ---- device-pointer runs (torch tensors or raw addresses) -----------------------------------
     @staticmethod
     def _addr(x):
@@ -139,8 +145,8 @@ class ProductPlan:
 
 class MultiProductPlan:
     """One resident plan per GPU of a node, one process (kdehip_product_multi_*): chains in contiguous ranges, Philox
-    counters keyed by the global sample index, one all-gather of [pGM | indices] by peer writes over xGMI, after which
-    every device holds the complete result."""
+    counters keyed by the global sample index, one all-gather of [pGM | indices] fused into the sampling kernel (peer
+    stores over xGMI), after which every device holds the complete result."""
 
     def __init__(self, trees, partialDimMask=None, precision=64, first_device=0, ngpus=1, ndims=None):
         trees = list(trees)
@@ -169,8 +175,15 @@ class MultiProductPlan:
     def __exit__(self, *exc):
         self.close()
 
+    @property
+    def transfers_per_product(self) -> int:
+        """copy-engine transfers each device issues per product: 0 = the all-gather is fused into the sampling kernel
+        (stores to the peer-mapped arrays of the other devices)"""
+        return int(_lib.lib.kdehip_product_multi_transfers_per_product(self._h))
+
     def sample_philox_device(self, Np, Niter, seed, sample_offset, addEntropy, d_points, d_indices, streams=None):
-        """d_points / d_indices: one device array (torch tensor or address) per GPU; enqueue only."""
+        """d_points / d_indices: one device array (torch tensor or address) per GPU, each holding the COMPLETE result
+        afterwards (the all-gather is part of the run); enqueue only."""
         G = self.ngpus
         P = (C.c_void_p * G)(*[ProductPlan._addr(x) for x in d_points])
         I = (C.c_void_p * G)(*[ProductPlan._addr(x) for x in d_indices])

@@ -33,6 +33,8 @@ for c in range(cases):
     prec = int(rng.choice([64, 32]))
     trees = [kdehip.kde(rng.standard_normal((D, n)) + rng.uniform(-1, 1, size=(D, 1)), rng.uniform(0.1, 0.6, size=D)) for n in Ns]
     ref = kdehip.prodAppxMSGibbsS(None, trees, None, None, Niter=Niter, Np=Np, seed=c, precision=prec)
+    if c == 0:   # the device has been acquired and a product has run: from here on a stall is the library's
+        print("SOAK first GPU call done", file=sys.stderr, flush=True)
     K, R, nU, nN = oracle.rng_sizes(M, D, Np, Niter, Ns)
     randU, randN = rng.random(nU), rng.standard_normal(nN)
     last = f"case {c}: D={D} M={M} Ns={Ns} Np={Np} Niter={Niter} fp{prec}"

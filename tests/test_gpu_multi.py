@@ -122,26 +122,40 @@ for G in (1, 3):
 assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and res[0][2] == res[1][2]
 o = oracle.gibbs1([oracle.OracleDensity(p, silverman_bw(p)) for p in pts], Np, Niter, randU, randN)
 assert np.array_equal(res[1][1], o[1])
-# resident plans on 4 logical devices, a stream each: afterwards EVERY device array holds the complete result
+# resident plans on 2, 3, 4 and 8 logical devices, a stream each: afterwards EVERY device array holds the complete
+# result; the all-gather is fused into the kernel (no copy-engine transfers)
 dev = torch.device("cuda", 0)
-with kdehip.MultiProductPlan(g, first_device=0, ngpus=4) as mp:
-    assert mp.ngpus == 4
-    Ps = [torch.zeros(D * Np, dtype=torch.float64, device=dev) for _ in range(4)]
-    Is = [torch.zeros(M * Np, dtype=torch.int64, device=dev) for _ in range(4)]
-    sts = [torch.cuda.Stream(device=dev) for _ in range(4)]
-    for rep in range(2):
-        mp.sample_philox_device(Np, Niter, seed, 0, True, Ps, Is, [s.cuda_stream for s in sts])
-    for k in range(4):
-        sts[k].synchronize()
-        assert np.array_equal(Ps[k].cpu().numpy().reshape(Np, D).T, one[0]), k
-        assert np.array_equal(Is[k].cpu().numpy().reshape(Np, M).T, one[1]), k
+other = kdehip.prodAppxMSGibbsS(None, g, None, None, Niter=Niter, Np=Np, seed=seed + 1, ngpus=1)
+for G in (2, 3, 4, 8):
+    with kdehip.MultiProductPlan(g, first_device=0, ngpus=G) as mp:
+        assert mp.ngpus == G and mp.transfers_per_product == 0
+        Ps = [torch.zeros(D * Np, dtype=torch.float64, device=dev) for _ in range(G)]
+        Is = [torch.zeros(M * Np, dtype=torch.int64, device=dev) for _ in range(G)]
+        sts = [torch.cuda.Stream(device=dev) for _ in range(G)]
+        for rep in range(2):
+            mp.sample_philox_device(Np, Niter, seed, 0, True, Ps, Is, [s.cuda_stream for s in sts])
+        # Write after read: a consumer of product 1 sits on every stream (held back by a long sleep) when product 2
+        # -- another seed, other numbers -- is enqueued into the SAME arrays; the consumers must still see product 1.
+        kept = []
+        for k in range(G):
+            with torch.cuda.stream(sts[k]):
+                torch.cuda._sleep(20_000_000)   # ~10 ms
+                kept.append((Ps[k].clone(), Is[k].clone()))
+        mp.sample_philox_device(Np, Niter, seed + 1, 0, True, Ps, Is, [s.cuda_stream for s in sts])
+        for k in range(G):
+            sts[k].synchronize()
+            assert np.array_equal(kept[k][0].cpu().numpy().reshape(Np, D).T, one[0]), (G, k, "consumer of product 1")
+            assert np.array_equal(kept[k][1].cpu().numpy().reshape(Np, M).T, one[1]), (G, k, "consumer of product 1")
+            assert np.array_equal(Ps[k].cpu().numpy().reshape(Np, D).T, other[0]), (G, k)
+            assert np.array_equal(Is[k].cpu().numpy().reshape(Np, M).T, other[1]), (G, k)
 print("alias ok")
 '''
 
 
 def test_multi_device_code_paths_with_aliased_devices():
     """KDEHIP_ALIAS_DEVICES=1 lets logical devices wrap around the visible ones: the complete N > 1 paths (slicing,
-    one plan per device, per-device streams, peer-copy all-gather, event waits, per-device result slices) run on one
+    one plan per device, per-device streams, the all-gather fused into the kernel epilogue, event waits in both
+    directions (write-after-read included), per-device result slices) run on one
     GPU and must reproduce the one-device result bit for bit."""
     import os
     import subprocess

@@ -132,3 +132,74 @@ def test_every_ccall_matches_the_header():
         for pos, (jt, ct) in enumerate(zip((x.strip() for x in items), cparams)):
             assert jt in JULIA_TO_C, f"{name}: argument {pos}: unknown Julia type {jt}"
             assert ct in JULIA_TO_C[jt], f"{name}: argument {pos}: Julia passes {jt}, header declares {ct}"
+
+
+# the keyword list of the reference's prodAppxMSGibbsS (src/MSGibbs01.jl:649-663), in its order
+REFERENCE_PROD_KEYWORDS = ["Niter", "addop", "diffop", "getMu", "getLambda", "glbs", "addEntropy", "ndims", "Ndens", "Np",
+                           "maxNp", "Nlevels", "randU", "randN", "partialDimMask"]
+
+
+def _keyword_names(signature):
+    """keyword names of a Julia `function f(a, b; k1=..., k2::T=...)` signature text (after the ';')"""
+    kw = signature.split(";", 1)[1]
+    names, depth, cur = [], 0, ""
+    for ch in kw:
+        if ch in "([{":
+            depth += 1
+        if ch in ")]}":
+            depth -= 1
+        if ch == "," and depth == 0:
+            names.append(cur)
+            cur = ""
+        else:
+            cur += ch
+    names.append(cur)
+    out = []
+    for n in names:
+        m = re.match(r"\s*([A-Za-z_][A-Za-z_0-9]*)", n)
+        if m:
+            out.append(m.group(1))
+    return out
+
+
+def _signatures(code, name):
+    """every `function name(...)` signature in `code` (text between the parentheses)"""
+    sigs = []
+    for m in re.finditer(r"function\s+" + re.escape(name) + r"\(", code):
+        i, depth = m.end(), 1
+        while depth:
+            depth += {"(": 1, ")": -1}.get(code[i], 0)
+            i += 1
+        sigs.append(code[m.end():i - 1])
+    return sigs
+
+
+def test_prodAppxMSGibbsS_keyword_surface_is_the_references():
+    """The shim's front end and the method enable!() installs into KernelDensityEstimate take the reference's keyword
+    list (src/MSGibbs01.jl:645-664) -- `maxNp` and `Nlevels` included -- and the deprecated positional-Niter method
+    (:632-643) exists."""
+    code = strip_code(open(SHIM).read())
+    sigs = _signatures(code, "prodAppxMSGibbsS")
+    kw_sigs = [s for s in sigs if ";" in s]
+    pos_sigs = [s for s in sigs if ";" not in s]
+    assert len(kw_sigs) == 2, "module-level front end + the override installed by enable!()"
+    for s in kw_sigs:
+        names = _keyword_names(s)
+        assert names[:len(REFERENCE_PROD_KEYWORDS)] == REFERENCE_PROD_KEYWORDS, names
+    # the override must not add keywords of its own (a caller of the reference could not have passed them)
+    override = [s for s in kw_sigs if "seed" not in s]
+    assert len(override) == 1 and _keyword_names(override[0]) == REFERENCE_PROD_KEYWORDS
+    assert any(re.search(r"anParams\s*,\s*Niter::Int\s*$", s.strip()) for s in pos_sigs), "positional Niter method"
+
+
+def test_enable_routes_default_rng_callers_to_the_device_rng():
+    """enable!() overrides prodAppxMSGibbsS with `randU=nothing, randN=nothing` defaults (no host rand(...) of
+    Np*Ndens*(Niter+2)*Nlevels doubles, src/MSGibbs01.jl:661-662) and the front end sends that case to
+    kdehip_prod_philox; explicit streams go through the gibbs1 drop-in."""
+    code = strip_code(open(SHIM).read())
+    enable = code[code.index("function enable!()"):]
+    assert "@eval KDE function prodAppxMSGibbsS" in enable and "@eval KDE function gibbs1" in enable
+    override = [s for s in _signatures(enable, "prodAppxMSGibbsS")][0]
+    assert re.search(r"randU\s*=\s*nothing", override) and re.search(r"randN\s*=\s*nothing", override)
+    front = code[code.index("function prodAppxMSGibbsS("):code.index("function enable!()")]
+    assert ":kdehip_prod_philox" in front and "gibbs1(Ndens, trees, Np, Niter, points, indices, randU, randN" in front
