@@ -1,22 +1,27 @@
 #!/usr/bin/env python3
 """bench.py -- Gibbs-product throughput of the HIP path on MI355X (BASELINE.json metric).
 
-A "step" is one `prodAppxMSGibbsS`-equivalent pass: every rank draws its Nout chains of the
-headline workload (BASELINE config 3: 6-D, 4 densities x 1000 points, Nout = 2048 per GPU,
-Niter = 10, fp64) from densities already resident in HBM, then (N > 1) the one all-gather of the
-product samples over RCCL.  Weak scaling: per-GPU work is fixed.
+A "step" is ONE COMPLETE `prodAppxMSGibbsS`-equivalent call (reference src/MSGibbs01.jl:645-703; SURVEY.md 8d: "Nout /
+wall time of one prodAppxMSGibbsS-equivalent call") on the headline workload (BASELINE config 3: 6-D, 4 densities x
+1000 points, Nout = 2048 per GPU, Niter = 10, fp64): the input densities -- the reference's flat BallTreeDensity
+arrays -- are resident in HBM when the clock starts (uploaded once, `kdehip_density_upload`); every step re-lays them
+out into level tiles on the GPU, builds the conditional tables, draws its Nout chains (`kdehip_prod_philox_device`) and,
+with N > 1 ranks, all-gathers the product samples over RCCL.  Nothing is reused between steps but the densities
+themselves; outputs stay in HBM.  Weak scaling: per-GPU work is fixed.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line.  The path is bound by vector-ALU issue, not by memory (the working set, 832 KB at
-config 3, is LDS/L2 resident; PMC-measured HBM traffic is ~10 MB per launch): `roofline` therefore reports the
-algorithmic fp64 (fp32) flops of the kernel evaluations -- E * (6D+4) per sample, E = (Niter+1) * sum_j sum_l
-n_{j,l} -- per second of kernel time (HIP events on the launch stream) against the MI355X vector
-peak, and `traffic` carries the PMC-measured HBM bytes per launch of the committed profile.  SURVEY.md 8(d)'s
-"algorithmic bytes / 8 TB/s" figure is kept as `normalised_hbm` (a throughput normalisation, not a roofline: it
-exceeds 1).  `call_inclusive` times the calls a drop-in user makes (pack + upload + kernel + copy back).
+Rank 0 prints ONE JSON line.  Beside `value` it carries, each measured in the same run: `call_inclusive` = the same
+call with HOST buffers in and out (pack on the host, PCIe both ways: what a drop-in `ccall` from Julia sees; never
+`value`), `resident_plan` = repeated sampling of ONE packed plan (no re-layout, no table build), and `roofline` =
+the sampling kernel alone (HIP events on the launch stream).  The path is bound by vector-ALU issue, not by memory
+(the working set, 832 KB at config 3, is LDS/L2 resident; PMC-measured HBM traffic is ~10 MB per launch): `roofline`
+reports the algorithmic fp64 (fp32) flops of the kernel evaluations -- E * (6D+4) per sample, E = (Niter+1) * sum_j
+sum_l n_{j,l} -- per second of kernel time against the MI355X vector peak, and `traffic` carries the
+PMC-measured HBM bytes per launch of the committed profile.  SURVEY.md 8(d)'s "algorithmic bytes / 8 TB/s" figure is
+kept as `normalised_hbm` (a throughput normalisation, not a roofline: it exceeds 1).
 --strong splits the configuration's TOTAL chain count over the ranks instead of giving every rank a full batch.
 """
 import argparse
@@ -156,42 +161,45 @@ def main():
     sp = ShardedProduct(plan, dev)
     seed = 20260101
 
-    def step(i):  # warm-up: both buffer slots of the pipelined timed loop get their first kernel and gather here
-        return sp.sample_async(Np_total, Niter=Niter, seed=seed, sample_base=i * Np_total, slot=i & 1).result()
-
-    for i in range(args.warmup):
-        step(i)
-    torch.cuda.synchronize()
-
-    # kernel-only duration: HIP events on the launch stream around the kernel of each timed step
+    # the densities live in HBM from here on (the timed region starts with resident inputs)
+    dd = [kdehip.DeviceDensity(t, device=dev_index) for t in trees]
     stream = torch.cuda.current_stream(dev)
     lo, hi = (Np_total * rank) // world, (Np_total * (rank + 1)) // world
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    # two buffer slots: the all-gather of step i (asynchronous collective on RCCL's stream) overlaps the kernel
-    # of step i+1; a slot is written again only after its previous gather has been waited for
+    # two buffer slots: the all-gather of step i (asynchronous collective on RCCL's stream) overlaps the work of step
+    # i+1; a slot is written again only after its previous gather has been waited for
     slots = [sp._buffers(Np_total, 0), sp._buffers(Np_total, 1)]
+
+    def one_call(i):
+        """ONE prodAppxMSGibbsS-equivalent call: tiles packed on the GPU from the resident densities + conditional
+        tables + sampling of this rank's chains; then (N > 1) the single all-gather of [pGM | labels]."""
+        bufs = slots[i & 1]
+        if bufs["pending"] is not None:
+            bufs["pending"].wait()
+            bufs["pending"] = None
+        if hi > lo:
+            kdehip.prodAppxMSGibbsS_device(dd, bufs["pts"], bufs["ind"], Np=hi - lo, Niter=Niter, seed=seed,
+                                           sample_offset=i * Np_total + lo, precision=prec, stream=stream.cuda_stream)
+        if use_dist:
+            bufs["pending"] = sp.gather(bufs, async_op=True)
+
+    def drain():
+        for bufs in slots:  # every product is complete (gathered) before the clock stops
+            if bufs["pending"] is not None:
+                bufs["pending"].wait()
+                bufs["pending"] = None
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        one_call(i)
+    drain()
 
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        base = (args.warmup + i) * Np_total
-        bufs = slots[i & 1]
-        if bufs["pending"] is not None:
-            bufs["pending"].wait()
-            bufs["pending"] = None
-        ev[i][0].record(stream)
-        plan.sample_philox_device(hi - lo, Niter, seed, base + lo, True, bufs["pts"], bufs["ind"], None,
-                                  stream.cuda_stream)
-        ev[i][1].record(stream)
-        if use_dist:
-            bufs["pending"] = sp.gather(bufs, async_op=True)  # the single all-gather of [pGM | labels]
-    for bufs in slots:  # every product of the timed region is complete (gathered) before the clock stops
-        if bufs["pending"] is not None:
-            bufs["pending"].wait()
-            bufs["pending"] = None
-    torch.cuda.synchronize()
+        one_call(args.warmup + i)
+    drain()
     if use_dist:
         dist.barrier()
     t1 = time.perf_counter()
@@ -200,6 +208,21 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # ---- outside the timed region: the sampling kernel alone, on ONE resident plan (HIP events on the launch stream) ----
+    nk = max(5, min(args.steps, 100))
+    for i in range(3):
+        plan.sample_philox_device(hi - lo, Niter, seed, lo, True, slots[0]["pts"], slots[0]["ind"], None, stream.cuda_stream)
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nk)]
+    tr0 = time.perf_counter()
+    for i in range(nk):
+        ev[i][0].record(stream)
+        plan.sample_philox_device(hi - lo, Niter, seed, (i + 1) * Np_total + lo, True, slots[0]["pts"], slots[0]["ind"], None,
+                                  stream.cuda_stream)
+        ev[i][1].record(stream)
+    torch.cuda.synchronize()
+    resident_ms = (time.perf_counter() - tr0) / nk * 1e3
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     if use_dist:
         t = torch.tensor([kern_ms], dtype=torch.float64, device=dev)
@@ -240,6 +263,8 @@ def main():
             "dtype": "f64" if prec == 64 else "f32",
             "data": "synthetic",
             "julia": "present" if shutil.which("julia") else "absent",
+            "value_is": "one complete prodAppxMSGibbsS-equivalent call per step, input densities resident in HBM: tiles packed "
+                        "on the GPU + conditional tables + sampling (+ all-gather); outputs left in HBM",
             "config": {"workload": workload, "ndims": D, "ndens": M, "npts": N, "nout_per_gpu": Nout,
                        "nout_total": Np_total, "niter": Niter, "rng": "device philox4x32-10",
                        "evals_per_sample": E, "bytes_per_eval": B, "flops_per_eval": flops_per_eval,
@@ -261,10 +286,13 @@ def main():
                                "ratio": alg_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                "algorithmic_bytes_per_launch": alg_bytes},
             "kernel_samples_per_sec": (hi - lo) / (kern_ms * 1e-3),
+            "resident_plan": {"ms_per_launch": resident_ms, "samples_per_sec": (hi - lo) / (resident_ms * 1e-3),
+                              "what": "repeated sampling of ONE packed plan: no re-layout, no table build (round-1/2 headline)"},
             "fast_math_path": plan.fast_math_path,
         }
         if world == 1:
             out["call_inclusive"] = call_inclusive(kdehip, trees, plan, D, M, Nout, Niter, seed, prec)
+            out["cold_start"] = cold_start(args.config)
         if world == 1 and not args.no_cpu_baseline:
             out.update(cpu_baseline_and_parity(kdehip, plan, pts_all, bw_all, D, M, N, Nout, Niter, seed, args.warmup))
     if use_dist:
@@ -357,6 +385,42 @@ def call_inclusive(kdehip, trees, plan, D, M, Nout, Niter, seed, prec):
             "what": "prodAppxMSGibbsS, device Philox: pack + H2D + kernel + D2H, host buffers in and out (median of 15)",
             "gibbs1_caller_streams_ms": t_g1, "randU_MB_over_pcie": randU.nbytes / 1e6,
             "resident_plan_run_plus_d2h_ms": t_res}
+
+
+_COLD_CHILD = r"""
+import json, sys, time
+t0 = time.perf_counter()
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+import kdehip                      # dlopen of libkdehip.so (+ the HIP runtime)
+t_load = time.perf_counter()
+import bench
+D, M, N, Nout, Niter, prec, cid = bench.CONFIGS[sys.argv[2]]
+pts, bws = bench.synth_inputs(kdehip, D, M, N, cid)
+trees = [kdehip.kde(p, b) for p, b in zip(pts, bws)]
+t1 = time.perf_counter()
+kdehip.prodAppxMSGibbsS(None, trees, None, None, Niter=Niter, Np=Nout, seed=1, precision=prec)   # device init, code objects, first launch
+t2 = time.perf_counter()
+kdehip.prodAppxMSGibbsS(None, trees, None, None, Niter=Niter, Np=Nout, seed=2, precision=prec)
+t3 = time.perf_counter()
+import os
+so = os.path.getsize(kdehip.LIB_PATH)
+print(json.dumps({"library_load_ms": (t_load - t0) * 1e3, "first_call_ms": (t2 - t1) * 1e3, "second_call_ms": (t3 - t2) * 1e3,
+                  "cold_start_ms": (t_load - t0 + t2 - t1) * 1e3, "libkdehip_bytes": so}))
+"""
+
+
+def cold_start(config):
+    """What a fresh process pays before its first product is back: load of libkdehip.so (ctypes dlopen,
+    no torch) + the first `prodAppxMSGibbsS` one-shot call (device initialisation, unpacking and loading the code objects,
+    first launch), against the second call of the same process.  Run in a child process; None if it fails."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, "-c", _COLD_CHILD, ROOT, config], capture_output=True, text=True, timeout=300)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        return json.loads(line[-1]) if line else None
+    except Exception:  # noqa: BLE001  (diagnostic extra: never fails the bench)
+        return None
 
 
 def cpu_baseline_and_parity(kdehip, plan, pts_all, bw_all, D, M, N, Nout, Niter, seed, warmup):

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define KDEHIP_VERSION 200 /* 0.2.0 */
+#define KDEHIP_VERSION 300 /* 0.3.0 */
 
 enum {
   KDEHIP_OK = 0,
@@ -156,7 +156,7 @@ int kdehip_product_sample_philox_host(kdehip_product *plan, int64_t Np, int Nite
 int64_t kdehip_product_fallback_count(kdehip_product *plan);
 /* Scheduling knob for experiments/benchmarks; results never depend on it.  0 = library default,
  * 1 = read every tile from global memory (no LDS staging), 4 = no conditional tables,
- * 2 / 8 / 12 / 16 = 4 / 8 / 12 / 16 chains per workgroup, one wavefront per chain; 52 / 54 = workgroups of 16
+ * 2 / 8 / 16 = 4 / 8 / 16 chains per workgroup, one wavefront per chain; 52 / 54 = workgroups of 16
  * wavefronts as 8 chains x 2 / 4 chains x 4 wavefronts (a TEAM of wavefronts shares the rows of a chain's deep
  * levels; fp64 products of 2..8 densities).  Default: chosen from the number of chains and the depth of the trees. */
 int kdehip_product_set_variant(kdehip_product *plan, int variant);
@@ -188,6 +188,28 @@ int kdehip_product_multi_sample_philox(kdehip_product_multi *mp, int64_t Np, int
                                        int64_t *const *d_indices, void *const *streams);
 /* copy-engine transfers each device issues per product: 0 when the all-gather is fused into the kernel */
 int kdehip_product_multi_transfers_per_product(const kdehip_product_multi *mp);
+
+/* ---- (2c) densities that live in HBM, and products of them ------------------------------------------------
+ * The reference hands gibbs1 host arrays (src/MSGibbs01.jl:527-537) and sections (1) and (2) do the same.  A caller
+ * whose densities stay on the device between products -- the inputs of the next product are the outputs of the
+ * previous ones -- uploads each BallTreeDensity ONCE (its means, bandwidth, weights, permutation and the frontier of
+ * every level, expanded from its child arrays at upload; src/BallTreeDensity01.jl:11-24, src/MSGibbs01.jl:500-523)
+ * and then runs prodAppxMSGibbsS (src/MSGibbs01.jl:645-703) on handles: the per-product re-layout into tiles is a
+ * gather kernel on the GPU, only a few KB of descriptors cross PCIe, nothing comes back.  Same results as
+ * kdehip_prod_philox, bit for bit (same layout, same kernels, same Philox stream). */
+typedef struct kdehip_device_density kdehip_device_density;
+int kdehip_density_upload(kdehip_device_density **out, const kdehip_density *host, int device);
+void kdehip_density_free(kdehip_device_density *d); /* waits for the device first */
+int64_t kdehip_density_npts(const kdehip_device_density *d);
+int kdehip_density_ndim(const kdehip_device_density *d);
+/* prodAppxMSGibbsS on device-resident densities, enqueue only: pack (GPU) + conditional tables + sampling on `stream`
+ * (hipStream_t, NULL = default stream).  d_points (double[ndims*Np]), d_indices (int64[Ndens*Np]) and the optional
+ * d_labels (as kdehip_product_sample_philox) are device pointers on the densities' device.  Random numbers: the
+ * device Philox stream keyed by (seed, sample_offset + s, draw).  The plan built for the call is released by a later
+ * call (or kdehip_clear_cache) once its work has run; at most 8 such calls are in flight per device. */
+int kdehip_prod_philox_device(int Ndens, kdehip_device_density *const *trees, int64_t Np, int Niter, uint64_t seed,
+                              int64_t sample_offset, int addEntropy, const uint8_t *partialDimMask, int precision,
+                              double *d_points, int64_t *d_indices, int32_t *d_labels, void *stream);
 
 /* ---- (3) host twin of the device RNG ----------------------------------------------------------
  * Fills the arrays a caller would pass as randU / randN so that a streams-run (or the Julia

@@ -78,6 +78,12 @@ SIGNATURES = {
                                                     C.c_int, f64p, i64p, i32p]),
     "kdehip_product_set_variant": (C.c_int, [C.c_void_p, C.c_int]),
     "kdehip_product_launch_geometry": (C.c_int, [C.c_void_p, C.c_int64, i32p, i32p]),
+    "kdehip_density_upload": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(CDensity), C.c_int]),
+    "kdehip_density_free": (None, [C.c_void_p]),
+    "kdehip_density_npts": (C.c_int64, [C.c_void_p]),
+    "kdehip_density_ndim": (C.c_int, [C.c_void_p]),
+    "kdehip_prod_philox_device": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.c_int64, C.c_int, C.c_uint64, C.c_int64,
+                                            C.c_int, u8p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "kdehip_philox_fill_uniform": (None, [C.c_uint64, C.c_int64, C.c_int64, C.c_int64, f64p]),
     "kdehip_philox_fill_normal": (None, [C.c_uint64, C.c_int64, C.c_int64, C.c_int64, f64p]),
     "kdehip_evaluate": (C.c_int, [C.POINTER(CDensity), f64p, C.c_int64, C.c_int, f64p, C.c_int]),

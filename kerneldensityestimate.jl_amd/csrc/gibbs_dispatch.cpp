@@ -25,14 +25,16 @@ int chains_per_workgroup(int64_t Np, int variant) {
   // round are measured ones (config 3: 0.59, 0.79, 1.10, 1.37 ms for 4, 8, 12, 16 chains per workgroup) and
   // differ little between shapes
   const int v = variant % 1000;
-  if (v == 8 || v == 12 || v == 16) return v;
+  if (v == 8 || v == 16) return v;
   if (v == 2) return 4;
-  static const int kWidth[4] = {4, 8, 12, 16};
-  static const double kCost[4] = {1.0, 1.34, 1.86, 2.31};
+  // (12 chains per workgroup, cost 1.86, was dropped in round 3: it won only between 2048 and 3072 chains, by 20 %,
+  // and cost a quarter of the library's kernels)
+  static const int kWidth[3] = {4, 8, 16};
+  static const double kCost[3] = {1.0, 1.34, 2.31};
   const int64_t cus = device_cu_count();
   int waves = 16;
   double best = 0.0;
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < 3; ++i) {
     const int64_t wgs = (Np + kWidth[i] - 1) / kWidth[i];
     const double t = static_cast<double>((wgs + cus - 1) / cus) * kCost[i];
     if (i == 0 || t < best) { best = t; waves = kWidth[i]; }
@@ -81,7 +83,7 @@ int launch_gibbs(int precision, int mode, const PlanDev &plan, const RunArgs &ar
   const int v = args.variant % 1000;
   const bool generic_only = (v >= kVariantGenericBase && v < kVariantGenericBase + 20);
   if (generic_only) args.variant -= kVariantGenericBase;
-  if (!generic_only && plan.M > 4) {  // 5..8 densities at 8 or 16 chains per workgroup: the same kernel, second set
+  if (!generic_only && plan.M == 8 && precision == 64) {  // 8 densities, fp64 (BASELINE config 4): its own translation unit
     int rc = kLeanNotCovered;
     switch (plan.D) {
       case 1: rc = launch_lean_hi_d1(precision, mode, plan, args, stream); break;
@@ -95,7 +97,7 @@ int launch_gibbs(int precision, int mode, const PlanDev &plan, const RunArgs &ar
       default: break;
     }
     if (rc != kLeanNotCovered) return rc;
-  } else if (!generic_only) {  // products of 2..4 densities, all dimensions active: the register-resident kernel
+  } else if (!generic_only && plan.M <= 4) {  // products of 2..4 densities, all dimensions active: the register-resident kernel  // products of 2..4 densities, all dimensions active: the register-resident kernel
     int rc = kLeanNotCovered;
     const bool f32 = (precision == 32);
     switch (plan.D) {

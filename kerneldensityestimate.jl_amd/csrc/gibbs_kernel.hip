@@ -537,7 +537,6 @@ static int launch_one(const PlanDev &plan, const RunArgs &args, hipStream_t stre
   if (args.Np <= 0) return KDEHIP_OK;
   const int waves = chains_per_workgroup(args.Np, args.variant);
   if (waves == 16) launch_waves<T, D, MODE, 16>(plan, args, stream);
-  else if (waves == 12) launch_waves<T, D, MODE, 12>(plan, args, stream);
   else if (waves == 8) launch_waves<T, D, MODE, 8>(plan, args, stream);
   else launch_waves<T, D, MODE, 4>(plan, args, stream);
   const hipError_t e = hipGetLastError();

@@ -32,8 +32,11 @@ __device__ __forceinline__ void static_for(F &&f) {
 // Three translation units per dimension count (build time: the kernel is instantiated per density count, precision
 // and width, and the units compile in parallel): fp64 products of 2..4 densities at every workgroup width, the same
 // in fp32 (-DKDEHIP_LEAN_F32), and fp64 products of 5..8 densities at 8 and 16 chains per workgroup (-DKDEHIP_LEAN_HI).
+// (Products of 5, 6 and 7 densities run the general kernel since round 3: their instantiations were a third of the
+// library's build time; a run-time density count inside a capacity-8 kernel was tried instead and made the register
+// allocator spill -- config 4, 2048 chains: 4.74 -> 6.28 ms -- so the density count stays a compile-time constant.)
 #if defined(KDEHIP_LEAN_HI) || (defined(KDEHIP_LEAN_DEV_M) && KDEHIP_LEAN_DEV_M > 4)
-constexpr int kLeanMinDens = 5, kLeanMaxDens = 8;
+constexpr int kLeanMinDens = 8, kLeanMaxDens = 8;
 #else
 constexpr int kLeanMinDens = 2, kLeanMaxDens = 4;
 #endif
@@ -525,7 +528,6 @@ static int launch_lean_m(const PlanDev &plan, const RunArgs &args_in, hipStream_
   RunArgs args = args_in;
   const int waves = set_geometry(plan, args, sizeof(T) == 8 ? 64 : 32);
   if (waves == 16) launch_lean_waves<T, D, M, 16>(plan, args, stream);
-  else if (waves == 12) launch_lean_waves<T, D, M, 12>(plan, args, stream);
   else if (waves == 8) launch_lean_waves<T, D, M, 8>(plan, args, stream);
   else launch_lean_waves<T, D, M, 4>(plan, args, stream);
   const hipError_t e = hipGetLastError();
@@ -591,12 +593,7 @@ int KDEHIP_CAT(KDEHIP_LEAN_ENTRY, KDEHIP_DIM)(int precision, int mode, const Pla
   return KDEHIP_OK;
 #elif defined(KDEHIP_LEAN_HI)
   if (!f64) return kLeanNotCovered;  // (fp32 products of more than 4 densities run the general kernel: build time)
-  switch (plan.M) {
-    case 5: return launch_lean_m_hi<double, D, 5>(plan, args, st);
-    case 6: return launch_lean_m_hi<double, D, 6>(plan, args, st);
-    case 7: return launch_lean_m_hi<double, D, 7>(plan, args, st);
-    default: return launch_lean_m_hi<double, D, 8>(plan, args, st);
-  }
+  return launch_lean_m_hi<double, D, 8>(plan, args, st);
 #elif defined(KDEHIP_LEAN_F32)
   if (f64) return kLeanNotCovered;
   switch (plan.M) {

@@ -34,29 +34,6 @@ using namespace kdehip;
 
 namespace kdehip {
 
-// One tile of the plan image as the gather kernel sees it (device copy of what pack_layout_shapes decided).
-struct FillJob {
-  int64_t hdr_off;    // element offset of the tile header in the plan's data
-  int64_t perm_off;   // offset of its permutation row
-  int64_t front_off;  // offset of the frontier's node ids in the density's `front` array
-  int32_t n, B, F, uniform;
-  int32_t dens;       // which density
-  int32_t pad_;
-};
-static_assert(sizeof(FillJob) == 48, "FillJob layout");
-
-struct FillArgs {
-  const double *means[KDEHIP_MAX_DENS];
-  const double *bandwidth[KDEHIP_MAX_DENS];
-  const double *weights[KDEHIP_MAX_DENS];
-  const int64_t *perm[KDEHIP_MAX_DENS];
-  const int32_t *front[KDEHIP_MAX_DENS];
-  const FillJob *jobs;
-  void *data;       // T[...]
-  int32_t *perm_out;
-  int32_t D;
-};
-
 // One wavefront per (tile, row): lane ln writes entry z = ln*B + row of the frontier (kdehip_internal.hpp "packed
 // per-level layout"), field by field -- 64 contiguous elements per store -- from the density's arrays in HBM.
 template <typename T>
@@ -85,7 +62,8 @@ __global__ __launch_bounds__(64) void fill_tiles_kernel(FillArgs a) {
   a.perm_out[job.perm_off + static_cast<int64_t>(row) * 64 + lane] = src >= 0 ? static_cast<int32_t>(a.perm[j][src]) : 0;
 }
 
-int launch_fill_tiles(int precision, const FillArgs &a, int ntiles, int maxB, hipStream_t stream) {
+int launch_fill_tiles(int precision, const FillArgs &a, int ntiles, int maxB, void *stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
   const dim3 grid(static_cast<unsigned>(maxB), static_cast<unsigned>(ntiles));
   if (precision == 64) hipLaunchKernelGGL(fill_tiles_kernel<double>, grid, dim3(64), 0, stream, a);
   else hipLaunchKernelGGL(fill_tiles_kernel<float>, grid, dim3(64), 0, stream, a);

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstring>
 
+#include "device_density.hpp"
 #include "kdehip_internal.hpp"
 
 namespace kdehip {
@@ -26,7 +27,6 @@ int nlevels_for(int64_t maxNp) {
   return static_cast<int>(std::floor(std::log(static_cast<double>(maxNp)) / std::log(2.0) + 1.0));
 }
 
-namespace {
 // The product/rsqrt form multiplies up to D variances c_d in [bw_lo, 2*bw_hi] (bandwidth plus a
 // leave-one-out product variance that is never larger than the largest bandwidth).  It is used
 // only when no partial product can leave the comfortable range of T; otherwise the per-dimension
@@ -40,7 +40,78 @@ bool variances_in_range(const double *bw_lo, const double *bw_hi, int D, int pre
   }
   return (precision == 64) ? (up < 1e120 && dn > 1e-120) : (up < 1e15 && dn > 1e-15);
 }
-}  // namespace
+
+// The frontiers of one density, levels 0..L (levelInit! / levelDown!, src/MSGibbs01.jl:467-475, 503-511), and with
+// `look` every node examined ONCE, at the level where it enters the frontier (a leaf re-enters the next frontier as its
+// own left child: not new): finiteness and the bandwidth range of the arithmetic-form decision.
+int expand_frontiers(const kdehip_density &t, int D, int L, bool look, Frontiers &out) {
+  const int64_t N = t.npts;
+  out.ids.clear();
+  out.ids.reserve(static_cast<size_t>(N) * (L + 1) / 2 + 64);
+  out.off.assign(static_cast<size_t>(L) + 2, 0);
+  out.uniform.assign(static_cast<size_t>(L) + 1, 1);
+  out.bad = false;
+  out.nodes = 0;
+  for (int d = 0; d < KDEHIP_MAX_DIMS; ++d) { out.lo[d] = INFINITY; out.hi[d] = 0.0; }
+  bool bad = false;
+  double lo[KDEHIP_MAX_DIMS], hi[KDEHIP_MAX_DIMS];
+  for (int d = 0; d < KDEHIP_MAX_DIMS; ++d) { lo[d] = INFINITY; hi[d] = 0.0; }
+  auto look_at = [&](int64_t node) {  // (branch-free: minima / maxima / one sticky flag in locals)
+    const double *mu = t.means + (node - 1) * D, *v = t.bandwidth + (node - 1) * D;
+    for (int d = 0; d < D; ++d) {
+      // (means beyond 1e100 would overflow the squared distances of the product/rsqrt forms)
+      bad |= !(std::fabs(mu[d]) < 1e100) | !(v[d] > 0.0) | !(v[d] < INFINITY);
+      lo[d] = v[d] < lo[d] ? v[d] : lo[d];
+      hi[d] = v[d] > hi[d] ? v[d] : hi[d];
+    }
+    const double w = t.weights[node - 1];
+    bad |= !(w >= 0.0) | !(w < INFINITY);
+  };
+  for (int l = 0; l <= L; ++l) {
+    const size_t begin = out.ids.size();
+    out.off[l] = static_cast<int64_t>(begin);
+    if (l == 0) {
+      out.ids.push_back(1);  // levelInit!: frontier = {root()}
+      if (look) look_at(1);
+    } else {
+      const size_t pb = static_cast<size_t>(out.off[l - 1]), pe = begin;
+      out.ids.resize(begin + 2 * (pe - pb));  // (at most two children per node; trimmed below)
+      int32_t *dst = out.ids.data() + begin;
+      const int32_t *src = out.ids.data() + pb;
+      size_t cnt = 0;
+      for (size_t z = 0; z < pe - pb; ++z) {
+        const int64_t node = src[z];
+        const int64_t a = t.left_child[node - 1], b = t.right_child[node - 1];
+        if (a > 0 && a <= 2 * N) {  // validIndex, BallTree01.jl:83
+          dst[cnt++] = static_cast<int32_t>(a);
+          if (a != node && look) look_at(a);
+        }
+        if (b > 0 && b <= 2 * N) {
+          dst[cnt++] = static_cast<int32_t>(b);
+          if (b != node && look) look_at(b);
+        }
+      }
+      out.ids.resize(begin + cnt);
+      const int64_t n = static_cast<int64_t>(cnt);
+      if (n == 0 || n > N) return set_error(KDEHIP_ERR_ARG, "malformed tree: frontier empty or larger than Npts");
+      out.nodes += n;
+    }
+    // one bandwidth vector shared by the whole frontier?  (stops at the first node that differs: frontiers with
+    // internal nodes are decided after a node or two, only the all-leaf frontiers are scanned in full)
+    const double *bw0 = t.bandwidth + (static_cast<int64_t>(out.ids[begin]) - 1) * D;
+    bool uni = true;
+    for (size_t z = begin + 1; z < out.ids.size() && uni; ++z) {
+      const double *v = t.bandwidth + (static_cast<int64_t>(out.ids[z]) - 1) * D;
+      for (int d = 0; d < D; ++d)
+        if (v[d] != bw0[d]) uni = false;
+    }
+    out.uniform[l] = uni ? 1 : 0;
+  }
+  out.off[static_cast<size_t>(L) + 1] = static_cast<int64_t>(out.ids.size());
+  out.bad = bad;
+  for (int d = 0; d < D; ++d) { out.lo[d] = lo[d]; out.hi[d] = hi[d]; }
+  return KDEHIP_OK;
+}
 
 // mode: kPackChecked looks at every node first (finiteness, bandwidth range) and decides between the fast and the
 // generic arithmetic form; kPackOptimistic assumes the fast form and leaves those checks to pack_fill, which reads
@@ -67,11 +138,58 @@ int pack_layout(int Ndens, const kdehip_density *trees, int ndims, const uint8_t
   const int D = ndims, M = Ndens;
   const int L = nlevels_for(maxN);
   out = PackedProduct();
+  out.front_off.assign(static_cast<size_t>(M) * (L + 1) + 1, 0);
+
+  // ---- phase 1: expand every frontier (levelDown!, src/MSGibbs01.jl:503-511) into one flat id array, and (checked
+  // mode) look at every frontier node once: finiteness, bandwidth range; whether a level shares one bandwidth vector
+  double bw_lo[KDEHIP_MAX_DIMS], bw_hi[KDEHIP_MAX_DIMS];
+  for (int d = 0; d < D; ++d) { bw_lo[d] = INFINITY; bw_hi[d] = 0.0; }
+  bool finite_ok = true;
+  std::vector<TileShape> shapes(static_cast<size_t>(M) * (L + 1));
+  out.front.clear();
+  int64_t nodes = 0;
+  Frontiers fr;
+  for (int j = 0; j < M; ++j) {
+    const int rc = expand_frontiers(trees[j], D, L, pmode == kPackChecked, fr);
+    if (rc != KDEHIP_OK) return rc;
+    const int64_t base = static_cast<int64_t>(out.front.size());
+    out.front.insert(out.front.end(), fr.ids.begin(), fr.ids.end());
+    for (int l = 0; l <= L; ++l) {
+      const size_t idx = static_cast<size_t>(j) * (L + 1) + l;
+      out.front_off[idx] = base + fr.off[l];
+      shapes[idx].n = fr.off[l + 1] - fr.off[l];
+      shapes[idx].uniform = fr.uniform[l] != 0;
+    }
+    nodes += fr.nodes;
+    if (fr.bad) finite_ok = false;
+    for (int d = 0; d < D; ++d) {
+      if (fr.lo[d] < bw_lo[d]) bw_lo[d] = fr.lo[d];
+      if (fr.hi[d] > bw_hi[d]) bw_hi[d] = fr.hi[d];
+    }
+  }
+  out.front_off.back() = static_cast<int64_t>(out.front.size());
+  const bool in_range = (pmode == kPackChecked) ? variances_in_range(bw_lo, bw_hi, D, precision) : true;
+  if (pmode == kPackGeneric) finite_ok = false;
+  const std::vector<int64_t> front_off = out.front_off;
+  std::vector<int32_t> front;
+  front.swap(out.front);
+  const int rc = pack_layout_shapes(M, D, L, shapes.data(), mask, precision, finite_ok && in_range, out);
+  out.front.swap(front);
+  out.front_off = front_off;
+  out.nodes_per_sweep = nodes;
+  return rc;
+}
+
+// Tile geometry, staging modes and conditional tables of a product from the shapes of its frontiers alone
+// (`shapes[j * (L+1) + l]`): what the host packer derives from the trees, and all the device packer needs
+// (pack_device.hip: the frontiers of a density in HBM were expanded when it was uploaded).
+int pack_layout_shapes(int M, int D, int L, const TileShape *shapes, const uint8_t *mask, int precision, bool fast,
+                       PackedProduct &out) {
+  out = PackedProduct();
   out.M = M; out.D = D; out.L = L;
   out.precision = precision;
   out.levels.resize(static_cast<size_t>(M) * (L + 1));
   out.front_off.assign(static_cast<size_t>(M) * (L + 1) + 1, 0);
-
   const uint32_t all = (1u << D) - 1u;
   std::vector<uint32_t> mask_bits(M, all), others_bits(M, 0);
   for (int j = 0; j < M; ++j) {
@@ -84,90 +202,13 @@ int pack_layout(int Ndens, const kdehip_density *trees, int ndims, const uint8_t
   }
   for (int j = 0; j < M; ++j)
     for (int k = 0; k < M; ++k) if (k != j) others_bits[j] |= mask_bits[k];
-
-  // ---- phase 1: expand every frontier (levelDown!, src/MSGibbs01.jl:503-511) into one flat id array, and look at
-  // every frontier node once: finiteness, bandwidth range, and whether a level shares one bandwidth vector
-  double bw_lo[KDEHIP_MAX_DIMS], bw_hi[KDEHIP_MAX_DIMS];
-  for (int d = 0; d < D; ++d) { bw_lo[d] = INFINITY; bw_hi[d] = 0.0; }
-  bool finite_ok = true;
-  std::vector<uint8_t> level_uniform(static_cast<size_t>(M) * (L + 1), 1);
-  out.front.clear();
-  for (int j = 0; j < M; ++j) {
-    const kdehip_density &t = trees[j];
-    const int64_t N = t.npts;
-    out.front.reserve(out.front.size() + static_cast<size_t>(N) * (L + 1) / 2 + 64);
-    double lo[KDEHIP_MAX_DIMS], hi[KDEHIP_MAX_DIMS];
-    for (int d = 0; d < KDEHIP_MAX_DIMS; ++d) { lo[d] = INFINITY; hi[d] = 0.0; }
-    bool bad = false;
-    for (int l = 0; l <= L; ++l) {
-      const size_t idx = static_cast<size_t>(j) * (L + 1) + l;
-      const size_t begin = out.front.size();
-      out.front_off[idx] = static_cast<int64_t>(begin);
-      // every node is looked at ONCE, at the level where it enters the frontier (a leaf re-enters the next frontier
-      // as its own left child: not new): finiteness and the bandwidth range of the arithmetic-form decision
-      auto look = [&](int64_t node) {  // (branch-free: minima / maxima / one sticky flag in locals of the density loop)
-        const double *mu = t.means + (node - 1) * D, *v = t.bandwidth + (node - 1) * D;
-        for (int d = 0; d < D; ++d) {
-          // (means beyond 1e100 would overflow the squared distances of the product/rsqrt forms)
-          bad |= !(std::fabs(mu[d]) < 1e100) | !(v[d] > 0.0) | !(v[d] < INFINITY);
-          lo[d] = v[d] < lo[d] ? v[d] : lo[d];
-          hi[d] = v[d] > hi[d] ? v[d] : hi[d];
-        }
-        const double w = t.weights[node - 1];
-        bad |= !(w >= 0.0) | !(w < INFINITY);
-      };
-      if (l == 0) {
-        out.front.push_back(1);  // levelInit!: frontier = {root()}
-        if (pmode == kPackChecked) look(1);
-      } else {
-        const size_t pb = static_cast<size_t>(out.front_off[idx - 1]), pe = begin;
-        out.front.resize(begin + 2 * (pe - pb));  // (at most two children per node; trimmed below)
-        int32_t *dst = out.front.data() + begin;
-        const int32_t *src = out.front.data() + pb;
-        size_t cnt = 0;
-        for (size_t z = 0; z < pe - pb; ++z) {
-          const int64_t node = src[z];
-          const int64_t a = t.left_child[node - 1], b = t.right_child[node - 1];
-          if (a > 0 && a <= 2 * N) {  // validIndex, BallTree01.jl:83
-            dst[cnt++] = static_cast<int32_t>(a);
-            if (a != node && pmode == kPackChecked) look(a);
-          }
-          if (b > 0 && b <= 2 * N) {
-            dst[cnt++] = static_cast<int32_t>(b);
-            if (b != node && pmode == kPackChecked) look(b);
-          }
-        }
-        out.front.resize(begin + cnt);
-        const int64_t n = static_cast<int64_t>(cnt);
-        if (n == 0 || n > N) return set_error(KDEHIP_ERR_ARG, "malformed tree: frontier empty or larger than Npts");
-        out.nodes_per_sweep += n;
-      }
-      // one bandwidth vector shared by the whole frontier?  (stops at the first node that differs: frontiers with
-      // internal nodes are decided after a node or two, only the all-leaf frontiers are scanned in full)
-      const double *bw0 = t.bandwidth + (static_cast<int64_t>(out.front[begin]) - 1) * D;
-      bool uni = true;
-      for (size_t z = begin + 1; z < out.front.size() && uni; ++z) {
-        const double *v = t.bandwidth + (static_cast<int64_t>(out.front[z]) - 1) * D;
-        for (int d = 0; d < D; ++d)
-          if (v[d] != bw0[d]) uni = false;
-      }
-      level_uniform[idx] = uni ? 1 : 0;
-    }
-    if (bad) finite_ok = false;
-    for (int d = 0; d < D; ++d) {
-      if (lo[d] < bw_lo[d]) bw_lo[d] = lo[d];
-      if (hi[d] > bw_hi[d]) bw_hi[d] = hi[d];
-    }
-  }
-  out.front_off.back() = static_cast<int64_t>(out.front.size());
-
-  const bool in_range = (pmode == kPackChecked) ? variances_in_range(bw_lo, bw_hi, D, precision) : true;
-  if (pmode == kPackGeneric) finite_ok = false;
   // the fast forms evaluate every dimension: they need every dimension of every density to be informed by
   // some OTHER density too (a one-density "product" or a partialDimMask leaves dimensions inactive: masked fast form)
   out.all_active = true;
   for (int j = 0; j < M; ++j) if ((mask_bits[j] & others_bits[j]) != all) out.all_active = false;
-  out.fast = finite_ok && in_range;
+  out.fast = fast;
+  for (int j = 0; j < M; ++j)
+    for (int l = 1; l <= L; ++l) out.nodes_per_sweep += shapes[static_cast<size_t>(j) * (L + 1) + l].n;
 
   // ---- phase 2: tile geometry and offsets (the payload is written by pack_fill)
   const int64_t esz = (precision == 64) ? 8 : 4;
@@ -175,9 +216,9 @@ int pack_layout(int Ndens, const kdehip_density *trees, int ndims, const uint8_t
   for (int j = 0; j < M; ++j) {
     for (int l = 0; l <= L; ++l) {
       const size_t idx = static_cast<size_t>(j) * (L + 1) + l;
-      const int64_t n = out.front_off[idx + 1] - out.front_off[idx];
+      const int64_t n = shapes[idx].n;
       const int64_t B = (n + 63) / 64;
-      const bool uni = out.fast && level_uniform[idx];  // compact tiles only on the fast path
+      const bool uni = out.fast && shapes[idx].uniform;  // compact tiles only on the fast path
       const int F = uni ? D + 1 : 2 * D + 1;
       const int64_t RS = static_cast<int64_t>(F) * 64 + 1;
       LevelDesc &ds = out.levels[idx];

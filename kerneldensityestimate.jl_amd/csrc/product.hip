@@ -9,11 +9,13 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <mutex>
 #include <new>
 #include <string>
 #include <vector>
 
+#include "device_density.hpp"
 #include "kdehip_internal.hpp"
 #include "philox.hpp"
 
@@ -240,39 +242,18 @@ int build_image(PlanImage &im, int Ndens, const kdehip_density *trees, int ndims
   return KDEHIP_OK;
 }
 
-// A plan on `device` from an image: one device allocation, one DMA transfer (hipMalloc / hipFree cost tens of
-// microseconds each and would dominate a one-shot small product; blocks come from the library's cache).
-// wait = false (one-shot calls, whose image outlives the work they enqueue): the upload is left in flight on the
-// null stream; everything the caller enqueues there afterwards is ordered behind it.
-int instantiate(const PlanImage &im, int device, kdehip_product **out, bool wait = true) {
-  *out = nullptr;
-  kdehip_product *p = new (std::nothrow) kdehip_product();
-  if (!p) return set_error(KDEHIP_ERR_ALLOC, "out of host memory");
-  DeviceGuard guard;
-  int rc = guard.enter(device);
-  if (rc != KDEHIP_OK) { delete p; return rc; }
-  p->device = device;
-  p->precision = im.precision;
-  p->host = im.host;  // descriptors (the frontier ids were released by build_image)
-  p->fast = p->host.fast;
-  p->mode = !p->host.fast ? kModeGeneric : (p->host.all_active ? kModeFast : kModeFastMasked);
-  hipError_t e = cached_malloc(&p->d_blob, im.total);
-  if (e == hipSuccess) p->blob_bytes = im.total;
-  if (e == hipSuccess) e = hipMemcpyAsync(p->d_blob, im.h_blob, im.off_tables, hipMemcpyHostToDevice, nullptr);
-  if (e == hipSuccess && wait) e = hipStreamSynchronize(nullptr);  // (the pinned image may be recycled after this call)
-  if (e != hipSuccess) {
-    const std::string m = std::string("plan upload: ") + hipGetErrorString(e);
-    kdehip_product_destroy(p);
-    return set_error(KDEHIP_ERR_HIP, m);
-  }
+// The device pointers and the kernel-side description of a plan whose blob (layout of PlanImage) is allocated and whose
+// host-side descriptors (p->host, p->precision, p->mode) are set.
+void bind_plan(kdehip_product *p, size_t off_lev, size_t off_count, size_t off_tab, size_t off_perm, size_t off_data,
+               size_t off_tables, size_t total) {
   unsigned char *base = static_cast<unsigned char *>(p->d_blob);
-  p->d_levels = reinterpret_cast<LevelDesc *>(base + im.off_lev);
-  p->d_tabdesc = reinterpret_cast<TabDesc *>(base + im.off_tab);
-  p->d_perm = reinterpret_cast<int32_t *>(base + im.off_perm);
-  p->d_data = base + im.off_data;
-  p->d_fallbacks = reinterpret_cast<unsigned long long *>(base + im.off_count);
-  p->d_tables = im.host.tab_entries ? base + im.off_tables : nullptr;
-  p->packed_bytes = static_cast<int64_t>(im.total);
+  p->d_levels = reinterpret_cast<LevelDesc *>(base + off_lev);
+  p->d_tabdesc = reinterpret_cast<TabDesc *>(base + off_tab);
+  p->d_perm = reinterpret_cast<int32_t *>(base + off_perm);
+  p->d_data = base + off_data;
+  p->d_fallbacks = reinterpret_cast<unsigned long long *>(base + off_count);
+  p->d_tables = p->host.tab_entries ? base + off_tables : nullptr;
+  p->packed_bytes = static_cast<int64_t>(total);
   p->dev.data = p->d_data;
   p->dev.perm = p->d_perm;
   p->dev.levels = p->d_levels;
@@ -304,6 +285,34 @@ int instantiate(const PlanImage &im, int device, kdehip_product **out, bool wait
     p->dev.deep_level[k] = deep;
     p->dev.deep_share[k] = all > 0.0 ? static_cast<float>(shared / all) : 0.0f;
   }
+}
+
+// A plan on `device` from an image: one device allocation, one DMA transfer (hipMalloc / hipFree cost tens of
+// microseconds each and would dominate a one-shot small product; blocks come from the library's cache).
+// wait = false (one-shot calls, whose image outlives the work they enqueue): the upload is left in flight on the
+// null stream; everything the caller enqueues there afterwards is ordered behind it.
+int instantiate(const PlanImage &im, int device, kdehip_product **out, bool wait = true) {
+  *out = nullptr;
+  kdehip_product *p = new (std::nothrow) kdehip_product();
+  if (!p) return set_error(KDEHIP_ERR_ALLOC, "out of host memory");
+  DeviceGuard guard;
+  int rc = guard.enter(device);
+  if (rc != KDEHIP_OK) { delete p; return rc; }
+  p->device = device;
+  p->precision = im.precision;
+  p->host = im.host;  // descriptors (the frontier ids were released by build_image)
+  p->fast = p->host.fast;
+  p->mode = !p->host.fast ? kModeGeneric : (p->host.all_active ? kModeFast : kModeFastMasked);
+  hipError_t e = cached_malloc(&p->d_blob, im.total);
+  if (e == hipSuccess) p->blob_bytes = im.total;
+  if (e == hipSuccess) e = hipMemcpyAsync(p->d_blob, im.h_blob, im.off_tables, hipMemcpyHostToDevice, nullptr);
+  if (e == hipSuccess && wait) e = hipStreamSynchronize(nullptr);  // (the pinned image may be recycled after this call)
+  if (e != hipSuccess) {
+    const std::string m = std::string("plan upload: ") + hipGetErrorString(e);
+    kdehip_product_destroy(p);
+    return set_error(KDEHIP_ERR_HIP, m);
+  }
+  bind_plan(p, im.off_lev, im.off_count, im.off_tab, im.off_perm, im.off_data, im.off_tables, im.total);
   *out = p;
   return KDEHIP_OK;
 }
@@ -419,8 +428,7 @@ int kdehip_product_launch_geometry(const kdehip_product *plan, int64_t Np, int32
   DeviceGuard guard;
   const int rc = guard.enter(plan->device);  // (the width heuristic asks the plan's device for its CU count)
   if (rc != KDEHIP_OK) return rc;
-  const bool lean = plan->mode == kModeFast && plan->host.M >= 2 && plan->host.M <= 8 &&
-                    (plan->precision == 64 || plan->host.M <= 4);
+  const bool lean = plan->mode == kModeFast && ((plan->host.M >= 2 && plan->host.M <= 4) || (plan->host.M == 8 && plan->precision == 64));
   LeanGeometry g{chains_per_workgroup(Np, plan->variant), 1, 0, 0};
   const int v = plan->variant % 1000;
   if (lean && !(v >= kVariantGenericBase && v < kVariantGenericBase + 20))
@@ -637,6 +645,171 @@ int kdehip_prod_philox(int Ndens, const kdehip_density *trees, int64_t Np, int N
                        int device, int ngpus, int32_t *labels) {
   return one_shot(Ndens, trees, Np, Niter, pts, ind, nullptr, 0, nullptr, 0, seed, addEntropy, ndims, partialDimMask,
                   precision, device, ngpus, labels);
+}
+
+// ---- products of densities that live in HBM (pack_device.hip) ------------------------------------------------------
+namespace {
+
+// Plans of enqueue-only calls live until the work that uses them has run: they wait here, with an event recorded behind
+// their last launch, and are released by later calls (or kdehip_clear_cache) once the event has fired.
+struct PendingPlan {
+  kdehip_product *plan;
+  hipEvent_t done;
+  void *h_desc;
+  size_t h_bytes;
+};
+std::mutex g_pending_mu;
+std::deque<PendingPlan> g_pending[64];
+constexpr size_t kMaxPending = 8;
+
+void release_pending(PendingPlan &pp) {
+  (void)hipEventDestroy(pp.done);
+  if (pp.h_desc) cached_host_free(pp.h_desc, pp.h_bytes);
+  if (pp.plan) {
+    if (pp.plan->d_blob) cached_free(pp.plan->d_blob, pp.plan->blob_bytes);
+    if (pp.plan->d_work) cached_free(pp.plan->d_work, pp.plan->work_cap);
+    delete pp.plan;
+  }
+}
+// (current device = `device`)  Releases what has finished; with more than kMaxPending plans in flight waits for the oldest.
+void reap_pending(int device, bool all) {
+  if (device < 0 || device >= 64) return;
+  std::lock_guard<std::mutex> lock(g_pending_mu);
+  auto &q = g_pending[device];
+  while (!q.empty()) {
+    PendingPlan &f = q.front();
+    if (all || q.size() > kMaxPending) (void)hipEventSynchronize(f.done);
+    else if (hipEventQuery(f.done) != hipSuccess) break;
+    release_pending(f);
+    q.pop_front();
+  }
+  (void)hipGetLastError();  // (hipEventQuery reports "not ready" as an error)
+}
+
+}  // namespace
+
+void kdehip_internal_drain_pending() {  // kdehip_clear_cache: nothing may stay behind
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return;
+  DeviceGuard guard;
+  for (int d = 0; d < n && d < 64; ++d)
+    if (guard.enter(d) == KDEHIP_OK) reap_pending(d, true);
+}
+
+int kdehip_prod_philox_device(int Ndens, kdehip_device_density *const *trees, int64_t Np, int Niter, uint64_t seed,
+                              int64_t sample_offset, int addEntropy, const uint8_t *partialDimMask, int precision,
+                              double *d_points, int64_t *d_indices, int32_t *d_labels, void *stream) {
+  if (Ndens < 1 || !trees) return set_error(KDEHIP_ERR_ARG, "need at least one density");
+  if (Ndens > KDEHIP_MAX_DENS) return set_error(KDEHIP_ERR_UNSUPPORTED, "more than KDEHIP_MAX_DENS densities in one product");
+  if (precision != 64 && precision != 32) return set_error(KDEHIP_ERR_ARG, "precision must be 64 or 32");
+  for (int j = 0; j < Ndens; ++j) {
+    if (!trees[j]) return set_error(KDEHIP_ERR_ARG, "null density");
+    if (trees[j]->D != trees[0]->D) return set_error(KDEHIP_ERR_DIM_MISMATCH, "kdes must have same dimension");
+    if (trees[j]->device != trees[0]->device) return set_error(KDEHIP_ERR_ARG, "densities on different devices");
+  }
+  if (Np < 0) return set_error(KDEHIP_ERR_ARG, "Np must be >= 0");
+  if (Niter < 0) return set_error(KDEHIP_ERR_ARG, "Niter must be >= 0");
+  if (Np > 0 && (!d_points || !d_indices)) return set_error(KDEHIP_ERR_ARG, "null output pointer");
+  if (Np == 0) return KDEHIP_OK;
+  const int M = Ndens, D = trees[0]->D, device = trees[0]->device;
+  int64_t maxN = 0;
+  for (int j = 0; j < M; ++j) if (trees[j]->N > maxN) maxN = trees[j]->N;
+  const int L = nlevels_for(maxN);
+  // the layout, from shapes alone: beyond a density's own depth its frontier stays what it was (all leaves)
+  std::vector<TileShape> shapes(static_cast<size_t>(M) * (L + 1));
+  double lo[KDEHIP_MAX_DIMS], hi[KDEHIP_MAX_DIMS];
+  for (int d = 0; d < KDEHIP_MAX_DIMS; ++d) { lo[d] = INFINITY; hi[d] = 0.0; }
+  bool finite_ok = true;
+  for (int j = 0; j < M; ++j) {
+    const kdehip_device_density &t = *trees[j];
+    for (int l = 0; l <= L; ++l) {
+      const int lj = l < t.Lown ? l : t.Lown;
+      shapes[static_cast<size_t>(j) * (L + 1) + l] = {t.fr.off[lj + 1] - t.fr.off[lj], t.fr.uniform[lj] != 0};
+    }
+    if (t.fr.bad) finite_ok = false;
+    for (int d = 0; d < D; ++d) {
+      if (t.fr.lo[d] < lo[d]) lo[d] = t.fr.lo[d];
+      if (t.fr.hi[d] > hi[d]) hi[d] = t.fr.hi[d];
+    }
+  }
+  const bool fast = finite_ok && variances_in_range(lo, hi, D, precision);
+  kdehip_product *p = new (std::nothrow) kdehip_product();
+  if (!p) return set_error(KDEHIP_ERR_ALLOC, "out of host memory");
+  int rc = pack_layout_shapes(M, D, L, shapes.data(), partialDimMask, precision, fast, p->host);
+  if (rc != KDEHIP_OK) { delete p; return rc; }
+  DeviceGuard guard;
+  rc = guard.enter(device);
+  if (rc != KDEHIP_OK) { delete p; return rc; }
+  reap_pending(device, false);
+  p->device = device;
+  p->precision = precision;
+  p->fast = p->host.fast;
+  p->mode = !p->host.fast ? kModeGeneric : (p->host.all_active ? kModeFast : kModeFastMasked);
+  // the blob: [counter | levels | table descriptors | fill jobs | permutation | tiles | tables]
+  const size_t nlev = p->host.levels.size(), ntab = p->host.tabdesc.size();
+  const size_t esz = (precision == 64) ? sizeof(double) : sizeof(float);
+  const size_t off_lev = 256, off_count = off_lev - sizeof(unsigned long long);
+  const size_t off_tab = align256(off_lev + nlev * sizeof(LevelDesc));
+  const size_t off_jobs = align256(off_tab + ntab * sizeof(TabDesc));
+  const size_t off_perm = align256(off_jobs + nlev * sizeof(FillJob));
+  const size_t off_data = align256(off_perm + static_cast<size_t>(p->host.perm_elems) * sizeof(int32_t));
+  const size_t off_tables = align256(off_data + static_cast<size_t>(p->host.data_elems) * esz);
+  const size_t total = off_tables + static_cast<size_t>(p->host.tab_entries) * esz;
+  PendingPlan pend{p, nullptr, nullptr, off_perm};
+  hipError_t e = cached_malloc(&p->d_blob, total);
+  if (e == hipSuccess) p->blob_bytes = total;
+  if (e == hipSuccess) e = cached_host_malloc(&pend.h_desc, pend.h_bytes);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&pend.done, hipEventDisableTiming);
+  if (e != hipSuccess) {
+    if (pend.h_desc) cached_host_free(pend.h_desc, pend.h_bytes);
+    if (p->d_blob) cached_free(p->d_blob, total);
+    delete p;
+    return set_error(KDEHIP_ERR_HIP, std::string("device product: ") + hipGetErrorString(e));
+  }
+  // descriptors: a few KB from pinned memory, in front of the launches on the caller's stream
+  unsigned char *hb = static_cast<unsigned char *>(pend.h_desc);
+  std::memset(hb, 0, off_lev);
+  std::memcpy(hb + off_lev, p->host.levels.data(), nlev * sizeof(LevelDesc));
+  std::memcpy(hb + off_tab, p->host.tabdesc.data(), ntab * sizeof(TabDesc));
+  FillJob *jobs = reinterpret_cast<FillJob *>(hb + off_jobs);
+  int maxB = 1;
+  for (int j = 0; j < M; ++j)
+    for (int l = 0; l <= L; ++l) {
+      const size_t idx = static_cast<size_t>(j) * (L + 1) + l;
+      const LevelDesc &ds = p->host.levels[idx];
+      const int lj = l < trees[j]->Lown ? l : trees[j]->Lown;
+      jobs[idx] = FillJob{ds.hdr_off, ds.perm_off, trees[j]->fr.off[lj], ds.n, ds.B, ds.F, ds.uniform_bw, j, 0};
+      if (ds.B > maxB) maxB = ds.B;
+    }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  bind_plan(p, off_lev, off_count, off_tab, off_perm, off_data, off_tables, total);
+  auto fail = [&](int code) {  // (nothing of this plan has been handed to the queue yet)
+    (void)hipStreamSynchronize(st);
+    release_pending(pend);
+    return code;
+  };
+  if (hipMemcpyAsync(p->d_blob, hb, off_perm, hipMemcpyHostToDevice, st) != hipSuccess)
+    return fail(set_error(KDEHIP_ERR_HIP, "device product: descriptor upload failed"));
+  FillArgs fa{};
+  for (int j = 0; j < M; ++j) {
+    fa.means[j] = trees[j]->means; fa.bandwidth[j] = trees[j]->bandwidth; fa.weights[j] = trees[j]->weights;
+    fa.perm[j] = trees[j]->perm; fa.front[j] = trees[j]->front;
+  }
+  fa.jobs = reinterpret_cast<const FillJob *>(static_cast<unsigned char *>(p->d_blob) + off_jobs);
+  fa.data = p->d_data;
+  fa.perm_out = p->d_perm;
+  fa.D = D;
+  rc = launch_fill_tiles(precision, fa, static_cast<int>(nlev), maxB, st);
+  if (rc != KDEHIP_OK) return fail(rc);
+  rc = enqueue_philox(p, Np, Niter, seed, sample_offset, addEntropy, d_points, d_indices, d_labels, stream,
+                      /*private_plan=*/true);
+  if (rc != KDEHIP_OK) return fail(rc);
+  if (hipEventRecord(pend.done, st) != hipSuccess) return fail(set_error(KDEHIP_ERR_HIP, "device product: hipEventRecord failed"));
+  {
+    std::lock_guard<std::mutex> lock(g_pending_mu);
+    if (device >= 0 && device < 64) g_pending[device].push_back(pend);
+  }
+  return KDEHIP_OK;
 }
 
 // ---- resident multi-GPU plans: one plan per device, chains in contiguous ranges, one all-gather ----------------

@@ -193,6 +193,49 @@ class MultiProductPlan:
                                                                int(bool(addEntropy)), P, I, S))
 
 
+class DeviceDensity:
+    """A BallTreeDensity uploaded ONCE and kept in HBM (kdehip_density_upload): products of such densities are laid
+    out by the GPU and move nothing but a few KB of descriptors over PCIe (`prodAppxMSGibbsS_device`)."""
+
+    def __init__(self, tree: BallTreeDensity, device=0):
+        h = C.c_void_p()
+        cs = tree._cstruct()
+        _lib.check(_lib.lib.kdehip_density_upload(C.byref(h), C.byref(cs), int(device)))
+        self._h = h
+        self.device = int(device)
+        self.num_points = int(_lib.lib.kdehip_density_npts(h))
+        self.dims = int(_lib.lib.kdehip_density_ndim(h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib.kdehip_density_free(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+def prodAppxMSGibbsS_device(trees, d_points, d_indices, *, Np, Niter=3, seed=0, sample_offset=0, addEntropy=True,
+                            partialDimMask=None, precision=64, d_labels=None, stream=None):
+    """`prodAppxMSGibbsS` (reference src/MSGibbs01.jl:645-703) on densities that live in HBM (`DeviceDensity`), results
+    left in HBM: d_points (float64[ndims*Np]) and d_indices (int64[Ndens*Np]) are device arrays (torch tensors or
+    addresses).  Enqueues on `stream` and returns; same numbers as `prodAppxMSGibbsS(..., seed=seed)`."""
+    trees = list(trees)
+    M = len(trees)
+    arr = (C.c_void_p * M)(*[t._h for t in trees])
+    ndims = trees[0].dims
+    mask = _mask_array(partialDimMask, M, ndims)
+    _lib.check(_lib.lib.kdehip_prod_philox_device(
+        M, arr, int(Np), int(Niter), C.c_uint64(int(seed) & (2 ** 64 - 1)), int(sample_offset), int(bool(addEntropy)),
+        None if mask is None else ptr(mask, u8p), int(precision), ProductPlan._addr(d_points), ProductPlan._addr(d_indices),
+        ProductPlan._addr(d_labels), ProductPlan._addr(stream)))
+
+
 def philox_streams(seed, sample_begin, nsamples, K, R):
     """Host twin of the device RNG: the (randU, randN) arrays a Philox run consumes
     (kdehip_philox_fill_uniform / _normal)."""

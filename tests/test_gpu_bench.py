@@ -40,6 +40,13 @@ def test_bench_single_gpu_json_contract():
     assert 0.2 < vf["frac"] < 1.0 and abs(vf["frac"] - vf["ms"] / r["kernel_ms"]) < 1e-12
     ci = d["call_inclusive"]
     assert ci["ms"] > d["roofline"]["kernel_ms"] and ci["gibbs1_caller_streams_ms"] > ci["ms"] * 0.8
+    # `value` is a complete prodAppxMSGibbsS-equivalent call from HBM-resident densities (re-layout + tables + sampling
+    # every step): slower than re-sampling one resident plan, faster than the same call through host buffers
+    assert "prodAppxMSGibbsS-equivalent call" in d["value_is"]
+    assert d["roofline"]["kernel_ms"] < d["ms_per_step"] < ci["ms"] * 1.1
+    assert d["resident_plan"]["ms_per_launch"] < d["ms_per_step"]
+    cs = d["cold_start"]
+    assert cs is not None and cs["cold_start_ms"] > cs["second_call_ms"] and cs["libkdehip_bytes"] < 40e6
     assert d["parity"]["label_mismatches"] == 0 and d["parity"]["moment_mean_diff"] < 1e-6
     assert d["parity"]["moment_var_diff"] < 1e-6 and d["parity"]["ks_max"] <= 2.0 / d["parity"]["samples_checked"]
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1

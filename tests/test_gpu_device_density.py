@@ -1,0 +1,94 @@
+"""Densities that live in HBM (include/kdehip.h section 2c, csrc/pack_device.hip): `kdehip_density_upload` keeps a
+BallTreeDensity and its per-level frontiers on the device, `kdehip_prod_philox_device` lays a product out on the GPU
+(gather kernel) and samples it with outputs left in HBM.  Same layout, same kernels, same Philox stream as the
+host-packed one-shot call: results must be bit-identical to `prodAppxMSGibbsS(..., seed=...)`, whatever the shapes."""
+import numpy as np
+import pytest
+
+import kdehip
+from tests.helpers import silverman_bw, synth_mixture
+
+pytestmark = pytest.mark.gpu
+
+
+def _trees(seed, D, Ns, weighted=False, per_dim_bw=True):
+    rng = np.random.default_rng(seed)
+    out = []
+    for N in Ns:
+        pts = synth_mixture(rng, D, N)
+        ks = silverman_bw(pts) if (N > 1 and per_dim_bw) else np.full(D, 0.4)
+        ks = np.where(ks > 0, ks, 0.4)
+        w = rng.uniform(0.2, 1.0, size=N) if weighted else None
+        out.append(kdehip.kde(pts, ks, w))
+    return out
+
+
+@pytest.mark.parametrize("D,Ns,Np,Niter,weighted,prec", [
+    (6, [1000] * 4, 300, 3, False, 64),          # BASELINE config 3's shape
+    (2, [200, 200, 200], 256, 5, False, 64),     # config 2
+    (3, [5000] * 8, 40, 1, False, 64),           # config 4's shape: chunked tiles
+    (6, [10000] * 4, 24, 2, False, 32),          # config 5's shape, fp32 tiles
+    (3, [37, 128, 129, 300], 70, 2, True, 64),   # ragged sizes, weights: frontiers repeat beyond a density's own depth
+    (4, [1, 60, 7], 33, 3, False, 64),           # a single-point density
+    (1, [100, 100], 100, 5, False, 32),
+    (8, [130, 90, 64, 65, 33], 50, 1, True, 64), # five densities: the general kernel
+])
+def test_device_resident_product_equals_host_packed_product(D, Ns, Np, Niter, weighted, prec):
+    import torch
+    dev = torch.device("cuda", 0)
+    trees = _trees(700 + D + len(Ns), D, Ns, weighted)
+    M = len(Ns)
+    seed = 31
+    ref_p, ref_i = kdehip.prodAppxMSGibbsS(None, trees, None, None, Niter=Niter, Np=Np, seed=seed, precision=prec)
+    dd = [kdehip.DeviceDensity(t) for t in trees]
+    assert [d.num_points for d in dd] == list(Ns) and all(d.dims == D for d in dd)
+    P = torch.zeros(D * Np, dtype=torch.float64, device=dev)
+    I = torch.zeros(M * Np, dtype=torch.int64, device=dev)
+    st = torch.cuda.Stream(device=dev)
+    for rep in range(3):   # (plans of earlier calls are released by later ones)
+        kdehip.prodAppxMSGibbsS_device(dd, P, I, Np=Np, Niter=Niter, seed=seed, precision=prec, stream=st.cuda_stream)
+    st.synchronize()
+    assert np.array_equal(I.cpu().numpy().reshape(Np, M).T, ref_i)
+    assert np.array_equal(P.cpu().numpy().reshape(Np, D).T, ref_p)
+    # a sample offset continues the same stream: chains [Np/2, Np) of the call above
+    half = Np // 2
+    P2 = torch.zeros(D * (Np - half), dtype=torch.float64, device=dev)
+    I2 = torch.zeros(M * (Np - half), dtype=torch.int64, device=dev)
+    kdehip.prodAppxMSGibbsS_device(dd, P2, I2, Np=Np - half, Niter=Niter, seed=seed, sample_offset=half, precision=prec)
+    torch.cuda.synchronize()
+    assert np.array_equal(I2.cpu().numpy().reshape(Np - half, M).T, ref_i[:, half:])
+    assert np.array_equal(P2.cpu().numpy().reshape(Np - half, D).T, ref_p[:, half:])
+    for d in dd:
+        d.close()
+    kdehip._clib.kdehip_clear_cache()
+
+
+def test_device_resident_product_with_mask_and_labels():
+    import torch
+    dev = torch.device("cuda", 0)
+    D, Ns, Np, Niter = 3, [150, 180, 90], 64, 2
+    trees = _trees(5, D, Ns)
+    mask = [[True, True, False], [True, False, True], [False, True, True]]
+    glbs = kdehip.makeEmptyGbGlb(recordChoosen=True)
+    ref_p, ref_i = kdehip.prodAppxMSGibbsS(None, trees, None, None, Niter=Niter, Np=Np, seed=8, partialDimMask=mask, glbs=glbs)
+    dd = [kdehip.DeviceDensity(t) for t in trees]
+    L = kdehip.nlevels(max(Ns))
+    P = torch.zeros(D * Np, dtype=torch.float64, device=dev)
+    I = torch.zeros(len(Ns) * Np, dtype=torch.int64, device=dev)
+    Lab = torch.zeros(Np * len(Ns) * L, dtype=torch.int32, device=dev)
+    kdehip.prodAppxMSGibbsS_device(dd, P, I, Np=Np, Niter=Niter, seed=8, partialDimMask=mask, d_labels=Lab)
+    torch.cuda.synchronize()
+    assert np.array_equal(I.cpu().numpy().reshape(Np, len(Ns)).T, ref_i)
+    assert np.array_equal(P.cpu().numpy().reshape(Np, D).T, ref_p)
+    lab = Lab.cpu().numpy().reshape(Np, len(Ns), L)
+    assert [glbs.labelsChoosen[7][2][l + 1] for l in range(L)] == list(lab[6, 1])
+
+
+def test_device_density_errors():
+    trees = _trees(9, 2, [50, 60])
+    other = _trees(10, 3, [40])
+    dd = [kdehip.DeviceDensity(t) for t in trees] + [kdehip.DeviceDensity(other[0])]
+    with pytest.raises(ValueError):   # "kdes must have same dimension" (src/MSGibbs01.jl:720-722)
+        kdehip.prodAppxMSGibbsS_device(dd, 0, 0, Np=0)
+    with pytest.raises(kdehip.KdeHipError):
+        kdehip.prodAppxMSGibbsS_device(dd[:2], None, None, Np=10)   # null outputs

@@ -12,7 +12,7 @@ from tests.helpers import silverman_bw, synth_mixture
 
 pytestmark = pytest.mark.gpu
 
-WIDTHS = (2, 8, 12, 16)   # one wavefront per chain: 4, 8, 12, 16 chains per workgroup
+WIDTHS = (2, 8, 16)   # one wavefront per chain: 4, 8, 16 chains per workgroup
 TEAMS = (52, 54)          # 16 wavefronts per workgroup as 8 chains x 2 / 4 chains x 4
 
 
@@ -47,7 +47,7 @@ def test_team_sizes_give_identical_results(D, Ns, Np, Niter, weighted):
         assert plan.fast_math_path
         res = {}
         for variant in (0,) + WIDTHS + TEAMS:
-            if len(Ns) > 4 and variant in (2, 12):   # (5..8 densities: lean kernel at 8 and 16 chains per workgroup only)
+            if len(Ns) > 4 and variant == 2:   # (5..8 densities: lean kernel at 8 and 16 chains per workgroup only)
                 continue
             plan.set_variant(variant)
             res[variant] = plan.sample(Np, Niter=Niter, seed=seed, want_labels=True)
