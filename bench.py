@@ -273,7 +273,7 @@ def main():
             # scans and selection not counted) per second of kernel time; peak = the MI355X vector peak of the dtype.
             "roofline": {"bound": "valu", "achieved": achieved_tf, "peak": peak_tf, "unit": "TFLOP/s",
                          "frac": achieved_tf / peak_tf, "traffic": prof.get("hbm_bytes_per_launch"),
-                         "kernel": "gibbs_lean_kernel" if (2 <= M <= 4 or (5 <= M <= 8 and prec == 64)) else "gibbs_product_kernel", "kernel_ms": kern_ms,
+                         "kernel": plan.kernel_name(hi - lo), "kernel_ms": kern_ms,
                          "algorithmic_flops_per_launch": alg_flops,
                          # issue-slot view from the committed PMC profile of this workload (profiles/): instructions the
                          # wavefronts issued per chain against the 4-cycle issue slots of their lifetime

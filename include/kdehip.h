@@ -164,6 +164,11 @@ int kdehip_product_set_variant(kdehip_product *plan, int variant);
  * workgroup and wavefronts per chain (1 = no team). */
 int kdehip_product_launch_geometry(const kdehip_product *plan, int64_t Np, int32_t *waves_per_workgroup,
                                    int32_t *waves_per_chain);
+/* Diagnostic: the sampling kernel a run of Np chains of this plan launches under its current variant --
+ * "gibbs_lean_kernel" (chain state in registers: products of 2..4 densities, fp64 products of 8, every dimension
+ * active) or "gibbs_product_kernel" (any density count, masks, the reference's divide + log arithmetic).  A static
+ * string. */
+const char *kdehip_product_kernel_name(const kdehip_product *plan, int64_t Np);
 
 /* ---- (2b) resident plans on several GPUs of one node (one process) --------------------------------
  * One plan per device (the packed densities are replicated), chains in contiguous ranges, Philox counters keyed by

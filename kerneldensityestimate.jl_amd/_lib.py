@@ -78,6 +78,7 @@ SIGNATURES = {
                                                     C.c_int, f64p, i64p, i32p]),
     "kdehip_product_set_variant": (C.c_int, [C.c_void_p, C.c_int]),
     "kdehip_product_launch_geometry": (C.c_int, [C.c_void_p, C.c_int64, i32p, i32p]),
+    "kdehip_product_kernel_name": (C.c_char_p, [C.c_void_p, C.c_int64]),
     "kdehip_density_upload": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(CDensity), C.c_int]),
     "kdehip_density_free": (None, [C.c_void_p]),
     "kdehip_density_npts": (C.c_int64, [C.c_void_p]),

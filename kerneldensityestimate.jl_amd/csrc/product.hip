@@ -438,6 +438,21 @@ int kdehip_product_launch_geometry(const kdehip_product *plan, int64_t Np, int32
   return KDEHIP_OK;
 }
 
+const char *kdehip_product_kernel_name(const kdehip_product *plan, int64_t Np) {
+  if (!plan) return "";
+  const int v = plan->variant % 1000;
+  const bool forced_general = (v >= kVariantGenericBase && v < kVariantGenericBase + 20);
+  const int M = plan->host.M, L = plan->host.L, D = plan->host.D;
+  bool lean = !forced_general && plan->mode == kModeFast && D * (L + 1) <= 128 &&
+              ((M >= 2 && M <= 4) || (M == 8 && plan->precision == 64));
+  if (lean && M == 8) {  // (the 8-density instantiations exist for 8 and 16 chains per workgroup)
+    DeviceGuard guard;
+    if (guard.enter(plan->device) != KDEHIP_OK) return "";
+    lean = lean_geometry(Np, plan->variant, plan->precision, plan->dev).waves != 4;
+  }
+  return lean ? "gibbs_lean_kernel" : "gibbs_product_kernel";
+}
+
 int kdehip_product_sample_streams(kdehip_product *plan, int64_t Np, int Niter, const double *d_randU,
                                   int64_t nU, const double *d_randN, int64_t nN, int addEntropy,
                                   double *d_points, int64_t *d_indices, int32_t *d_labels,

@@ -97,6 +97,10 @@ class ProductPlan:
     def set_variant(self, v: int):
         _lib.check(_lib.lib.kdehip_product_set_variant(self._h, int(v)))
 
+    def kernel_name(self, Np: int) -> str:
+        """the sampling kernel a run of Np chains launches: "gibbs_lean_kernel" or "gibbs_product_kernel" """
+        return _lib.lib.kdehip_product_kernel_name(self._h, int(Np)).decode()
+
     def launch_geometry(self, Np: int) -> dict:
         """Wavefronts per workgroup and per chain (`team`; 1 = none) a run of Np chains gets under the current variant."""
         w, t = C.c_int32(0), C.c_int32(0)

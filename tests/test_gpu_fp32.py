@@ -133,3 +133,29 @@ def test_fp32_takes_the_uniform_fallback_exactly_where_fp64_does(sep, expect):
             assert (expect == "some") == (n64 < 0.7 * total)
         if n64 == 0:   # no uniform draws: fp32 follows the fp64 chains up to the usual rounding flips
             assert (i32 != i64).mean() < 0.1
+
+
+def test_config5_total_chain_count_on_one_gpu():
+    """BASELINE config 5 as stated -- fp32, 6-D, 4 densities x 10000 points, Nout = 65536, Niter = 20 -- all chains on
+    one GPU (what `bench.py --strong --config c5 --gpus 1` times): the same chains drawn as eight shards of 8192 (the
+    8-GPU split of the config: global Philox index) are bit-identical to the one call, and an 8192-chain slice from
+    the MIDDLE of the batch passes the SURVEY.md 8(d) gates against fp64 on the same stream."""
+    import bench
+    D, M, N, _, Niter, prec, cid = bench.CONFIGS["c5"]
+    Np = bench.TOTAL_NOUT["c5"]
+    assert (Np, Niter, prec) == (65536, 20, 32)
+    pts, bws = bench.synth_inputs(kdehip, D, M, N, cid)
+    trees = [kdehip.kde(p, b) for p, b in zip(pts, bws)]
+    seed = 20260101
+    with kdehip.ProductPlan(trees, precision=32) as p32:
+        assert p32.kernel_name(Np) == "gibbs_lean_kernel"
+        b, ib = p32.sample(Np, Niter=Niter, seed=seed)
+        shards = [p32.sample(Np // 8, Niter=Niter, seed=seed, sample_offset=g * (Np // 8)) for g in range(8)]
+    assert np.isfinite(b).all() and ib.min() >= 2 and ib.max() <= N + 1
+    assert np.array_equal(np.concatenate([s[0] for s in shards], axis=1), b)
+    assert np.array_equal(np.concatenate([s[1] for s in shards], axis=1), ib)
+    lo = 3 * (Np // 8)
+    with kdehip.ProductPlan(trees, precision=64) as p64:
+        a, ia = p64.sample(Np // 8, Niter=Niter, seed=seed, sample_offset=lo)
+    _gates(a, b[:, lo:lo + Np // 8], Np // 8)
+    assert (ia != ib[:, lo:lo + Np // 8]).mean() < 0.15
