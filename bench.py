@@ -381,9 +381,14 @@ def call_inclusive(kdehip, trees, plan, D, M, Nout, Niter, seed, prec):
     t_g1 = med(lambda: kdehip.prodAppxMSGibbsS(None, trees, None, None, Niter=Niter, Np=Nout, randU=randU, randN=randN)) \
         if prec == 64 else None
     t_res = med(lambda: plan.sample(Nout, Niter=Niter, seed=seed))
+    dd = [kdehip.DeviceDensity(t) for t in trees]
+    t_dev = med(lambda: kdehip.prodAppxMSGibbsS_resident(dd, Np=Nout, Niter=Niter, seed=seed, precision=prec))
+    for d in dd:
+        d.close()
     return {"ms": t_prod, "samples_per_sec": Nout / (t_prod * 1e-3),
             "what": "prodAppxMSGibbsS, device Philox: pack + H2D + kernel + D2H, host buffers in and out (median of 15)",
             "gibbs1_caller_streams_ms": t_g1, "randU_MB_over_pcie": randU.nbytes / 1e6,
+            "densities_resident_host_outputs_ms": t_dev,   # kdehip_prod_philox_resident: GPU re-layout, one copy back
             "resident_plan_run_plus_d2h_ms": t_res}
 
 

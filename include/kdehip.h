@@ -216,6 +216,12 @@ int kdehip_prod_philox_device(int Ndens, kdehip_device_density *const *trees, in
                               int64_t sample_offset, int addEntropy, const uint8_t *partialDimMask, int precision,
                               double *d_points, int64_t *d_indices, int32_t *d_labels, void *stream);
 
+/* The same with host output buffers (pts: ndims*Np, ind: Ndens*Np), blocking: for hosts that keep no device arrays of
+ * their own -- a Julia caller without AMDGPU.jl uploads its densities once and then pays neither the host re-layout
+ * nor the upload of the tiles per product (sample offset 0, default stream). */
+int kdehip_prod_philox_resident(int Ndens, kdehip_device_density *const *trees, int64_t Np, int Niter, uint64_t seed,
+                                int addEntropy, const uint8_t *partialDimMask, int precision, double *pts, int64_t *ind);
+
 /* ---- (3) host twin of the device RNG ----------------------------------------------------------
  * Fills the arrays a caller would pass as randU / randN so that a streams-run (or the Julia
  * reference, via its randU=/randN= keywords, src/MSGibbs01.jl:661-662) consumes exactly the

@@ -10,7 +10,7 @@ from .density import (BallTree, BallTreeDensity, Ndim, Npts, density_from_arrays
                       getWeights, kde, kde_b, kde_batch)
 from .bandwidth import auto_bandwidth, evaluateDualTree, kde_auto  # noqa: F401
 from .product import (DeviceDensity, GbGlb, MultiProductPlan, ProductPlan, gibbs1, makeEmptyGbGlb, mul, nlevels,  # noqa: F401
-                      philox_streams, prodAppxMSGibbsS, prodAppxMSGibbsS_device)
+                      philox_streams, prodAppxMSGibbsS, prodAppxMSGibbsS_device, prodAppxMSGibbsS_resident)
 
 
 def device_count() -> int:

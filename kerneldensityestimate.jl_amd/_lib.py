@@ -85,6 +85,8 @@ SIGNATURES = {
     "kdehip_density_ndim": (C.c_int, [C.c_void_p]),
     "kdehip_prod_philox_device": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.c_int64, C.c_int, C.c_uint64, C.c_int64,
                                             C.c_int, u8p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "kdehip_prod_philox_resident": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.c_int64, C.c_int, C.c_uint64, C.c_int, u8p,
+                                              C.c_int, f64p, i64p]),
     "kdehip_philox_fill_uniform": (None, [C.c_uint64, C.c_int64, C.c_int64, C.c_int64, f64p]),
     "kdehip_philox_fill_normal": (None, [C.c_uint64, C.c_int64, C.c_int64, C.c_int64, f64p]),
     "kdehip_evaluate": (C.c_int, [C.POINTER(CDensity), f64p, C.c_int64, C.c_int, f64p, C.c_int]),

@@ -50,7 +50,10 @@
 
 namespace kdehip {
 
-template <typename T, int D, int MODE, int WAVES>
+// TBL: the instantiation that only fills the conditional tables (a.table_build) -- the same code, but without the
+// 120 KiB tile pool in its LDS footprint, so that a CU holds many more of its wavefronts (one wavefront per table row,
+// ~19,000 rows at config 3: 45 us with the sampler's one-workgroup-per-CU footprint, every one-shot call pays it).
+template <typename T, int D, int MODE, int WAVES, bool TBL = false>
 __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan, RunArgs a) {
   constexpr bool FAST = (MODE != kModeGeneric);      // product/rsqrt + uniform-bandwidth forms
   constexpr bool MASKED = (MODE == kModeFastMasked);  // ... with inactive dimensions
@@ -59,7 +62,7 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan,
   // builds have 128 VGPRs and would spill from D = 6 on
   constexpr bool kPrefetchRows = (WAVES <= 12) || sizeof(T) == 4 || D <= 4;
   using Lay = LdsLayout<T, D, WAVES>;
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[Lay::kBytes];
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[TBL ? Lay::kPoolOff : Lay::kBytes];
 
   double *sExpTab = reinterpret_cast<double *>(smem);
   if (threadIdx.x < 32) sExpTab[threadIdx.x] = kExp2Tab[threadIdx.x];
@@ -265,7 +268,7 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan,
   // without the kernel evaluation, scan and state update on the per-step critical path.
   const TabTable tabs{(const __attribute__((address_space(4))) kdehip_v8i *)(plan.tabdesc)};
   T *tables = static_cast<T *>(const_cast<void *>(plan.tables));
-  if (a.table_build) {
+  if (TBL || a.table_build) {
     const int64_t g = static_cast<int64_t>(blockIdx.x) * WAVES + wave;
     if (g >= plan.tab_rows_total) return;
     int tl = 1, tj = 0;
@@ -313,6 +316,7 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan,
     });
     return;
   }
+  if constexpr (!TBL) {
   const int Lt = (vlev == 1 || vlev == 4 || !a.use_tables) ? 0 : plan.Lt;  // variant 4: tables off (A/B, tests)
 
   // init: frontier = {root}, label = root (levelInit!/initIndices!/calcIndices!, :587-589)
@@ -517,6 +521,7 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan,
       for (int q = 0; q < a.npeers; ++q) a.peer_points[q][s * D + lane] = static_cast<double>(xf);
     }
   }
+  }  // !TBL
 }
 
 // ---- launcher --------------------------------------------------------------------------------------
@@ -535,6 +540,18 @@ static int launch_waves(const PlanDev &plan, const RunArgs &args, hipStream_t st
 template <typename T, int D, int MODE>
 static int launch_one(const PlanDev &plan, const RunArgs &args, hipStream_t stream) {
   if (args.Np <= 0) return KDEHIP_OK;
+  if (args.table_build) {  // the table-only instantiation: 4 wavefronts per workgroup, no tile pool
+    if constexpr (MODE != kModeGeneric) {
+      constexpr int TW = 4;
+      const int64_t blocks = (args.Np + TW - 1) / TW;
+      hipLaunchKernelGGL((gibbs_product_kernel<T, D, MODE, TW, true>), dim3(static_cast<unsigned>(blocks)), dim3(TW * 64), 0,
+                         stream, plan, args);
+      const hipError_t e = hipGetLastError();
+      if (e != hipSuccess)
+        return set_error(KDEHIP_ERR_HIP, std::string("table build launch failed: ") + hipGetErrorString(e));
+      return KDEHIP_OK;
+    }
+  }
   const int waves = chains_per_workgroup(args.Np, args.variant);
   if (waves == 16) launch_waves<T, D, MODE, 16>(plan, args, stream);
   else if (waves == 8) launch_waves<T, D, MODE, 8>(plan, args, stream);

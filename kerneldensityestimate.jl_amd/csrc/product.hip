@@ -827,6 +827,39 @@ int kdehip_prod_philox_device(int Ndens, kdehip_device_density *const *trees, in
   return KDEHIP_OK;
 }
 
+// The same with HOST output buffers, blocking: what a host without device arrays of its own (a Julia caller without
+// AMDGPU.jl) uses once its densities are uploaded -- no host re-layout, no upload of tiles, one copy back.
+int kdehip_prod_philox_resident(int Ndens, kdehip_device_density *const *trees, int64_t Np, int Niter, uint64_t seed,
+                                int addEntropy, const uint8_t *partialDimMask, int precision, double *pts, int64_t *ind) {
+  if (Ndens < 1 || !trees || !trees[0]) return set_error(KDEHIP_ERR_ARG, "need at least one density");
+  if (Np < 0) return set_error(KDEHIP_ERR_ARG, "Np must be >= 0");
+  if (Np > 0 && (!pts || !ind)) return set_error(KDEHIP_ERR_ARG, "null output pointer");
+  if (Np == 0) return KDEHIP_OK;
+  const size_t D = trees[0]->D, M = Ndens;
+  DeviceGuard guard;
+  int rc = guard.enter(trees[0]->device);
+  if (rc != KDEHIP_OK) return rc;
+  const size_t off_i = align256(sizeof(double) * D * Np), span = off_i + sizeof(int64_t) * M * Np;
+  void *d_out = nullptr, *h_out = nullptr;
+  KDEHIP_CHECK(cached_malloc(&d_out, span));
+  hipError_t e = cached_host_malloc(&h_out, span);
+  if (e != hipSuccess) { cached_free(d_out, span); return set_error(KDEHIP_ERR_HIP, "pinned result block"); }
+  unsigned char *w = static_cast<unsigned char *>(d_out);
+  rc = kdehip_prod_philox_device(Ndens, trees, Np, Niter, seed, 0, addEntropy, partialDimMask, precision,
+                                 reinterpret_cast<double *>(w), reinterpret_cast<int64_t *>(w + off_i), nullptr, nullptr);
+  if (rc == KDEHIP_OK) e = hipMemcpyAsync(h_out, d_out, span, hipMemcpyDeviceToHost, nullptr);
+  const hipError_t se = hipStreamSynchronize(nullptr);  // (also before the blocks go back to the caches on an error)
+  if (rc == KDEHIP_OK && e == hipSuccess && se == hipSuccess) {
+    std::memcpy(pts, h_out, sizeof(double) * D * Np);
+    std::memcpy(ind, static_cast<unsigned char *>(h_out) + off_i, sizeof(int64_t) * M * Np);
+  }
+  cached_host_free(h_out, span);
+  cached_free(d_out, span);
+  if (rc != KDEHIP_OK) return rc;
+  if (e != hipSuccess || se != hipSuccess) return set_error(KDEHIP_ERR_HIP, "device product: result copy failed");
+  return KDEHIP_OK;
+}
+
 // ---- resident multi-GPU plans: one plan per device, chains in contiguous ranges, one all-gather ----------------
 struct kdehip_product_multi {
   int first_device = 0, ngpus = 0;

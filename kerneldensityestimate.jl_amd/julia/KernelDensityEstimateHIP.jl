@@ -186,6 +186,54 @@ function prodAppxMSGibbsS(npd0::BallTreeDensity, trees::Array{BallTreeDensity,1}
 end
 
 """
+    DeviceDensity(bd; device=0)
+
+A `BallTreeDensity` uploaded ONCE and kept in HBM (`kdehip_density_upload`; include/kdehip.h section 2c).  Products of
+such densities -- `prodAppxMSGibbsS(npd0, ::Vector{DeviceDensity}, ...)` -- are laid out into tiles by the GPU: no host
+re-layout, no upload per product.  `free!(d)` releases it (also run by the finalizer).
+"""
+mutable struct DeviceDensity
+  handle::Ptr{Cvoid}
+  npts::Int
+  ndim::Int
+  function DeviceDensity(bd::BallTreeDensity; device::Int=0)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    cd = Ref(CDensity(bd))
+    GC.@preserve bd begin
+      check(ccall((:kdehip_density_upload, libkdehip), Cint, (Ref{Ptr{Cvoid}}, Ref{CDensity}, Cint), h, cd, device))
+    end
+    d = new(h[], Npts(bd), Ndim(bd))
+    finalizer(free!, d)
+    return d
+  end
+end
+function free!(d::DeviceDensity)
+  if d.handle != C_NULL
+    ccall((:kdehip_density_free, libkdehip), Cvoid, (Ptr{Cvoid},), d.handle)
+    d.handle = C_NULL
+  end
+  nothing
+end
+
+function prodAppxMSGibbsS(npd0, trees::Vector{DeviceDensity}, anFcns, anParams;
+                          Niter::Int=3, addEntropy::Bool=true, ndims::Integer=maximum(t.ndim for t in trees),
+                          Ndens=length(trees), Np=(npd0 isa BallTreeDensity ? Npts(npd0) : Int(npd0)),
+                          partialDimMask::AbstractVector{<:BitVector}=[ones(Int, ndims) .== 1 for i in 1:length(trees)],
+                          seed::Union{Nothing,UInt64}=nothing, precision::Int=64)
+  points = zeros(ndims * Np)
+  indices = ones(Int, Ndens, Np)
+  handles = Ptr{Cvoid}[t.handle for t in trees]
+  mask = maskbytes(partialDimMask, Ndens, ndims)
+  s = seed === nothing ? rand(UInt64) : seed
+  GC.@preserve trees handles mask begin
+    check(ccall((:kdehip_prod_philox_resident, libkdehip), Cint,
+                (Cint, Ptr{Ptr{Cvoid}}, Int64, Cint, UInt64, Cint, Ptr{UInt8}, Cint, Ptr{Float64}, Ptr{Int64}),
+                Ndens, handles, Np, Niter, s, addEntropy ? 1 : 0, mask, precision, points, indices))
+  end
+  return reshape(points, ndims, Np), indices
+end
+
+"""
     evaluateDualTree(bd, pos, lvFlag=false)
 
 `evaluateDualTree` / `bd(pos)` with the reference's default `FORCE_EVAL_DIRECT = true`

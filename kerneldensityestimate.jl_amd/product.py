@@ -240,6 +240,22 @@ def prodAppxMSGibbsS_device(trees, d_points, d_indices, *, Np, Niter=3, seed=0, 
         ProductPlan._addr(d_labels), ProductPlan._addr(stream)))
 
 
+def prodAppxMSGibbsS_resident(trees, *, Np, Niter=3, seed=0, addEntropy=True, partialDimMask=None, precision=64):
+    """`prodAppxMSGibbsS` on `DeviceDensity` inputs with host outputs (blocking): returns (points[ndims, Np],
+    indices[Ndens, Np]) -- the numbers of `prodAppxMSGibbsS(..., seed=seed)` without the per-call host re-layout and
+    upload."""
+    trees = list(trees)
+    M, D = len(trees), trees[0].dims
+    arr = (C.c_void_p * M)(*[t._h for t in trees])
+    mask = _mask_array(partialDimMask, M, D)
+    pts = np.zeros(D * Np)
+    ind = np.ones(M * Np, dtype=np.int64)
+    _lib.check(_lib.lib.kdehip_prod_philox_resident(M, arr, int(Np), int(Niter), C.c_uint64(int(seed) & (2 ** 64 - 1)),
+                                                    int(bool(addEntropy)), None if mask is None else ptr(mask, u8p),
+                                                    int(precision), ptr(pts, f64p), ptr(ind, i64p)))
+    return pts.reshape(Np, D).T.copy(), ind.reshape(Np, M).T.copy()
+
+
 def philox_streams(seed, sample_begin, nsamples, K, R):
     """Host twin of the device RNG: the (randU, randN) arrays a Philox run consumes
     (kdehip_philox_fill_uniform / _normal)."""

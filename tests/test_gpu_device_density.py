@@ -58,6 +58,9 @@ def test_device_resident_product_equals_host_packed_product(D, Ns, Np, Niter, we
     torch.cuda.synchronize()
     assert np.array_equal(I2.cpu().numpy().reshape(Np - half, M).T, ref_i[:, half:])
     assert np.array_equal(P2.cpu().numpy().reshape(Np - half, D).T, ref_p[:, half:])
+    # host outputs (the route of a host without device arrays of its own)
+    rp, ri = kdehip.prodAppxMSGibbsS_resident(dd, Np=Np, Niter=Niter, seed=seed, precision=prec)
+    assert np.array_equal(ri, ref_i) and np.array_equal(rp, ref_p)
     for d in dd:
         d.close()
     kdehip._clib.kdehip_clear_cache()

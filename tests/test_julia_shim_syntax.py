@@ -92,6 +92,8 @@ JULIA_TO_C = {
     "Ptr{Float64}": {"double*"}, "Ptr{Int64}": {"int64_t*"}, "Ptr{Int32}": {"int32_t*"}, "Ref{Int32}": {"int32_t*"},
     "Ptr{UInt8}": {"uint8_t*"}, "Ptr{CDensity}": {"kdehip_density*"}, "Ref{CDensity}": {"kdehip_density*"},
     "Cstring": {"char*"}, "Cvoid": {"void"},
+    "Ptr{Cvoid}": {"kdehip_device_density*"}, "Ref{Ptr{Cvoid}}": {"kdehip_device_density**"},
+    "Ptr{Ptr{Cvoid}}": {"kdehip_device_density**"},
 }
 
 
@@ -182,6 +184,7 @@ def test_prodAppxMSGibbsS_keyword_surface_is_the_references():
     sigs = _signatures(code, "prodAppxMSGibbsS")
     kw_sigs = [s for s in sigs if ";" in s]
     pos_sigs = [s for s in sigs if ";" not in s]
+    kw_sigs = [s for s in kw_sigs if "DeviceDensity" not in s]   # (the device-resident method has its own, shorter list)
     assert len(kw_sigs) == 2, "module-level front end + the override installed by enable!()"
     for s in kw_sigs:
         names = _keyword_names(s)
