@@ -10,7 +10,7 @@
 //     (gaussianProductMeanCov!, src/MSGibbs01.jl:176-216) is M-1 register adds, adopting a drawn kernel
 //     (updateGlbParticlesVariance!, :89-115) is one LDS gather + reciprocal, and no LDS round trip or
 //     wavefront fence separates consecutive steps;
-//   * the M level descriptors are read once per level (scalar registers) instead of once per step;
+//   * a step's few descriptor fields are detached from the 16-dword scalar load into registers of their own (LeanTile);
 //   * the D*(L+1) normal deviates of a chain are produced (Philox) or fetched (caller's randN) once, lane-parallel,
 //     into a per-wavefront LDS strip, instead of D at a time at every level.
 // Results: labels identical to gibbs_kernel.hip and to the oracle, points bit-identical to gibbs_kernel.hip
@@ -82,12 +82,15 @@ struct LeanTile {
   }
 };
 
-template <typename T, int D, int M, int WAVES>
+// TEAMS: the instantiation whose wavefronts can form teams (RunArgs.team = 2 or 4; 16-wavefront fp64 builds).  A kernel
+// of its own: with the team paths compiled in, a 16-wavefront build is up to 25 % slower even when every chain has one
+// wavefront (config 4 with 16,384 chains: 31 -> 39 ms), and that is the build large batches run.
+template <typename T, int D, int M, int WAVES, bool TEAMS = false>
 __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan, RunArgs a) {
   constexpr bool kPrefetchRows = (WAVES <= 12) || sizeof(T) == 4 || D <= 4;  // as in gibbs_kernel.hip
   constexpr bool kKeptRows = (WAVES <= 8);
   // wavefront teams (a chain on 2 or 4 wavefronts, RunArgs.team): the 16-wavefront fp64 builds
-  constexpr bool kTeams = (WAVES == 16) && sizeof(T) == 8;
+  constexpr bool kTeams = TEAMS && (WAVES == 16) && sizeof(T) == 8;
   // LDS: [exp table 2 KiB][normals: 1 KiB per chain; teams: the partial-sum strips in the upper half][uniforms:
   // WAVES x 1 KiB][teams: 2 KiB of segment notes][tile pool]
   constexpr int kNormOff = 2048;
@@ -106,8 +109,12 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan, Ru
   int tsize = 1;
   if constexpr (kTeams) tsize = a.team == 4 ? 4 : (a.team == 2 ? 2 : 1);
   const int tshift = tsize >> 1;  // log2 of 1, 2, 4
-  const int tmember = wave & (tsize - 1);
-  const int chain = wave >> tshift;
+  // Members of a team are WAVES / team wavefronts apart: a workgroup's wavefronts go to the SIMDs in a cyclic order of
+  // four (scripts/micro/simd_map.hip), so the first members -- who walk the shallow levels alone -- are spread evenly
+  // over the four SIMDs (adjacent wavefronts as a team would park all first members on two of them).
+  const int chains_wg = WAVES >> tshift;
+  const int tmember = wave / chains_wg;
+  const int chain = wave - tmember * chains_wg;
   int64_t s = static_cast<int64_t>(blockIdx.x) * (WAVES >> tshift) + chain;
   const bool in_range = s < a.Np;  // surplus wavefronts of the last workgroup replay the last chain and store nothing
   if (!in_range) s = a.Np - 1;
@@ -306,13 +313,17 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan, Ru
       product(IC<-1>{}, mean, cov);
       x = mean + Num<T>::sqrt(cov) * static_cast<T>(sNorm[(l - 1) * D + dl]);
     }
-    LeanTile<D> dsc[M];
-    int level_mode = 0;
-    static_for<M>([&](auto jc) {
-      const LevelDesc d = levels[decltype(jc)::value * (L + 1) + l];
-      dsc[decltype(jc)::value].load(d);
-      if constexpr (decltype(jc)::value == 0) level_mode = scalar_copy(d.stage_mode);
-    });
+    // Every step fetches its own tile descriptor -- and its successor's, whose tile it stages -- from the scalar cache
+    // (one s_load_dwordx16 each, issued a step's worth of work before use).  Keeping the level's M descriptors in
+    // scalar registers instead (round 2) crowds the register file: M x 7 live fields pushed the 16-wavefront builds into
+    // scratch in their per-step code (config 4 with 16,384 chains: 39 ms against 31 ms; config 3: 4.32 against 4.22 ms)
+    // and bought the 8-wavefront builds nothing (0.6255 against 0.6222 ms).
+    const int level_mode = scalar_copy(levels[l].stage_mode);
+    auto tile = [&](int j) -> LeanTile<D> {  // (j is a compile-time constant at every call site)
+      LeanTile<D> t;
+      t.load(levels[j * (L + 1) + l]);
+      return t;
+    };
     const int mode = vlev == 1 ? int(kStageGlobal) : level_mode;
     const bool tabulated = (l <= Lt);
     const int npass = tabulated ? 1 : a.Niter + 1;  // tabulated levels: only the sampleIndices! pass runs here
@@ -321,26 +332,30 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan, Ru
     if (mode == kStageResident) {
       staging_barrier();  // every wavefront is done reading the previous level's images
       static_for<M>([&](auto jc) {
-        const LeanTile<D> &ds = dsc[decltype(jc)::value];
+        const LeanTile<D> ds = tile(decltype(jc)::value);
         stage_tile<WAVES>(reinterpret_cast<const unsigned char *>(data + ds.hdr_off()), pool + ds.lds_off, ds.stage_bytes, wave, lane);
       });
       staging_barrier();
       if (active)
         for (int p = 0; p < npass; ++p)
           static_for<M>([&](auto jc) {
-            const LeanTile<D> &ds = dsc[decltype(jc)::value];
+            const LeanTile<D> ds = tile(decltype(jc)::value);
             step(jc, ds, (LdsPtr<T>)(pool + ds.lds_off), p == 0, x);
           });
     } else if (mode == kStageStream) {
       staging_barrier();
-      stage_tile<WAVES>(reinterpret_cast<const unsigned char *>(data + dsc[0].hdr_off()), pool, dsc[0].stage_bytes, wave, lane);
+      {
+        const LeanTile<D> d0 = tile(0);
+        stage_tile<WAVES>(reinterpret_cast<const unsigned char *>(data + d0.hdr_off()), pool, d0.stage_bytes, wave, lane);
+      }
       int t = 0;
       const int nsteps = npass * M;
       for (int p = 0; p < npass; ++p)
         static_for<M>([&](auto jc) {
           constexpr int j = decltype(jc)::value;
           constexpr int jn = (j + 1 == M) ? 0 : j + 1;
-          const LeanTile<D> &ds = dsc[j];
+          const LeanTile<D> ds = tile(j);
+          const LeanTile<D> dn = tile(jn);  // the next step's tile (staged during this step)
           T mean = x, cov = T(0);
           double u = 0.0;
           if (active) {
@@ -351,8 +366,8 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan, Ru
           // read in step t-1, which everyone has left -> start the next copy
           staging_barrier();
           if (t + 1 < nsteps)
-            stage_tile<WAVES>(reinterpret_cast<const unsigned char *>(data + dsc[jn].hdr_off()),
-                              pool + ((t + 1) & 1) * (kLdsPoolBytes / 2), dsc[jn].stage_bytes, wave, lane);
+            stage_tile<WAVES>(reinterpret_cast<const unsigned char *>(data + dn.hdr_off()),
+                              pool + ((t + 1) & 1) * (kLdsPoolBytes / 2), dn.stage_bytes, wave, lane);
           if (active) {
             auto hdr = (LdsPtr<T>)(pool + (t & 1) * (kLdsPoolBytes / 2));
             auto rows = hdr + kTileHeader;
@@ -368,14 +383,15 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan, Ru
       // chunk, the copy of chunk g+1 overlaps the evaluation of chunk g); the second pass and the new kernel are
       // read from global memory.  (Chunked levels are always shared by a team: lean_geometry.)
       staging_barrier();
-      stage_chunk(dsc[0], 0, gchunk & 1);
+      stage_chunk(tile(0), 0, gchunk & 1);
       int t = 0;
       const int nsteps = npass * M;
       for (int p = 0; p < npass; ++p)
         static_for<M>([&](auto jc) {
           constexpr int j = decltype(jc)::value;
           constexpr int jn = (j + 1 == M) ? 0 : j + 1;
-          const LeanTile<D> &ds = dsc[j];
+          const LeanTile<D> ds = tile(j);
+          const LeanTile<D> dn = tile(jn);  // the next step's tile (its first chunk is staged during this step's last)
           T mean = x, cov = T(0);
           if (p != 0) product(jc, mean, cov);
           const double u = next_uniform();
@@ -388,13 +404,13 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan, Ru
             SegSums<T> seg;
             const int cps = seg_chunks(rc);
             const bool use_seg = seg_applies(ds.B, rc);
-            bool shared = false;
-            if constexpr (kTeams) shared = shared_level;
+            // (a chunked level is always a shared one, and the team instantiation only runs with teams: lean_geometry)
+            constexpr bool shared = kTeams;
             int cin = 0;
             for (int r0 = 0; r0 < ds.B; r0 += rc, ++gchunk) {
               staging_barrier();  // this chunk has landed for every wavefront; the other half is free again
               if (r0 + rc < ds.B) stage_chunk(ds, r0 + rc, (gchunk + 1) & 1);
-              else if (t + 1 < nsteps) stage_chunk(dsc[jn], 0, (gchunk + 1) & 1);
+              else if (t + 1 < nsteps) stage_chunk(dn, 0, (gchunk + 1) & 1);
               const int nrows = (ds.B - r0 < rc) ? (ds.B - r0) : rc;
               const auto crows = (LdsPtr<T>)(pool + (gchunk & 1) * (kLdsPoolBytes / 2));
               if (shared)
@@ -427,7 +443,7 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan, Ru
       if (active)
         for (int p = 0; p < npass; ++p)
           static_for<M>([&](auto jc) {
-            const LeanTile<D> &ds = dsc[decltype(jc)::value];
+            const LeanTile<D> ds = tile(decltype(jc)::value);
             step(jc, ds, data + ds.hdr_off(), p == 0, x);
           });
     }
@@ -453,7 +469,7 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan, Ru
           int pos;
           if (!(total >= Num<T>::tiny_total())) {  // uniform fallback (:311-315), rare
             count_fallback(fb, lane);
-            const LeanTile<D> &dk = dsc[j];
+            const LeanTile<D> dk = tile(j);
             const T wl = ((LdsPtr<T>)(pool + dk.lds_off) + kTileHeader)[(dk.F - 1) * 64 + (n - 1)];
             int z = n - 1;
             if (wl > T(0)) {
@@ -473,7 +489,8 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan, Ru
       static_for<M>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
         const int pk = static_cast<int>((word >> td[j].shift) & ((1u << td[j].bits) - 1u));
-        adopt(jc, dsc[j], (LdsPtr<T>)(pool + dsc[j].lds_off), pk);
+        const LeanTile<D> dk = tile(j);
+        adopt(jc, dk, (LdsPtr<T>)(pool + dk.lds_off), pk);
       });
     }
     if (a.labels && live && lane == 0) {
@@ -510,6 +527,13 @@ template <typename T, int D, int M, int WAVES>
 static void launch_lean_waves(const PlanDev &plan, const RunArgs &args, hipStream_t stream) {
   const int chains = WAVES / (args.team > 1 ? args.team : 1);  // chains per workgroup
   const int64_t blocks = (args.Np + chains - 1) / chains;
+  if constexpr (WAVES == 16 && sizeof(T) == 8) {
+    if (args.team > 1) {
+      hipLaunchKernelGGL((gibbs_lean_kernel<T, D, M, WAVES, true>), dim3(static_cast<unsigned>(blocks)), dim3(WAVES * 64), 0,
+                         stream, plan, args);
+      return;
+    }
+  }
   hipLaunchKernelGGL((gibbs_lean_kernel<T, D, M, WAVES>), dim3(static_cast<unsigned>(blocks)), dim3(WAVES * 64), 0,
                      stream, plan, args);
 }

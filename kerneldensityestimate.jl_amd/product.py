@@ -215,7 +215,11 @@ class DeviceDensity:
             _lib.lib.kdehip_density_free(self._h)
             self._h = None
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
 
     def __enter__(self):
         return self
