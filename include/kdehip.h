@@ -243,6 +243,14 @@ int kdehip_make_density(int64_t D, int64_t N, const double *points, const double
                         int64_t *highest_leaf, int64_t *permutation, double *means,
                         double *bandwidth, double *bandwidthMin, double *bandwidthMax);
 
+/* The bandwidth-dependent half of the construction on an existing tree: topology, bounding boxes, weights and means
+ * do not depend on ks, only `bandwidth` (leaves ks^2, internal nodes by moment matching,
+ * src/BallTreeDensity01.jl:141-187) and bandwidthMin/Max do.  Lets kde!(points) build its tree while the GPU searches
+ * the LOOCV bandwidth; the result is bit-identical to kdehip_make_density called with this ks. */
+int kdehip_density_set_bandwidth(int64_t D, int64_t N, const double *ks, int64_t nks, const double *weights,
+                                 const int64_t *left_child, const int64_t *right_child, const double *means,
+                                 double *bandwidth, double *bandwidthMin, double *bandwidthMax);
+
 /* The same construction on the GPU, for a batch of `nb` densities of one dimension count (one workgroup per
  * density, level-synchronous; csrc/treebuild.hip): bit-identical arrays -- same node numbering, leaf order and
  * statistics as kdehip_make_density and the reference.  Every pointer argument is an array of nb pointers to

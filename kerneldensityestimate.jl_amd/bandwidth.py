@@ -26,9 +26,40 @@ def auto_bandwidth(points, device=0, return_evals=False):
 
 
 def kde_auto(points, device=0) -> BallTreeDensity:
-    """`kde!(points)`: LOOCV bandwidth per dimension, then `kde!(points, bwds)` (src/KDE01.jl:24)."""
-    # (one density: the host builder is the faster one -- the GPU builder pays off for batches, see kde_batch)
-    return kde(points, auto_bandwidth(points, device=device))
+    """`kde!(points)`: LOOCV bandwidth per dimension, then `kde!(points, bwds)` (src/KDE01.jl:24).
+
+    The tree's topology, bounding boxes, weights and means do not depend on the bandwidth: the host builder runs
+    WHILE the GPU searches the bandwidth (the search is a chain of ~20 dependent launches; the blocking C call releases
+    the GIL), and the variances are filled in afterwards (kdehip_density_set_bandwidth) -- bit-identical to building with
+    the final bandwidth."""
+    import threading
+    pts = np.asarray(points, dtype=np.float64)
+    if pts.ndim == 1:
+        pts = pts.reshape(1, -1)
+    D, N = pts.shape
+    if N < 2:
+        return kde(pts, auto_bandwidth(pts, device=device))
+    box = {}
+
+    def search():
+        try:
+            box["bw"] = auto_bandwidth(pts, device=device)
+        except BaseException as e:  # noqa: BLE001  (re-raised in the caller's thread)
+            box["err"] = e
+    th = threading.Thread(target=search)
+    th.start()
+    bd = kde(pts, np.ones(D))   # (one density: the host builder is the faster one; placeholder bandwidth)
+    th.join()
+    if "err" in box:
+        raise box["err"]
+    bw = np.ascontiguousarray(box["bw"], dtype=np.float64)
+    bt = bd.bt
+    i64p = _lib.i64p
+    _lib.check(_lib.lib.kdehip_density_set_bandwidth(D, N, ptr(bw, f64p), bw.size, ptr(bt.weights, f64p),
+                                                     ptr(bt.left_child, i64p), ptr(bt.right_child, i64p),
+                                                     ptr(bd.means, f64p), ptr(bd.bandwidth, f64p),
+                                                     ptr(bd.bandwidthMin, f64p), ptr(bd.bandwidthMax, f64p)))
+    return bd
 
 
 def evaluateDualTree(bd: BallTreeDensity, pos=None, lvFlag=False, errTol=1e-3, device=0):

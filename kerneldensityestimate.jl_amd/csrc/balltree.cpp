@@ -245,3 +245,69 @@ extern "C" int kdehip_make_density(int64_t D, int64_t N, const double *points, c
       .build(wnorm.data(), var.data());
   return KDEHIP_OK;
 }
+
+// The bandwidth-dependent half of kde!(points, ks, weights) on an EXISTING tree: the topology (splits, leaf order),
+// the bounding boxes, the weights and the means of makeBallTreeDensity do not depend on the bandwidth -- only
+// `bandwidth` (leaf: ks^2, src/KDE01.jl:45; internal: the moment matching of calcStatsDensity!,
+// src/BallTreeDensity01.jl:141-187) and bandwidthMin/Max do.  `kde!(points)` can therefore build its tree while the
+// GPU is still searching the LOOCV bandwidth, and fill the variances in afterwards: the same expressions on the same
+// operands in an order that keeps children before parents, i.e. bit-identical to kdehip_make_density with that ks.
+extern "C" int kdehip_density_set_bandwidth(int64_t D, int64_t N, const double *ks, int64_t nks, const double *weights,
+                                            const int64_t *left_child, const int64_t *right_child, const double *means,
+                                            double *bandwidth, double *bandwidthMin, double *bandwidthMax) {
+  using namespace kdehip;
+  if (D < 1 || N < 1) return set_error(KDEHIP_ERR_ARG, "kdehip_density_set_bandwidth: need D >= 1 and N >= 1");
+  if (nks != 1 && nks != D) return set_error(KDEHIP_ERR_ARG, "kdehip_density_set_bandwidth: ks must have 1 or D entries");
+  if (!ks || !weights || !left_child || !right_child || !means || !bandwidth || !bandwidthMin || !bandwidthMax)
+    return set_error(KDEHIP_ERR_ARG, "kdehip_density_set_bandwidth: null pointer");
+  std::vector<double> var(static_cast<size_t>(D));
+  for (int64_t k = 0; k < D; ++k) {
+    const double sd = (nks == 1) ? ks[0] : ks[k];
+    var[static_cast<size_t>(k)] = sd * sd;  // ks.^2, KDE01.jl:45
+  }
+  for (int64_t i = 0; i < N; ++i)
+    for (int64_t k = 0; k < D; ++k) {
+      bandwidth[(N + i) * D + k] = var[static_cast<size_t>(k)];
+      bandwidthMin[i * D + k] = var[static_cast<size_t>(k)];
+      bandwidthMax[i * D + k] = var[static_cast<size_t>(k)];
+    }
+  if (N == 1) {  // single-point density (BallTree01.jl:351-362): the root summarises the leaf with itself
+    const double wa0 = weights[N], wt = wa0 + wa0 + DBL_EPSILON;
+    const double wa = wa0 / wt, wb = wa0 / wt;
+    for (int64_t k = 0; k < D; ++k) {
+      const double ma = means[N * D + k], m = wa * ma + wb * ma;
+      bandwidth[k] = wa * (bandwidth[N * D + k] + ma * ma) + wb * (bandwidth[N * D + k] + ma * ma) - m * m;
+    }
+    return KDEHIP_OK;
+  }
+  // internal nodes 1 .. N-1, children before parents: an explicit post-order walk from the root
+  std::vector<int64_t> stack, order;
+  stack.reserve(64);
+  order.reserve(static_cast<size_t>(N));
+  stack.push_back(1);
+  while (!stack.empty()) {
+    const int64_t id = stack.back();
+    stack.pop_back();
+    if (id < 1 || id >= N) return set_error(KDEHIP_ERR_ARG, "kdehip_density_set_bandwidth: malformed tree");
+    order.push_back(id);
+    const int64_t a = left_child[id - 1], b = right_child[id - 1];
+    if (a <= N && a >= 1 && a != id) stack.push_back(a);
+    if (b <= N && b >= 1 && b != id) stack.push_back(b);
+    if (static_cast<int64_t>(order.size()) > N) return set_error(KDEHIP_ERR_ARG, "kdehip_density_set_bandwidth: malformed tree");
+  }
+  for (size_t t = order.size(); t-- > 0;) {  // reverse pre-order: every node after its descendants
+    const int64_t id = order[t];
+    const int64_t a = left_child[id - 1], b = right_child[id - 1];
+    if (a < 1 || a > 2 * N || b < 1 || b > 2 * N) continue;
+    double wa = weights[a - 1], wb = weights[b - 1];
+    const double wt = wa + wb + DBL_EPSILON;  // eps(Float64), BallTreeDensity01.jl:161
+    wa /= wt;
+    wb /= wt;
+    for (int64_t k = 0; k < D; ++k) {
+      const double ma = means[(a - 1) * D + k], mb = means[(b - 1) * D + k];
+      const double m = wa * ma + wb * mb;
+      bandwidth[(id - 1) * D + k] = wa * (bandwidth[(a - 1) * D + k] + ma * ma) + wb * (bandwidth[(b - 1) * D + k] + mb * mb) - m * m;
+    }
+  }
+  return KDEHIP_OK;
+}

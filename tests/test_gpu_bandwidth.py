@@ -121,3 +121,18 @@ def test_star_product():
     # hack fix for #70 (:713-716): one density, no entropy -> kde!(its own points)
     one = kdehip.mul([p], addEntropy=False)
     assert np.allclose(kdehip.getPoints(one), kdehip.getPoints(p))
+
+
+def test_kde_auto_builds_its_tree_under_the_search_and_equals_the_sequential_form():
+    """`kde!(points)` = LOOCV bandwidth, then `kde!(points, bw)` (src/KDE01.jl:3-27).  The mirror builds the tree on the host
+    WHILE the GPU searches (topology and means do not depend on the bandwidth) and fills the variances in afterwards:
+    every array must be bit-identical to the two steps run one after the other."""
+    rng = np.random.default_rng(21)
+    for D, N in [(1, 100), (3, 257), (6, 2048)]:
+        pts = rng.standard_normal((D, N)) * rng.uniform(0.5, 2.0, size=(D, 1))
+        a = kdehip.kde_auto(pts)
+        b = kdehip.kde(pts, kdehip.auto_bandwidth(pts))
+        for f in ("means", "bandwidth", "bandwidthMin", "bandwidthMax"):
+            assert np.array_equal(getattr(a, f), getattr(b, f)), (D, N, f)
+        for f in ("centers", "ranges", "weights", "left_child", "right_child", "permutation"):
+            assert np.array_equal(getattr(a.bt, f), getattr(b.bt, f)), (D, N, f)

@@ -206,3 +206,28 @@ def test_prod_front_end_keyword_surface():
         kdehip.prodAppxMSGibbsS(p, [p, p], None, None, randU=np.zeros(10))
     with pytest.raises(TypeError):
         kdehip.prodAppxMSGibbsS(p, [p, p], None, None, 3, 4)
+
+
+def test_set_bandwidth_equals_building_with_that_bandwidth():
+    """kdehip_density_set_bandwidth recomputes the bandwidth-dependent statistics of an existing tree (leaf variances,
+    moment-matched variances of the internal nodes, src/BallTreeDensity01.jl:141-187): bit-identical to
+    kdehip_make_density with that bandwidth -- what lets kde!(points) build its tree while the GPU searches the bandwidth."""
+    from kdehip import _lib
+    from kdehip._lib import f64p, i64p, ptr
+    rng = np.random.default_rng(0)
+    for D, N, weighted in [(1, 1, False), (2, 2, False), (1, 3, False), (3, 37, True), (2, 100, True), (6, 1500, False)]:
+        pts = rng.standard_normal((D, N))
+        pts[:, : N // 3] = pts[:, N // 3: 2 * (N // 3)]          # ties
+        w = rng.uniform(0.1, 1.0, N) if weighted else None
+        bw = rng.uniform(0.1, 0.9, D)
+        ref = kdehip.kde(pts, bw, w)
+        bd = kdehip.kde(pts, np.ones(D), w)
+        bt = bd.bt
+        rc = _lib.lib.kdehip_density_set_bandwidth(D, N, ptr(bw, f64p), bw.size, ptr(bt.weights, f64p), ptr(bt.left_child, i64p),
+                                                   ptr(bt.right_child, i64p), ptr(bd.means, f64p), ptr(bd.bandwidth, f64p),
+                                                   ptr(bd.bandwidthMin, f64p), ptr(bd.bandwidthMax, f64p))
+        assert rc == 0
+        for f in ("means", "bandwidth", "bandwidthMin", "bandwidthMax"):
+            assert np.array_equal(getattr(bd, f), getattr(ref, f)), (D, N, f)
+        for f in ("centers", "ranges", "weights", "left_child", "right_child", "permutation", "lowest_leaf", "highest_leaf"):
+            assert np.array_equal(getattr(bd.bt, f), getattr(ref.bt, f)), (D, N, f)
