@@ -8,7 +8,7 @@
 //
 // Mapping (MI355X-first, not a translation of the Julia loop nest):
 //   * one 64-lane wavefront owns one output sample (one Gibbs chain); chains never communicate.
-//     4, 8, 12 or 16 chains (picked per launch, see launch_one) share a workgroup, one workgroup per CU,
+//     4, 8 or 16 chains (picked per launch, see launch_one) share a workgroup, one workgroup per CU,
 //     and walk the data-independent (level, pass, density) schedule in lock step so that the tile every wavefront
 //     is about to read is staged ONCE per workgroup into LDS with direct-to-LDS loads
 //     (buffer_load_dwordx4 ... lds): levels whose tiles all fit the 120 KiB pool stay resident for the
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan,
   unsigned char *pool = smem + Lay::kPoolOff;
   const int dl = lane < D ? lane : D - 1;  // this lane's dimension in the "lanes = dimensions" phases
 
-  // variant: 0 default; 1 = read every tile from global memory (no LDS staging); 2 / 8 / 12 / 16 = 4 / 8 / 12 / 16 chains per workgroup.
+  // variant: 0 default; 1 = read every tile from global memory (no LDS staging); 2 / 8 / 16 = 4 / 8 / 16 chains per workgroup.
   // Diagnostic builds (-DKDEHIP_EXPERIMENTS, scripts/) add level cut-offs and ablation flags.
   const int vlev = a.variant % 1000;
 #ifdef KDEHIP_EXPERIMENTS

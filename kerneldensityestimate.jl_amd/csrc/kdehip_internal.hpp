@@ -193,7 +193,7 @@ int device_cu_count();
 
 int launch_gibbs(int precision, int mode, const PlanDev &plan, const RunArgs &args, void *stream);
 
-// Chains per workgroup (= wavefronts per CU, one workgroup per CU at a time) of a sampling launch: 4, 8, 12 or 16,
+// Chains per workgroup (= wavefronts per CU, one workgroup per CU at a time) of a sampling launch: 4, 8 or 16,
 // the width with the smallest estimated time rounds(width) * cost(width) unless `variant` pins it
 // (kdehip_product_set_variant).  Shared by both sampler kernels.
 int chains_per_workgroup(int64_t Np, int variant);

@@ -86,3 +86,23 @@ def test_partial_product_acceptance():
     pGM, _ = oracle.gibbs1(trees, 100, 3, rng.random(nU), rng.standard_normal(nN), partialDimMask=mask)
     assert 80 < int(((0 < pGM[0]) & (pGM[0] < 10)).sum())
     assert 80 < int(((-10 < pGM[1]) & (pGM[1] < 0)).sum())
+
+
+def test_oracle_label_tuples_follow_the_exact_mixture_weights():
+    """The CPU oracle against mathematics (see tests/test_gpu_exact_mixture.py): final label tuples of a tiny product
+    distributed like the analytic component weights of the product mixture."""
+    from tests.test_gpu_exact_mixture import exact_component_weights, make_case
+    D, Ns, weighted = 2, [4, 3, 4], True
+    pts, sds, ws = make_case(100 + D + len(Ns), D, Ns, weighted)
+    exact, mean, var = exact_component_weights(pts, sds, ws)
+    trees = [oracle.OracleDensity(p, s, w) for p, s, w in zip(pts, sds, ws)]
+    Np, Niter = 40_000, 25
+    K, R, nU, nN = oracle.rng_sizes(len(Ns), D, Np, Niter, Ns)
+    rng = np.random.default_rng(7)
+    x, ind = oracle.gibbs1(trees, Np, Niter, rng.random(nU), rng.standard_normal(nN), nthreads=8)
+    labels, counts = np.unique(ind.T, axis=0, return_counts=True)
+    freq = {tuple(int(v) for v in lab): c / Np for lab, c in zip(labels, counts)}
+    for combo, w in exact.items():
+        se = np.sqrt(max(w * (1 - w), 1e-12) / Np)
+        assert abs(freq.get(combo, 0.0) - w) < 5.0 * se + 2e-4, (combo, w, freq.get(combo, 0.0))
+    assert np.all(np.abs(x.mean(axis=1) - mean) < 5.0 * np.sqrt(var / Np) + 1e-3)
