@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Thread-safety soak: several host threads call the blocking entry points concurrently on one device (one-shot
-products with device Philox and with caller streams, resident-plan samples, evaluation, LOOCV bandwidth); every result
+products with device Philox and with caller streams, products of densities kept in HBM -- shared handles --, evaluation,
+LOOCV bandwidth); every result
 must equal the single-threaded one.   python scripts/soak_threads.py [threads] [calls per thread]"""
 import os
 import sys
@@ -27,7 +28,8 @@ for c in range(24):   # a pool of prepared problems with their single-threaded a
     randU, randN = rng.random(nU), rng.standard_normal(nN)
     pos = rng.standard_normal((D, 300))
     x = rng.standard_normal((D, 400))
-    jobs.append(dict(trees=trees, Np=Np, Niter=Niter, randU=randU, randN=randN, pos=pos, x=x, seed=c,
+    jobs.append(dict(trees=trees, dd=[kdehip.DeviceDensity(t) for t in trees], Np=Np, Niter=Niter, randU=randU, randN=randN,
+                     pos=pos, x=x, seed=c,
                      a=kdehip.prodAppxMSGibbsS(None, trees, None, None, Niter=Niter, Np=Np, seed=c),
                      b=kdehip.prodAppxMSGibbsS(None, trees, None, None, Niter=Niter, Np=Np, randU=randU, randN=randN),
                      e=trees[0](pos), bw=kdehip.auto_bandwidth(x)))
@@ -38,7 +40,7 @@ def worker(t):
     bad = 0
     for _ in range(ncalls):
         j = jobs[int(r.integers(0, len(jobs)))]
-        kind = int(r.integers(0, 4))
+        kind = int(r.integers(0, 5))
         if kind == 0:
             got = kdehip.prodAppxMSGibbsS(None, j["trees"], None, None, Niter=j["Niter"], Np=j["Np"], seed=j["seed"])
             ok = np.array_equal(got[0], j["a"][0]) and np.array_equal(got[1], j["a"][1])
@@ -47,6 +49,9 @@ def worker(t):
             ok = np.array_equal(got[0], j["b"][0]) and np.array_equal(got[1], j["b"][1])
         elif kind == 2:
             ok = np.array_equal(j["trees"][0](j["pos"]), j["e"])
+        elif kind == 4:   # densities resident in HBM, handles shared by all threads; the plan queue is shared state
+            got = kdehip.prodAppxMSGibbsS_resident(j["dd"], Np=j["Np"], Niter=j["Niter"], seed=j["seed"])
+            ok = np.array_equal(got[0], j["a"][0]) and np.array_equal(got[1], j["a"][1])
         else:
             ok = np.array_equal(kdehip.auto_bandwidth(j["x"]), j["bw"])
         bad += not ok
