@@ -65,7 +65,9 @@ int kdehip_device_count(void); /* 0 when no device is usable */
 void kdehip_clear_cache(void);
 
 /* ---- (1) drop-in for gibbs1 (reference src/MSGibbs01.jl:527-537) ------------------------------
- * Host buffers in, host buffers out, blocking.  Arguments in the reference's order:
+ * Host buffers in, host buffers out, blocking.  The blocking entry points of this header are thread-safe and enqueue
+ * their work on the calling thread's own stream (hipStreamPerThread): calls of concurrent host threads overlap on the
+ * device instead of queueing behind each other on the null stream.  Arguments in the reference's order:
  *   Ndens, trees, Np, Niter, pts (out, ndims*Np), ind (out, Ndens*Np, = permutation+1, :615),
  *   randU (nU values), randN (nN values), then the keywords addEntropy, ndims, partialDimMask
  *   (Ndens*ndims bytes, density-major, 1 = active; NULL = all active).  `device` = HIP ordinal.
@@ -218,7 +220,7 @@ int kdehip_prod_philox_device(int Ndens, kdehip_device_density *const *trees, in
 
 /* The same with host output buffers (pts: ndims*Np, ind: Ndens*Np), blocking: for hosts that keep no device arrays of
  * their own -- a Julia caller without AMDGPU.jl uploads its densities once and then pays neither the host re-layout
- * nor the upload of the tiles per product (sample offset 0, default stream). */
+ * nor the upload of the tiles per product (sample offset 0). */
 int kdehip_prod_philox_resident(int Ndens, kdehip_device_density *const *trees, int64_t Np, int Niter, uint64_t seed,
                                 int addEntropy, const uint8_t *partialDimMask, int precision, double *pts, int64_t *ind);
 

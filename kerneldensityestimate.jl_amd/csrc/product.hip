@@ -55,6 +55,11 @@ namespace {
       return set_error(KDEHIP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
   } while (0)
 
+// The stream of the BLOCKING entry points (host buffers in and out): the calling thread's own stream.  On the legacy
+// null stream the calls of concurrent host threads -- a multi-threaded belief-propagation host issues many small
+// products at once -- would run one after the other on the device although each of them fills a fraction of it.
+inline hipStream_t call_stream() { return hipStreamPerThread; }
+
 int check_run(const kdehip_product *plan, int64_t Np, int Niter, const void *d_points,
               const void *d_indices) {
   if (!plan) return set_error(KDEHIP_ERR_ARG, "null plan");
@@ -107,8 +112,8 @@ struct OutPiece { void *host; size_t dev_off, bytes; };
 int copy_out(const void *d_base, size_t span, const OutPiece *pieces, int npieces) {
   void *h = nullptr;
   KDEHIP_CHECK(cached_host_malloc(&h, span));
-  hipError_t e = hipMemcpyAsync(h, d_base, span, hipMemcpyDeviceToHost, nullptr);
-  if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+  hipError_t e = hipMemcpyAsync(h, d_base, span, hipMemcpyDeviceToHost, call_stream());
+  if (e == hipSuccess) e = hipStreamSynchronize(call_stream());
   if (e == hipSuccess)
     for (int i = 0; i < npieces; ++i)
       if (pieces[i].host && pieces[i].bytes) std::memcpy(pieces[i].host, static_cast<unsigned char *>(h) + pieces[i].dev_off, pieces[i].bytes);
@@ -290,7 +295,7 @@ void bind_plan(kdehip_product *p, size_t off_lev, size_t off_count, size_t off_t
 // A plan on `device` from an image: one device allocation, one DMA transfer (hipMalloc / hipFree cost tens of
 // microseconds each and would dominate a one-shot small product; blocks come from the library's cache).
 // wait = false (one-shot calls, whose image outlives the work they enqueue): the upload is left in flight on the
-// null stream; everything the caller enqueues there afterwards is ordered behind it.
+// calling thread's stream (call_stream); everything the caller enqueues there afterwards is ordered behind it.
 int instantiate(const PlanImage &im, int device, kdehip_product **out, bool wait = true) {
   *out = nullptr;
   kdehip_product *p = new (std::nothrow) kdehip_product();
@@ -305,8 +310,8 @@ int instantiate(const PlanImage &im, int device, kdehip_product **out, bool wait
   p->mode = !p->host.fast ? kModeGeneric : (p->host.all_active ? kModeFast : kModeFastMasked);
   hipError_t e = cached_malloc(&p->d_blob, im.total);
   if (e == hipSuccess) p->blob_bytes = im.total;
-  if (e == hipSuccess) e = hipMemcpyAsync(p->d_blob, im.h_blob, im.off_tables, hipMemcpyHostToDevice, nullptr);
-  if (e == hipSuccess && wait) e = hipStreamSynchronize(nullptr);  // (the pinned image may be recycled after this call)
+  if (e == hipSuccess) e = hipMemcpyAsync(p->d_blob, im.h_blob, im.off_tables, hipMemcpyHostToDevice, call_stream());
+  if (e == hipSuccess && wait) e = hipStreamSynchronize(call_stream());  // (the pinned image may be recycled after this call)
   if (e != hipSuccess) {
     const std::string m = std::string("plan upload: ") + hipGetErrorString(e);
     kdehip_product_destroy(p);
@@ -493,7 +498,7 @@ int kdehip_product_sample_philox_host(kdehip_product *plan, int64_t Np, int Nite
   int32_t *dl = labels ? reinterpret_cast<int32_t *>(w + off_l) : nullptr;
   // (this call's run is waited for by the blocking copies below, so it never marks the plan "async pending";
   // the flag is only ever set, by the device-pointer entry points, and read by kdehip_product_destroy)
-  rc = enqueue_philox(plan, Np, Niter, seed, sample_offset, addEntropy, dp, di, dl, nullptr);
+  rc = enqueue_philox(plan, Np, Niter, seed, sample_offset, addEntropy, dp, di, dl, call_stream());
   if (rc != KDEHIP_OK) return rc;
   const size_t lab_bytes = labels ? sizeof(int32_t) * M * L * Np : 0;
   const OutPiece out[3] = {{points, 0, sizeof(double) * D * Np}, {indices, off_i, sizeof(int64_t) * M * Np},
@@ -541,7 +546,7 @@ int one_shot(int Ndens, const kdehip_density *trees, int64_t Np, int Niter, doub
     std::vector<int> devs;
     ~DrainOnExit() {
       DeviceGuard g;
-      for (int d : devs) if (g.enter(d) == KDEHIP_OK) (void)hipStreamSynchronize(nullptr);
+      for (int d : devs) if (g.enter(d) == KDEHIP_OK) (void)hipStreamSynchronize(call_stream());
     }
   };
   rc = build_image(im, Ndens, trees, ndims, partialDimMask, precision);
@@ -598,15 +603,15 @@ int one_shot(int Ndens, const kdehip_density *trees, int64_t Np, int Niter, doub
     if (streams) {
       double *du = reinterpret_cast<double *>(w), *dn = reinterpret_cast<double *>(w + off_n);
       // sample s of this shard reads element (s - lo)*K + c - 1 of its slice = element s*K + c - 1 of the caller's array
-      KDEHIP_CHECK(hipMemcpyAsync(du, randU + S.lo * K, sizeof(double) * useU, hipMemcpyHostToDevice, nullptr));
-      KDEHIP_CHECK(hipMemcpyAsync(dn, randN + S.lo * R, sizeof(double) * useN, hipMemcpyHostToDevice, nullptr));
-      rc = enqueue_streams(S.plan, n, Niter, du, useU, dn, useN, addEntropy, dp, di, dl, nullptr, /*private_plan=*/true);
+      KDEHIP_CHECK(hipMemcpyAsync(du, randU + S.lo * K, sizeof(double) * useU, hipMemcpyHostToDevice, call_stream()));
+      KDEHIP_CHECK(hipMemcpyAsync(dn, randN + S.lo * R, sizeof(double) * useN, hipMemcpyHostToDevice, call_stream()));
+      rc = enqueue_streams(S.plan, n, Niter, du, useU, dn, useN, addEntropy, dp, di, dl, call_stream(), /*private_plan=*/true);
     } else {
-      rc = enqueue_philox(S.plan, n, Niter, seed, S.lo, addEntropy, dp, di, dl, nullptr, /*private_plan=*/true);
+      rc = enqueue_philox(S.plan, n, Niter, seed, S.lo, addEntropy, dp, di, dl, call_stream(), /*private_plan=*/true);
     }
     if (rc != KDEHIP_OK) return rc;
     KDEHIP_CHECK(cached_host_malloc(&S.h_out, S.span));
-    KDEHIP_CHECK(hipMemcpyAsync(S.h_out, w + S.off_p, S.span, hipMemcpyDeviceToHost, nullptr));
+    KDEHIP_CHECK(hipMemcpyAsync(S.h_out, w + S.off_p, S.span, hipMemcpyDeviceToHost, call_stream()));
   }
   const double us_enqueue = us_since(t_begin);
   double us_wait = 0.0;
@@ -614,7 +619,7 @@ int one_shot(int Ndens, const kdehip_density *trees, int64_t Np, int Niter, doub
     Shard &S = sh[g];
     rc = guard.enter(S.device);
     if (rc != KDEHIP_OK) return rc;
-    KDEHIP_CHECK(hipStreamSynchronize(nullptr));
+    KDEHIP_CHECK(hipStreamSynchronize(call_stream()));
     if (g == ngpus - 1) us_wait = us_since(t_begin);
     const int64_t n = S.hi - S.lo;
     const unsigned char *h = static_cast<const unsigned char *>(S.h_out);
@@ -846,9 +851,9 @@ int kdehip_prod_philox_resident(int Ndens, kdehip_device_density *const *trees, 
   if (e != hipSuccess) { cached_free(d_out, span); return set_error(KDEHIP_ERR_HIP, "pinned result block"); }
   unsigned char *w = static_cast<unsigned char *>(d_out);
   rc = kdehip_prod_philox_device(Ndens, trees, Np, Niter, seed, 0, addEntropy, partialDimMask, precision,
-                                 reinterpret_cast<double *>(w), reinterpret_cast<int64_t *>(w + off_i), nullptr, nullptr);
-  if (rc == KDEHIP_OK) e = hipMemcpyAsync(h_out, d_out, span, hipMemcpyDeviceToHost, nullptr);
-  const hipError_t se = hipStreamSynchronize(nullptr);  // (also before the blocks go back to the caches on an error)
+                                 reinterpret_cast<double *>(w), reinterpret_cast<int64_t *>(w + off_i), nullptr, call_stream());
+  if (rc == KDEHIP_OK) e = hipMemcpyAsync(h_out, d_out, span, hipMemcpyDeviceToHost, call_stream());
+  const hipError_t se = hipStreamSynchronize(call_stream());  // (also before the blocks go back to the caches on an error)
   if (rc == KDEHIP_OK && e == hipSuccess && se == hipSuccess) {
     std::memcpy(pts, h_out, sizeof(double) * D * Np);
     std::memcpy(ind, static_cast<unsigned char *>(h_out) + off_i, sizeof(int64_t) * M * Np);
