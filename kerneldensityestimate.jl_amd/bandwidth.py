@@ -12,6 +12,9 @@ from ._lib import f64p, ptr
 from .density import BallTreeDensity, kde
 
 
+_OVERLAP_MIN_POINTS = 1024
+
+
 def auto_bandwidth(points, device=0, return_evals=False):
     """Per-dimension LOOCV bandwidth (standard deviations) that `kde!(points)` selects."""
     pts = np.asarray(points, dtype=np.float64)
@@ -25,19 +28,22 @@ def auto_bandwidth(points, device=0, return_evals=False):
     return (bw, ne.value) if return_evals else bw
 
 
-def kde_auto(points, device=0) -> BallTreeDensity:
+def kde_auto(points, device=0, overlap=None) -> BallTreeDensity:
     """`kde!(points)`: LOOCV bandwidth per dimension, then `kde!(points, bwds)` (src/KDE01.jl:24).
 
     The tree's topology, bounding boxes, weights and means do not depend on the bandwidth: the host builder runs
     WHILE the GPU searches the bandwidth (the search is a chain of ~20 dependent launches; the blocking C call releases
     the GIL), and the variances are filled in afterwards (kdehip_density_set_bandwidth) -- bit-identical to building with
-    the final bandwidth."""
+    the final bandwidth.  `overlap`: None = where it pays (large densities: starting a host thread costs about what the
+    pooled builder needs for 2048 points, csrc/host_pool.hpp)."""
     import threading
     pts = np.asarray(points, dtype=np.float64)
     if pts.ndim == 1:
         pts = pts.reshape(1, -1)
     D, N = pts.shape
-    if N < 2:
+    if overlap is None:
+        overlap = N >= _OVERLAP_MIN_POINTS
+    if N < 2 or not overlap:
         return kde(pts, auto_bandwidth(pts, device=device))
     box = {}
 

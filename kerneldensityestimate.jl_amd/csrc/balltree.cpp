@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "../../include/kdehip.h"
+#include "host_pool.hpp"
 #include "kdehip_internal.hpp"
 
 namespace kdehip {
@@ -26,38 +27,91 @@ namespace {
 // this builder permutes only an index array `slot_` (leaf slot -> input point) with the reference's
 // exact swap sequence, materialises the leaves once, and then computes the node statistics in the
 // reference's post-order.  Same arrays, bit for bit, at a fraction of the memory traffic.
+//
+// Subtrees are independent once their node's quick-select is done: the leaf range, and -- because the reference hands
+// out ids left subtree first and a subtree of n leaves holds n-1 internal nodes -- the id range of each side are known
+// before either is built (the same closed form the device builder uses, treebuild.hip).  The top two or three levels
+// of a large density therefore build their left side on another host thread; every node is still computed by the same
+// expressions from the same operands, so the arrays do not depend on the number of threads (host_pool.hpp).
 class DensityBuilder {
  public:
   DensityBuilder(int64_t D, int64_t N, const double *points, double *centers, double *ranges,
                  double *weights, int64_t *left, int64_t *right, int64_t *lo, int64_t *hi, int64_t *perm,
                  double *means, double *bw)
       : D_(D), N_(N), pts_(points), centers_(centers), ranges_(ranges), weights_(weights), left_(left),
-        right_(right), lo_(lo), hi_(hi), perm_(perm), means_(means), bw_(bw), next_id_(2) {
+        right_(right), lo_(lo), hi_(hi), perm_(perm), means_(means), bw_(bw) {
     slot_.resize(static_cast<size_t>(N));
     for (int64_t i = 0; i < N; ++i) slot_[static_cast<size_t>(i)] = i;  // buildTree!, :419-429
-    post_order_.reserve(static_cast<size_t>(N));
-    acc_.resize(static_cast<size_t>(2 * D));
   }
 
   // wnorm: normalised weight of every input point; var: the D leaf variances
   void build(const double *wnorm, const double *var) {
-    build_node(N_ + 1, 2 * N_, 1);
-    for (int64_t s = 0; s < N_; ++s) {  // materialise the leaves in their final order
-      const int64_t id = N_ + 1 + s, src = slot_[static_cast<size_t>(s)];
-      weights_[id - 1] = wnorm[src];
+    wnorm_ = wnorm;
+    leaf_var_ = var;
+    Scratch s(D_);
+    int depth = 0;
+    if (N_ >= kSplitLeaves) {  // (small densities never start the workers)
+      const int w = HostPool::get().workers();
+      depth = w >= 15 ? 4 : (w >= 7 ? 3 : (w >= 3 ? 2 : (w >= 1 ? 1 : 0)));
+    }
+    subtree(N_ + 1, 2 * N_, 1, 2, depth, s);
+    if (N_ == 1) right_[0] = -1;  // single-point density, :358-360
+  }
+
+ private:
+  static constexpr int64_t kSplitLeaves = 512;  // a node with fewer leaves is built by the thread that reached it
+
+  struct Scratch {  // per host thread
+    explicit Scratch(int64_t D) : acc(static_cast<size_t>(2 * D)) {}
+    std::vector<double> acc, keys;
+    std::vector<int64_t> order;
+  };
+
+  // the leaves first..last in their final order
+  void materialise(int64_t first, int64_t last) {
+    for (int64_t id = first; id <= last; ++id) {
+      const int64_t src = slot_[static_cast<size_t>(id - N_ - 1)];
+      weights_[id - 1] = wnorm_[src];
       perm_[id - 1] = src + 1;
       for (int64_t k = 0; k < D_; ++k) {
         const double x = pts_[src * D_ + k];
         centers_[(id - 1) * D_ + k] = x;
         means_[(id - 1) * D_ + k] = x;
-        bw_[(id - 1) * D_ + k] = var[k];
+        bw_[(id - 1) * D_ + k] = leaf_var_[k];
       }
     }
-    for (int64_t id : post_order_) summarize(id);
-    if (N_ == 1) right_[0] = -1;  // single-point density, :358-360
   }
 
- private:
+  // Everything below internal node `id` (leaves first..last; `next` = the first id its descendants take): topology,
+  // leaves, statistics.  `depth` = how many more levels may hand their left side to another thread.
+  void subtree(int64_t first, int64_t last, int64_t id, int64_t next, int depth, Scratch &s) {
+    if (depth <= 0 || last - first + 1 < kSplitLeaves) {
+      s.order.clear();
+      build_node(first, last, id, next, s);
+      materialise(first, last);
+      const std::vector<int64_t> order = s.order;  // (summarize does not touch the scratch; the copy keeps that obvious)
+      for (int64_t node : order) summarize(node);
+      return;
+    }
+    lo_[id - 1] = first;
+    hi_[id - 1] = last;
+    const int64_t k = widest_dim(first, last, s);
+    const int64_t mid = (first + last) / 2;
+    quick_select(k, mid, first, last, s);
+    const int64_t a = next++, b = next++;      // (kSplitLeaves >= 4: both sides are internal nodes)
+    left_[id - 1] = a;
+    right_[id - 1] = b;
+    const int64_t next_right = next + (mid - first + 1) - 2;  // the left side's n-1 internal nodes, `a` among them
+    HostPool &pool = HostPool::get();
+    HostPool::Ticket left = pool.submit([=] {
+      Scratch mine(D_);
+      subtree(first, mid, a, next, depth - 1, mine);
+    });
+    subtree(mid + 1, last, b, next_right, depth - 1, s);
+    pool.join(left);  // (runs it here if no worker has started it)
+    summarize(id);
+  }
+
   // coordinate k of the point currently in leaf `id` (N+1 .. 2N)
   double key(int64_t id, int64_t k) const { return pts_[slot_[static_cast<size_t>(id - N_ - 1)] * D_ + k]; }
   void exchange(int64_t a, int64_t b) {  // swapBall!/swapDensity!, BallTree01.jl:109-138
@@ -72,11 +126,11 @@ class DensityBuilder {
   // Dimension of largest spread over leaves first..last (most_spread_coord, BallTree01.jl:142-173).
   // The reference leaves the last leaf out of both sums while scaling by 1/(last-first); ties and
   // the all-equal case resolve to the lowest dimension (strict '>').
-  int64_t widest_dim(int64_t first, int64_t last) {
+  int64_t widest_dim(int64_t first, int64_t last, Scratch &s) {
     // every dimension keeps the reference's own sequential sums; the dimensions are interleaved in
     // the inner loop only to give the CPU D independent dependency chains over contiguous memory
     const double scale = 1.0 / static_cast<double>(last - first);
-    double *m = acc_.data(), *v = acc_.data() + D_;
+    double *m = s.acc.data(), *v = s.acc.data() + D_;
     for (int64_t k = 0; k < D_; ++k) m[k] = v[k] = 0.0;
     for (int64_t id = first; id < last; ++id) {
       const double *x = pts_ + slot_[static_cast<size_t>(id - N_ - 1)] * D_;
@@ -99,12 +153,12 @@ class DensityBuilder {
   // Quick-select (select!, BallTree01.jl:223-242): afterwards leaves first..pos are <= those after.
   // The scan is the reference's single forward pass ("if less than the pivot: ++store, swap(store, i)"),
   // written branch-free on a contiguous copy of the keys: a not-less element swaps with itself.
-  void quick_select(int64_t k, int64_t pos, int64_t first, int64_t last) {
+  void quick_select(int64_t k, int64_t pos, int64_t first, int64_t last, Scratch &s) {
     if (first >= last) return;
     const int64_t base = first;
     const int64_t n0 = last - first + 1;
-    if (static_cast<int64_t>(keys_.size()) < n0) keys_.resize(static_cast<size_t>(n0));
-    double *kk = keys_.data();                                   // kk[i]  = key of leaf base+i
+    if (static_cast<int64_t>(s.keys.size()) < n0) s.keys.resize(static_cast<size_t>(n0));
+    double *kk = s.keys.data();                                  // kk[i]  = key of leaf base+i
     int64_t *sl = slot_.data() + (base - N_ - 1);                // sl[i]  = input point in leaf base+i
     for (int64_t i = 0; i < n0; ++i) kk[i] = pts_[sl[i] * D_ + k];
     int64_t lo = 0, hi = n0 - 1;
@@ -162,26 +216,27 @@ class DensityBuilder {
 
   // buildBall!, BallTree01.jl:342-411.  Child ids are handed out (left, then right) before either
   // subtree is built; a one-leaf side points straight at the leaf.  Statistics are deferred: nodes
-  // are recorded in the order the reference computes them (children before parents).
-  void build_node(int64_t first, int64_t last, int64_t id) {
+  // are recorded in the order the reference computes them (children before parents).  `next`: the
+  // next free id, shared by the whole recursion below one subtree() call.
+  void build_node(int64_t first, int64_t last, int64_t id, int64_t &next, Scratch &s) {
     lo_[id - 1] = first;
     hi_[id - 1] = last;
     if (first == last) {  // single-point density, :351-362 (right child fixed up after the stats)
       left_[id - 1] = first;
       right_[id - 1] = last;
-      post_order_.push_back(id);
+      s.order.push_back(id);
       return;
     }
-    const int64_t k = widest_dim(first, last);
+    const int64_t k = widest_dim(first, last, s);
     const int64_t mid = (first + last) / 2;
-    quick_select(k, mid, first, last);
-    const int64_t a = (mid <= first) ? first : next_id_++;
-    const int64_t b = (mid + 1 >= last) ? last : next_id_++;
+    quick_select(k, mid, first, last, s);
+    const int64_t a = (mid <= first) ? first : next++;
+    const int64_t b = (mid + 1 >= last) ? last : next++;
     left_[id - 1] = a;
     right_[id - 1] = b;
-    if (a != first) build_node(first, mid, a);
-    if (b != last) build_node(mid + 1, last, b);
-    post_order_.push_back(id);
+    if (a != first) build_node(first, mid, a, next, s);
+    if (b != last) build_node(mid + 1, last, b, next, s);
+    s.order.push_back(id);
   }
 
   const int64_t D_, N_;
@@ -189,9 +244,8 @@ class DensityBuilder {
   double *centers_, *ranges_, *weights_;
   int64_t *left_, *right_, *lo_, *hi_, *perm_;
   double *means_, *bw_;
-  int64_t next_id_;
-  std::vector<int64_t> slot_, post_order_;
-  std::vector<double> acc_, keys_;
+  const double *wnorm_ = nullptr, *leaf_var_ = nullptr;
+  std::vector<int64_t> slot_;
 };
 
 }  // namespace

@@ -383,9 +383,11 @@ __device__ inline bool node_interval(int64_t n, int d, int t, int64_t &low, int6
 
 // One block per dimension: x_d in original order to `xo`, sort in LDS, interval arithmetic, initial search state.
 __global__ __launch_bounds__(kPrepThreads) void loocv_prep_kernel(const double *__restrict__ points, int64_t N, int D,
-                                                                 double *__restrict__ xo, Golden *__restrict__ state) {
+                                                                 double *__restrict__ xo, Golden *__restrict__ state,
+                                                                 unsigned *__restrict__ arrivals, int ntiles) {
   extern __shared__ double sm[];
   const int d = blockIdx.x;
+  if (static_cast<int>(threadIdx.x) < ntiles) arrivals[d * ntiles + threadIdx.x] = 0;  // (the rounds' slot counters)
   int64_t P = 1;
   while (P < N) P <<= 1;
   double *xs = sm;              // [P] sorted marginal (padded with +inf)
@@ -398,13 +400,14 @@ __global__ __launch_bounds__(kPrepThreads) void loocv_prep_kernel(const double *
     if (i < N) xo[static_cast<int64_t>(d) * N + i] = v;
   }
   __syncthreads();
-  // bitonic sort, ascending.  Exchange partners less than 64 positions apart are handled by lanes of ONE wavefront
-  // (element i belongs to thread i mod 1024, its partner i ^ j to a thread of the same 64-thread group), whose LDS
-  // accesses execute in order: those stages need no workgroup barrier.
+  // bitonic sort, ascending.  Compare-exchange number c of a stage works on (i, i + j), i = c with a 0 bit inserted at
+  // bit log2(j): for j <= 64 the 64 exchanges c = 64w .. 64w+63 of wavefront w stay inside elements 128w .. 128w+127,
+  // whatever j is -- consecutive stages with j <= 64 read only what the SAME wavefront wrote, and a wavefront's LDS
+  // accesses execute in order, so only the stages with j >= 128 (10 of the 66 at 2048 points) sit between barriers.
   const int Pi = static_cast<int>(P);
   for (int k = 2; k <= Pi; k <<= 1)
     for (int j = k >> 1; j > 0; j >>= 1) {
-      // compare-exchange number c of this stage works on (i, i + j), i = c with a 0 bit inserted at bit log2(j)
+      if (j >= 64) __syncthreads();  // (j = 64 follows a wider stage, or starts a phase whose input other wavefronts wrote)
       for (int c = threadIdx.x; c < Pi / 2; c += kPrepThreads) {
         const int i = ((c & ~(j - 1)) << 1) | (c & (j - 1));
         const int l = i | j;
@@ -412,8 +415,9 @@ __global__ __launch_bounds__(kPrepThreads) void loocv_prep_kernel(const double *
         const bool up = (i & k) == 0;
         if ((a > b) == up) { xs[i] = b; xs[l] = a; }
       }
-      __syncthreads();
+      __builtin_amdgcn_wave_barrier();
     }
+  __syncthreads();
   int depth = 0;
   while ((int64_t(1) << depth) < N) ++depth;  // the deepest level that can hold a node
   double vmin = INFINITY;
@@ -454,7 +458,8 @@ constexpr int kLooChunk = 128;    // source points per staged chunk
 
 struct LooRound {
   const double *x;        // [D][N] marginals, original order
-  double *partial;        // [D][ngroups][N]
+  double *partial;        // [D][ngroups][N]; one launch per round: [D][T][T][64], (tile, source tile) slots
+  unsigned *arrivals;     // [D][T] slots delivered per tile (one launch per round; zero between rounds)
   double *hpart;          // [2][D][nfb] block partials of W*log p of the evaluation in flight (by round parity)
   Golden *state;          // [2][D]
   int64_t N;
@@ -512,14 +517,21 @@ __global__ __launch_bounds__(kLooThreads) void loo_round_partial_kernel(const Lo
   if (q < r.N) r.partial[(static_cast<int64_t>(d) * r.ngroups + blockIdx.y) * r.N + q] = total;
 }
 
-// A whole round in ONE launch (marginals up to kFusedMaxN points): a workgroup of 8 wavefronts owns the 64 queries
-// of tile I -- every wavefront holds the same queries, lane t query I*64+t -- and wavefront w sums over the source
-// tiles J = w, w+8, ...: the 64 sources of a tile travel around the wavefront one lane per step (DPP wave rotate),
-// so every lane meets every source without any LDS traffic besides the exp table.  The 8 partial sums per query
-// are added in wavefront order, turned into W*log p and reduced to the block's share of the log-likelihood
-// (evalAvgLogL, src/DualTree01.jl:450-474): no second launch, no intermediate array.
+// A whole round in ONE launch (marginals up to kFusedMaxN points), every kernel value computed ONCE: exp(-(x_i-x_j)^2/2bw)
+// is the same for (i, j) and (j, i), so a wavefront that holds the 64 points of tile I in its lanes and lets the 64 points
+// of tile J travel around them (DPP wave rotate, one lane per step -- no LDS traffic besides the exp table) adds every
+// value to two sums: the row sum of its own point and a column sum that travels with the visiting point and is home
+// again after 64 steps.  The unordered tile pairs are dealt out in a circle: the items of tile I are the diagonal
+// (I, I) and (I, I+k mod T) for k = 1 .. T/2 (for even T the offset T/2 pairs every tile with one partner only, so the
+// tiles of the lower half take it).  An item leaves the 64 sums it holds for tile I in part[I][src = J] and those for
+// tile J in part[J][src = I]: every (tile, source tile) slot is written exactly once, so the total of a query is the
+// sum of its T slots in source order -- fixed, whatever the order the items finish in.  That total, W*log p and the
+// tile's share of the log-likelihood (evalAvgLogL, src/DualTree01.jl:450-474) are the work of whichever wavefront
+// delivers a tile's LAST slot (a counter per tile): no second launch, and the search state of the next round is
+// advanced in the next launch's prologue.  (Measured at 6 x 2048: the arithmetic of a round fell from 21 to 9.5 us; the
+// hand-over beyond the L2 -- store acknowledgement, count, 32 loads -- costs 10 of them back: 25.8 -> 23.5 us a round.)
 constexpr int kTile = 64;
-constexpr int kFusedWaves = 16;
+constexpr int kPairWaves = 4;
 constexpr int64_t kFusedMaxN = 4096;
 __device__ __forceinline__ double wave_rotate(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
@@ -527,58 +539,111 @@ __device__ __forceinline__ double wave_rotate(double v) {
   hi = __builtin_amdgcn_update_dpp(hi, hi, 0x13C, 0xF, 0xF, false);
   return __hiloint2double(hi, lo);
 }
-__global__ __launch_bounds__(kTile *kFusedWaves) void loo_round_fused_kernel(const LooRound r) {
-  __shared__ double sExpTab[256];
-  __shared__ double sRow[kFusedWaves][kTile];
-  __shared__ Golden sh;
-  const int d = blockIdx.z, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int I = blockIdx.x;
-  if (threadIdx.x < 256) sExpTab[threadIdx.x] = kExp2Tab256[threadIdx.x];
-  if (threadIdx.x == 0) {
-    Golden s = r.state[(r.round & 1) * r.D + d];
-    golden_book(s, r.hpart + (static_cast<int64_t>(r.round & 1) * r.D + d) * r.nfb, r.nfb);
-    golden_decide(s);
-    sh = s;
-    if (I == 0) r.state[((r.round + 1) & 1) * r.D + d] = s;
-  }
-  __syncthreads();
-  if (sh.phase == 3) return;  // this dimension's search is over
-  const double nhib = -0.5 / sh.bw_eval;
-  const double *x = r.x + static_cast<int64_t>(d) * r.N;
-  const int64_t qi = static_cast<int64_t>(I) * kTile + lane;
-  const double xi = qi < r.N ? x[qi] : INFINITY;
-  const int ntiles = r.ngroups;
-  double rowsum = 0.0;
-  for (int J = wave; J < ntiles; J += kFusedWaves) {
-    const int64_t qj = static_cast<int64_t>(J) * kTile + lane;
-    double xj = qj < r.N ? x[qj] : -INFINITY;  // (a point at infinity contributes exp(-inf) = 0; opposite signs: no inf - inf)
-    double acc = 0.0;
-    int s0 = 0;
-    if (J == I) { xj = wave_rotate(xj); s0 = 1; }  // the own tile: the first rotation skips the self term (:141)
-#pragma unroll 4
-    for (int s = s0; s < kTile; ++s) {
-      const double dlt = xi - xj;
-      acc += exp256_nonpos((dlt * dlt) * nhib, sExpTab);
-      xj = wave_rotate(xj);
-    }
-    rowsum += acc;
-  }
-  sRow[wave][lane] = rowsum;
-  __syncthreads();
-  if (wave != 0) return;
+// The slots cross workgroups (and XCDs, each with an L2 of its own) inside one launch.  A release fence at device scope
+// writes the whole L2 back (buffer_wbl2: measured 4x the round's arithmetic); instead every slot is stored and loaded
+// as a device-scope relaxed atomic -- written through to, and read from, the level all XCDs share -- and a wavefront
+// counts only after its stores have been acknowledged (s_waitcnt vmcnt(0)).
+__device__ __forceinline__ void slot_store(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double slot_load(const double *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void slots_delivered() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// all T slots of `tile` are in place: total per query in source order, W*log p, the tile's share of the log-likelihood
+__device__ __forceinline__ void pairs_finish_tile(const LooRound &r, int d, int tile, int lane, double bw_eval) {
+  const int T = r.ngroups;
+  if (lane == 0) r.arrivals[d * T + tile] = 0;  // every slot is in: nobody counts on this tile again before the next round
+  const double *slots = r.partial + (static_cast<int64_t>(d) * T + tile) * T * kTile + lane;
   double tot = 0.0;
+  for (int s0 = 0; s0 < T; s0 += 32) {  // (32 loads in flight: they come from beyond the L2, 3 us a trip)
+    double v[32];
 #pragma unroll
-  for (int w = 0; w < kFusedWaves; ++w) tot += sRow[w][lane];
-  const double inv_norm = 1.0 / (r.sqrt_2pi * sqrt(sh.bw_eval));  // norm = (2 pi)^(1/2) * sqrt(bw), :325-330
+    for (int u = 0; u < 32; ++u) v[u] = s0 + u < T ? slot_load(slots + static_cast<int64_t>(s0 + u) * kTile) : 0.0;
+#pragma unroll
+    for (int u = 0; u < 32; ++u)
+      if (s0 + u < T) tot += v[u];
+  }
+  const int64_t q = static_cast<int64_t>(tile) * kTile + lane;
+  const double inv_norm = 1.0 / (r.sqrt_2pi * sqrt(bw_eval));  // norm = (2 pi)^(1/2) * sqrt(bw), :325-330
   double term = 0.0;
-  if (qi < r.N) {
+  if (q < r.N) {
     const double w = r.w;
     const double p = (tot * w) * inv_norm / (1.0 - w);
     if (p == 0.0) term = (w != 0.0) ? -INFINITY : 0.0;  // a zero likelihood that carries weight: -Inf (:460-463)
     else term = log(p) * w;
   }
   for (int off = 32; off > 0; off >>= 1) term += __shfl_down(term, off);  // fixed order
-  if (lane == 0) r.hpart[(static_cast<int64_t>((r.round + 1) & 1) * r.D + d) * r.nfb + I] = term;
+  if (lane == 0) r.hpart[(static_cast<int64_t>((r.round + 1) & 1) * r.D + d) * r.nfb + tile] = term;
+}
+// This wavefront's slots of tiles I and J (J < 0: of tile I only) are in place: count them -- lane 0 for I, lane 1 for J,
+// one atomic instruction -- and finish every tile whose T slots are complete with that.
+__device__ __forceinline__ void pairs_arrive(const LooRound &r, int d, int I, int J, int lane, double bw_eval) {
+  const int T = r.ngroups;
+  unsigned old = 0;
+  if (lane == 0 || (lane == 1 && J >= 0))
+    old = __hip_atomic_fetch_add(r.arrivals + d * T + (lane == 0 ? I : J), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned oldI = __builtin_amdgcn_readlane(old, 0), oldJ = __builtin_amdgcn_readlane(old, 1);
+  if (oldI == static_cast<unsigned>(T - 1)) pairs_finish_tile(r, d, I, lane, bw_eval);
+  if (J >= 0 && oldJ == static_cast<unsigned>(T - 1)) pairs_finish_tile(r, d, J, lane, bw_eval);
+}
+__global__ __launch_bounds__(kTile *kPairWaves) void loo_round_pairs_kernel(const LooRound r) {
+  __shared__ double sExpTab[256];
+  __shared__ double sPart[kFusedMaxN / kTile];
+  __shared__ Golden sh;
+  const int d = blockIdx.z, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  static_assert(kTile * kPairWaves == 256, "one table entry per thread");
+  sExpTab[threadIdx.x] = kExp2Tab256[threadIdx.x];
+  // the tile shares of the evaluation in flight: one load per thread (not T dependent ones by thread 0)
+  if (static_cast<int>(threadIdx.x) < r.nfb) sPart[threadIdx.x] = r.hpart[(static_cast<int64_t>(r.round & 1) * r.D + d) * r.nfb + threadIdx.x];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    Golden s = r.state[(r.round & 1) * r.D + d];
+    golden_book(s, sPart, r.nfb);
+    golden_decide(s);
+    sh = s;
+    if (blockIdx.x == 0) r.state[((r.round + 1) & 1) * r.D + d] = s;
+  }
+  __syncthreads();
+  if (sh.phase == 3) return;  // this dimension's search is over
+  const int T = r.ngroups, K = T / 2;
+  const int e = blockIdx.x * kPairWaves + wave;
+  const int I = e / (K + 1), k = e - I * (K + 1);
+  if (I >= T) return;
+  if (2 * k == T && I >= K) return;  // even T, offset T/2: the partner tile holds this pair
+  const int J = I + k < T ? I + k : I + k - T;
+  const double bw_eval = sh.bw_eval;
+  const double nhib = -0.5 / bw_eval;
+  const double *x = r.x + static_cast<int64_t>(d) * r.N;
+  const int64_t qi = static_cast<int64_t>(I) * kTile + lane, qj = static_cast<int64_t>(J) * kTile + lane;
+  const double xi = qi < r.N ? x[qi] : INFINITY;
+  double xj = qj < r.N ? x[qj] : -INFINITY;  // (a point at infinity contributes exp(-inf) = 0; opposite signs: no inf - inf)
+  double *slot_row = r.partial + ((static_cast<int64_t>(d) * T + I) * T + J) * kTile + lane;
+  double row = 0.0;
+  if (k == 0) {  // the own tile: the first rotation skips the self term (:141); both orders of a pair are met
+    xj = wave_rotate(xj);
+#pragma unroll 4
+    for (int s = 1; s < kTile; ++s) {
+      const double dlt = xi - xj;
+      row += exp256_nonpos((dlt * dlt) * nhib, sExpTab);
+      xj = wave_rotate(xj);
+    }
+    slot_store(slot_row, row);
+    slots_delivered();
+    pairs_arrive(r, d, I, -1, lane, bw_eval);
+    return;
+  }
+  double col = 0.0;
+#pragma unroll 4
+  for (int s = 0; s < kTile; ++s) {
+    const double dlt = xi - xj;
+    const double v = exp256_nonpos((dlt * dlt) * nhib, sExpTab);
+    row += v;
+    col = wave_rotate(col + v);
+    xj = wave_rotate(xj);
+  }
+  slot_store(slot_row, row);
+  slot_store(r.partial + ((static_cast<int64_t>(d) * T + J) * T + I) * kTile + lane, col);  // (64 rotations: home again)
+  slots_delivered();
+  pairs_arrive(r, d, I, J, lane, bw_eval);
 }
 
 // Round, second launch: p_q = w * (sum over groups) / norm / (1 - w); block partial of W_q * log p_q
@@ -662,9 +727,10 @@ extern "C" int kdehip_auto_bandwidth(int64_t D64, int64_t N, const double *point
   auto al = [](size_t x) { return (x + 255) & ~static_cast<size_t>(255); };
   const size_t off_x = al(sizeof(double) * N * D);
   const size_t off_part = al(off_x + sizeof(double) * N * D);
-  const size_t off_h = al(off_part + sizeof(double) * D * r.ngroups * N);
+  const size_t off_h = al(off_part + sizeof(double) * D * r.ngroups * (pairs ? int64_t(ntiles) * kTile : N));
   const size_t off_state = al(off_h + sizeof(double) * 2 * D * r.nfb);
-  const size_t total = off_state + sizeof(Golden) * 2 * D;
+  const size_t off_arr = al(off_state + sizeof(Golden) * 2 * D);
+  const size_t total = off_arr + sizeof(unsigned) * D * ntiles;
   DevBuf dev;
   KDEHIP_CHECK(dev.alloc(total));
   unsigned char *base = dev.as<unsigned char>();
@@ -673,6 +739,7 @@ extern "C" int kdehip_auto_bandwidth(int64_t D64, int64_t N, const double *point
   r.partial = reinterpret_cast<double *>(base + off_part);
   r.hpart = reinterpret_cast<double *>(base + off_h);
   r.state = reinterpret_cast<Golden *>(base + off_state);
+  r.arrivals = reinterpret_cast<unsigned *>(base + off_arr);
   struct Pinned {
     void *p = nullptr;
     size_t n = 0;
@@ -696,7 +763,7 @@ extern "C" int kdehip_auto_bandwidth(int64_t D64, int64_t N, const double *point
     KDEHIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(loocv_prep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      static_cast<int>(sizeof(double) * 5 * P)));  // up to 80 KiB; per call = per device
     hipLaunchKernelGGL(loocv_prep_kernel, dim3(D), dim3(kPrepThreads), sizeof(double) * 5 * P, nullptr, d_pts, N, D,
-                       const_cast<double *>(r.x), r.state);
+                       const_cast<double *>(r.x), r.state, r.arrivals, ntiles);
     KDEHIP_CHECK(hipGetLastError());
   } else {
     // large marginals: sort and interval arithmetic on the host (one thread per dimension), same state afterwards
@@ -716,6 +783,7 @@ extern "C" int kdehip_auto_bandwidth(int64_t D64, int64_t N, const double *point
     for (auto &t2 : th) t2.join();
     KDEHIP_CHECK(hipMemcpy(const_cast<double *>(r.x), xo.data(), sizeof(double) * D * N, hipMemcpyHostToDevice));
     KDEHIP_CHECK(hipMemcpy(r.state, g.data(), sizeof(Golden) * D, hipMemcpyHostToDevice));
+    if (pairs) KDEHIP_CHECK(hipMemset(r.arrivals, 0, sizeof(unsigned) * D * ntiles));
   }
   auto t_prep = tnow();
 
@@ -723,11 +791,12 @@ extern "C" int kdehip_auto_bandwidth(int64_t D64, int64_t N, const double *point
   int rounds = 0, batches = 0;
   const dim3 gridA(static_cast<unsigned>(qblocks), static_cast<unsigned>(r.ngroups), static_cast<unsigned>(D));
   const dim3 gridB(static_cast<unsigned>(r.nfb), static_cast<unsigned>(D));
-  const dim3 gridP(static_cast<unsigned>(ntiles), 1, static_cast<unsigned>(D));
+  const int pair_items = ntiles * (ntiles / 2 + 1);  // per dimension: the diagonal and the offsets 1 .. T/2 of every tile
+  const dim3 gridP(static_cast<unsigned>((pair_items + kPairWaves - 1) / kPairWaves), 1, static_cast<unsigned>(D));
   for (int batch = 20; batches < 16; batch = 8) {
     for (int k = 0; k < batch; ++k) {
       if (pairs) {
-        hipLaunchKernelGGL(loo_round_fused_kernel, gridP, dim3(kTile * kFusedWaves), 0, nullptr, r);
+        hipLaunchKernelGGL(loo_round_pairs_kernel, gridP, dim3(kTile * kPairWaves), 0, nullptr, r);
       } else {
         hipLaunchKernelGGL(loo_round_partial_kernel, gridA, dim3(kLooThreads), 0, nullptr, r);
         hipLaunchKernelGGL(loo_round_entropy_kernel<kLooThreads>, gridB, dim3(kLooThreads), 0, nullptr, r);

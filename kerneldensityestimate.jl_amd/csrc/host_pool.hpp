@@ -1,0 +1,109 @@
+// host_pool.hpp -- a few persistent host threads for the host-side builders (balltree.cpp).
+//
+// Creating a thread costs more than building a 2048-point tree (measured: 0.1-1.5 ms per create+join under the
+// container runtimes this library runs in), so the workers are started once, on first use, and sleep on a condition
+// variable in between.  A task that no worker has picked up by the time its owner needs the result is run by the owner
+// itself (`claim`), so nested fork/join cannot deadlock, a process that fork()ed away from its workers still makes
+// progress, and a machine with one core simply builds serially.
+#pragma once
+
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <thread>
+
+#include <pthread.h>
+
+namespace kdehip {
+
+class HostPool {
+ public:
+  struct Task {
+    std::function<void()> fn;
+    std::atomic<int> state{0};  // 0 queued, 1 claimed (running), 2 done
+  };
+  using Ticket = std::shared_ptr<Task>;
+
+  static HostPool &get() {
+    static HostPool *pool = new HostPool();  // never destroyed: the workers may outlive static destruction
+    return *pool;
+  }
+  int workers() const { return nworkers_.load(std::memory_order_relaxed); }
+
+  Ticket submit(std::function<void()> fn) {
+    Ticket t = std::make_shared<Task>();
+    t->fn = std::move(fn);
+    if (workers() > 0) {
+      {
+        std::lock_guard<std::mutex> lock(mu_);
+        queue_.push_back(t);
+      }
+      cv_.notify_one();
+    }
+    return t;
+  }
+
+  // returns when the task has run -- on a worker, or here if none has started it yet
+  void join(const Ticket &t) {
+    if (run_if_unclaimed(*t)) return;
+    for (int spin = 0; spin < 4096; ++spin) {
+      if (t->state.load(std::memory_order_acquire) == 2) return;
+      __builtin_ia32_pause();
+    }
+    std::unique_lock<std::mutex> lock(done_mu_);
+    done_cv_.wait(lock, [&] { return t->state.load(std::memory_order_acquire) == 2; });
+  }
+
+ private:
+  HostPool() {
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int want = hw > 1 ? static_cast<int>(hw > kMaxWorkers ? kMaxWorkers : hw - 1) : 0;
+    for (int i = 0; i < want; ++i) {
+      try {
+        std::thread([this] { work(); }).detach();
+        nworkers_.fetch_add(1, std::memory_order_relaxed);
+      } catch (const std::system_error &) {
+        break;
+      }
+    }
+    // a fork()ed child has none of the workers (and must not touch locks other threads held): its owners run their own tasks
+    self_.store(this, std::memory_order_release);
+    pthread_atfork(nullptr, nullptr, [] {
+      if (HostPool *p = self_.load(std::memory_order_acquire)) p->nworkers_.store(0, std::memory_order_relaxed);
+    });
+  }
+  static bool run_if_unclaimed(Task &t) {
+    int expect = 0;
+    if (!t.state.compare_exchange_strong(expect, 1, std::memory_order_acq_rel)) return false;
+    t.fn();
+    t.state.store(2, std::memory_order_release);
+    return true;
+  }
+  void work() {
+    for (;;) {
+      Ticket t;
+      {
+        std::unique_lock<std::mutex> lock(mu_);
+        cv_.wait(lock, [&] { return !queue_.empty(); });
+        t = std::move(queue_.front());
+        queue_.pop_front();
+      }
+      if (run_if_unclaimed(*t)) {
+        std::lock_guard<std::mutex> lock(done_mu_);  // (pairs with the predicate check in join)
+        done_cv_.notify_all();
+      }
+    }
+  }
+
+  static constexpr unsigned kMaxWorkers = 15;  // (measured on the 256-thread MI355X host: 7 -> 15 gains 10 % at 1e5 points)
+  inline static std::atomic<HostPool *> self_{nullptr};
+  std::atomic<int> nworkers_{0};
+  std::mutex mu_, done_mu_;
+  std::condition_variable cv_, done_cv_;
+  std::deque<Ticket> queue_;
+};
+
+}  // namespace kdehip

@@ -28,7 +28,8 @@ t_ph, _ = T(lambda: kdehip.prodAppxMSGibbsS(None, trees, None, None, Niter=Niter
 print(f"prodAppxMSGibbsS host-to-host with device Philox (plan create + run + D2H): {t_ph:.2f} ms = {Nout/t_ph*1e3:.0f} samples/s")
 # the product operator itself (src/MSGibbs01.jl:707-726): Np = mean Npts (here N, not Nout), Niter = 5, then kde!(pGM)
 big = [kdehip.kde(p, b) for p, b in zip(*bench.synth_inputs(kdehip, D, M, Nout, cid))]   # Nout-point inputs: a Nout-chain product
-t_mul, _ = T(lambda: kdehip.mul(big, seed=5), 5)
-t_auto, _ = T(lambda: kdehip.kde_auto(pGM), 5)
-print(f"`*` of {M} densities x {Nout} points ({Nout} chains, Niter 5, kde!(pGM) with the tree built under the bandwidth search): "
-      f"{t_mul:.2f} ms; kde!(pGM) alone {t_auto:.2f} ms (search {t_bw:.2f} + tree {t_final:.2f} one after the other)")
+t_mul, _ = T(lambda: kdehip.mul(big, seed=5), 20)
+t_auto, _ = T(lambda: kdehip.kde_auto(pGM), 20)
+t_auto_ov, _ = T(lambda: kdehip.kde_auto(pGM, overlap=True), 20)
+print(f"`*` of {M} densities x {Nout} points ({Nout} chains, Niter 5, then kde!(pGM)): {t_mul:.2f} ms; kde!(pGM) alone {t_auto:.2f} ms "
+      f"(search {t_bw:.2f} + tree {t_final:.2f}; with the tree built on a host thread under the search: {t_auto_ov:.2f} ms)")

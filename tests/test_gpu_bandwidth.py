@@ -59,7 +59,10 @@ def test_loocv_bandwidth_reproduces_reference_golden(golden_dir):
     check_density_against_golden(_Flat(d), gold, 1e-4)
 
 
-@pytest.mark.parametrize("D,N", [(1, 100), (2, 300), (3, 64), (6, 2048), (4, 1000), (2, 2), (3, 7), (2, 3000), (1, 5000)])
+@pytest.mark.parametrize("D,N", [(1, 100), (2, 300), (3, 64), (6, 2048), (4, 1000), (2, 2), (3, 7), (2, 3000), (1, 5000),
+                                 # the tile-pair kernel's circle of offsets: 2, 4 and 64 tiles (even: the half-way
+                                 # offset is held by the lower tiles only), 3 and 63 tiles (odd), ragged last tiles
+                                 (2, 128), (2, 193), (3, 130), (1, 4096), (1, 4000), (8, 65)])
 def test_loocv_bandwidth_parity_with_oracle(D, N):
     rng = np.random.default_rng(100 + D)
     pts = rng.standard_normal((D, N)) * rng.uniform(0.3, 3.0, size=(D, 1)) + rng.uniform(-2, 2, size=(D, 1))
@@ -128,9 +131,9 @@ def test_kde_auto_builds_its_tree_under_the_search_and_equals_the_sequential_for
     WHILE the GPU searches (topology and means do not depend on the bandwidth) and fills the variances in afterwards:
     every array must be bit-identical to the two steps run one after the other."""
     rng = np.random.default_rng(21)
-    for D, N in [(1, 100), (3, 257), (6, 2048)]:
+    for D, N, overlap in [(1, 100, True), (3, 257, True), (6, 2048, True), (6, 2048, None), (2, 9000, None), (3, 1000, None)]:
         pts = rng.standard_normal((D, N)) * rng.uniform(0.5, 2.0, size=(D, 1))
-        a = kdehip.kde_auto(pts)
+        a = kdehip.kde_auto(pts, overlap=overlap)   # (None: the mirror's own choice -- from 1024 points up)
         b = kdehip.kde(pts, kdehip.auto_bandwidth(pts))
         for f in ("means", "bandwidth", "bandwidthMin", "bandwidthMax"):
             assert np.array_equal(getattr(a, f), getattr(b, f)), (D, N, f)

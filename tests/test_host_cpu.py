@@ -83,7 +83,9 @@ def test_product_tree_builder_matches_reference_goldens(golden_dir):
 
 
 @pytest.mark.parametrize("D,N,weighted", [(1, 1, False), (1, 2, False), (1, 7, True), (2, 33, False),
-                                          (3, 200, True), (6, 1000, False), (4, 513, True)])
+                                          (3, 200, True), (6, 1000, False), (4, 513, True),
+                                          # 512 leaves and up: the top levels build their left side on pool threads
+                                          (2, 1024, False), (3, 2049, True), (2, 9001, False)])
 def test_product_tree_builder_equals_oracle_bitwise(D, N, weighted):
     rng = np.random.default_rng(100 * D + N)
     pts = rng.standard_normal((D, N))
@@ -101,6 +103,57 @@ def test_product_tree_builder_equals_oracle_bitwise(D, N, weighted):
     assert np.allclose(kdehip.getBW(a), np.repeat(ks[:, None], N, axis=1))
     ww = np.ones(N) if w is None else w
     assert np.allclose(kdehip.getWeights(a), ww / ww.sum())
+
+
+def test_tree_builder_from_concurrent_host_threads():
+    """several callers share the builder's worker pool (csrc/host_pool.hpp); an owner runs what no worker has started"""
+    import threading
+    rng = np.random.default_rng(77)
+    cases = [(rng.standard_normal((3, N)), rng.uniform(0.1, 0.5, size=3)) for N in (700, 2048, 3000, 5000, 1500, 4097)]
+    want = [kdehip.kde(p, k) for p, k in cases]
+    got = [None] * (4 * len(cases))
+
+    def run(i):
+        p, k = cases[i % len(cases)]
+        got[i] = kdehip.kde(p, k)
+
+    threads = [threading.Thread(target=run, args=(i,)) for i in range(len(got))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for i, g in enumerate(got):
+        w = want[i % len(cases)]
+        for k in ("centers", "ranges", "weights", "left_child", "right_child", "lowest_leaf", "highest_leaf", "permutation"):
+            assert np.array_equal(getattr(g.bt, k), getattr(w.bt, k)), (i, k)
+        assert np.array_equal(g.means, w.means) and np.array_equal(g.bandwidth, w.bandwidth)
+
+
+def test_tree_builder_in_a_forked_child():
+    """a fork()ed child has none of the pool's workers: it must build (serially) the same tree, not wait for them"""
+    import os
+    rng = np.random.default_rng(5)
+    pts, ks = rng.standard_normal((3, 4000)), np.full(3, 0.2)
+    a = kdehip.kde(pts, ks)   # (starts the workers in this process)
+    pid = os.fork()
+    if pid == 0:
+        try:
+            b = kdehip.kde(pts, ks)
+            ok = np.array_equal(a.means, b.means) and np.array_equal(a.bt.permutation, b.bt.permutation)
+        except BaseException:
+            ok = False
+        os._exit(0 if ok else 1)
+    import time
+    deadline = time.time() + 60
+    while time.time() < deadline:
+        done, status = os.waitpid(pid, os.WNOHANG)
+        if done:
+            assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0
+            return
+        time.sleep(0.02)
+    os.kill(pid, 9)
+    os.waitpid(pid, 0)
+    raise AssertionError("the forked child did not finish its tree build")
 
 
 def test_kde_argument_forms():
