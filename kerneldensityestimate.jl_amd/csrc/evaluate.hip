@@ -285,6 +285,8 @@ extern "C" int kdehip_evaluate(const kdehip_density *bd, const double *pos, int6
 namespace {
 
 constexpr double kGoldenTol = 1e-2;  // ksize, src/CrossValidation.jl:116
+constexpr int kCounterStride = 32;   // loo_round_pairs_kernel's slot counters: a 128-byte line each (neighbours in one line
+                                     // make it bounce between the XCDs' L2s)
 constexpr int kPrepThreads = 1024;
 constexpr int64_t kPrepMaxN = 2048;  // marginals up to this size are prepared on the device (LDS: 40 bytes per point of the
                                      // next power of two: 80 KiB; 4096 points would need all 160 KiB plus the statics)
@@ -387,7 +389,8 @@ __global__ __launch_bounds__(kPrepThreads) void loocv_prep_kernel(const double *
                                                                  unsigned *__restrict__ arrivals, int ntiles) {
   extern __shared__ double sm[];
   const int d = blockIdx.x;
-  if (static_cast<int>(threadIdx.x) < ntiles) arrivals[d * ntiles + threadIdx.x] = 0;  // (the rounds' slot counters)
+  if (static_cast<int>(threadIdx.x) < ntiles)  // (the rounds' slot counters, both probes of the joint first launch)
+    arrivals[(d * ntiles + threadIdx.x) * kCounterStride] = arrivals[((D + d) * ntiles + threadIdx.x) * kCounterStride] = 0;
   int64_t P = 1;
   while (P < N) P <<= 1;
   double *xs = sm;              // [P] sorted marginal (padded with +inf)
@@ -460,6 +463,8 @@ struct LooRound {
   const double *x;        // [D][N] marginals, original order
   double *partial;        // [D][ngroups][N]; one launch per round: [D][T][T][64], (tile, source tile) slots
   unsigned *arrivals;     // [D][T] slots delivered per tile (one launch per round; zero between rounds)
+  int joint;              // one launch per round: the first launch evaluates BOTH opening probes of every search (a second
+                          // set of slots, counters and shares behind the first), the second launch books both
   double *hpart;          // [2][D][nfb] block partials of W*log p of the evaluation in flight (by round parity)
   Golden *state;          // [2][D]
   int64_t N;
@@ -549,10 +554,15 @@ __device__ __forceinline__ double slot_load(const double *p) {
 }
 __device__ __forceinline__ void slots_delivered() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // all T slots of `tile` are in place: total per query in source order, W*log p, the tile's share of the log-likelihood
-__device__ __forceinline__ void pairs_finish_tile(const LooRound &r, int d, int tile, int lane, double bw_eval) {
+struct PairSet {  // where one probe of a launch keeps its slots [D][T][T][64], counters [D][T] and tile shares [T]
+  double *slots;
+  unsigned *arrivals;
+  double *shares;
+};
+__device__ __forceinline__ void pairs_finish_tile(const LooRound &r, const PairSet &ps, int d, int tile, int lane, double bw_eval) {
   const int T = r.ngroups;
-  if (lane == 0) r.arrivals[d * T + tile] = 0;  // every slot is in: nobody counts on this tile again before the next round
-  const double *slots = r.partial + (static_cast<int64_t>(d) * T + tile) * T * kTile + lane;
+  if (lane == 0) ps.arrivals[(d * T + tile) * kCounterStride] = 0;  // every slot is in: nobody counts on this tile again before the next round
+  const double *slots = ps.slots + (static_cast<int64_t>(d) * T + tile) * T * kTile + lane;
   double tot = 0.0;
   for (int s0 = 0; s0 < T; s0 += 32) {  // (32 loads in flight: they come from beyond the L2, 3 us a trip)
     double v[32];
@@ -572,51 +582,82 @@ __device__ __forceinline__ void pairs_finish_tile(const LooRound &r, int d, int 
     else term = log(p) * w;
   }
   for (int off = 32; off > 0; off >>= 1) term += __shfl_down(term, off);  // fixed order
-  if (lane == 0) r.hpart[(static_cast<int64_t>((r.round + 1) & 1) * r.D + d) * r.nfb + tile] = term;
+  if (lane == 0) ps.shares[tile] = term;
 }
 // This wavefront's slots of tiles I and J (J < 0: of tile I only) are in place: count them -- lane 0 for I, lane 1 for J,
 // one atomic instruction -- and finish every tile whose T slots are complete with that.
-__device__ __forceinline__ void pairs_arrive(const LooRound &r, int d, int I, int J, int lane, double bw_eval) {
+__device__ __forceinline__ void pairs_arrive(const LooRound &r, const PairSet &ps, int d, int I, int J, int lane, double bw_eval) {
   const int T = r.ngroups;
   unsigned old = 0;
   if (lane == 0 || (lane == 1 && J >= 0))
-    old = __hip_atomic_fetch_add(r.arrivals + d * T + (lane == 0 ? I : J), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    old = __hip_atomic_fetch_add(ps.arrivals + (d * T + (lane == 0 ? I : J)) * kCounterStride, 1u, __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
   const unsigned oldI = __builtin_amdgcn_readlane(old, 0), oldJ = __builtin_amdgcn_readlane(old, 1);
-  if (oldI == static_cast<unsigned>(T - 1)) pairs_finish_tile(r, d, I, lane, bw_eval);
-  if (J >= 0 && oldJ == static_cast<unsigned>(T - 1)) pairs_finish_tile(r, d, J, lane, bw_eval);
+  if (oldI == static_cast<unsigned>(T - 1)) pairs_finish_tile(r, ps, d, I, lane, bw_eval);
+  if (J >= 0 && oldJ == static_cast<unsigned>(T - 1)) pairs_finish_tile(r, ps, d, J, lane, bw_eval);
 }
+// OPENING: 0 = a round of one evaluation per search; 1 = the first launch, both opening probes; 2 = the launch after it
+// (reqd_work_group_size: where the compiler keeps a thread's temporaries in LDS it indexes them by the flat thread id,
+// and without the sizes it reads them from the dispatch packet -- in host memory: 2-15 us on every workgroup's path)
+template <int OPENING>
 __global__ __launch_bounds__(kTile *kPairWaves) void loo_round_pairs_kernel(const LooRound r) {
   __shared__ double sExpTab[256];
-  __shared__ double sPart[kFusedMaxN / kTile];
-  __shared__ Golden sh;
-  const int d = blockIdx.z, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ double sPart[OPENING == 2 ? 2 : 1][kFusedMaxN / kTile];
+  __shared__ double sBw;   // what the workgroup needs of the advanced search state: the variance of this evaluation,
+  __shared__ int sPhase;   // and whether the search is over
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // golden's first two evaluations (x1, x2: src/CrossValidation.jl:57-66) do not depend on each other: the first launch
+  // runs both, blockIdx.z >= D being the second probe of dimension z - D on its own slots, counters and shares
+  const int probe = OPENING == 1 && static_cast<int>(blockIdx.z) >= r.D ? 1 : 0, d = blockIdx.z - probe * r.D;
+  PairSet ps;
+  ps.slots = r.partial + probe * (static_cast<int64_t>(r.D) * r.ngroups * r.ngroups * kTile);
+  ps.arrivals = r.arrivals + probe * (r.D * r.ngroups * kCounterStride);
+  // the tile shares of this launch: plane (round+1)&1 of [4][D][nfb]; the second probe's land in plane 3
+  ps.shares = r.hpart + (static_cast<int64_t>(probe ? 3 : ((r.round + 1) & 1)) * r.D + d) * r.nfb;
+  constexpr bool follow = OPENING == 2;  // the launch after the joint one: two evaluations to book
   static_assert(kTile * kPairWaves == 256, "one table entry per thread");
   sExpTab[threadIdx.x] = kExp2Tab256[threadIdx.x];
   // the tile shares of the evaluation in flight: one load per thread (not T dependent ones by thread 0)
-  if (static_cast<int>(threadIdx.x) < r.nfb) sPart[threadIdx.x] = r.hpart[(static_cast<int64_t>(r.round & 1) * r.D + d) * r.nfb + threadIdx.x];
+  if (static_cast<int>(threadIdx.x) < r.nfb) {
+    sPart[0][threadIdx.x] = r.hpart[(static_cast<int64_t>(r.round & 1) * r.D + d) * r.nfb + threadIdx.x];
+    if constexpr (follow) sPart[1][threadIdx.x] = r.hpart[(static_cast<int64_t>(3) * r.D + d) * r.nfb + threadIdx.x];
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
     Golden s = r.state[(r.round & 1) * r.D + d];
-    golden_book(s, sPart, r.nfb);
+    golden_book(s, sPart[0], r.nfb);
     golden_decide(s);
-    sh = s;
-    if (blockIdx.x == 0) r.state[((r.round + 1) & 1) * r.D + d] = s;
+    if constexpr (follow) {
+      golden_book(s, sPart[1], r.nfb);
+      golden_decide(s);
+    }
+    if (blockIdx.x == 0 && !probe) r.state[((r.round + 1) & 1) * r.D + d] = s;
+    if (probe) {  // the second probe: the state as it will be once the first is booked (the booking needs no result)
+      const double a2 = s.alpha * s.alpha;
+      s.bcur = (s.bcur * a2) / a2;
+      s.nevals += 1;
+      s.phase = 1;
+      s.pending = 0;
+      golden_decide(s);
+    }
+    sBw = s.bw_eval;
+    sPhase = s.phase;
   }
   __syncthreads();
-  if (sh.phase == 3) return;  // this dimension's search is over
+  if (sPhase == 3) return;  // this dimension's search is over
   const int T = r.ngroups, K = T / 2;
   const int e = blockIdx.x * kPairWaves + wave;
   const int I = e / (K + 1), k = e - I * (K + 1);
   if (I >= T) return;
   if (2 * k == T && I >= K) return;  // even T, offset T/2: the partner tile holds this pair
   const int J = I + k < T ? I + k : I + k - T;
-  const double bw_eval = sh.bw_eval;
+  const double bw_eval = sBw;
   const double nhib = -0.5 / bw_eval;
   const double *x = r.x + static_cast<int64_t>(d) * r.N;
   const int64_t qi = static_cast<int64_t>(I) * kTile + lane, qj = static_cast<int64_t>(J) * kTile + lane;
   const double xi = qi < r.N ? x[qi] : INFINITY;
   double xj = qj < r.N ? x[qj] : -INFINITY;  // (a point at infinity contributes exp(-inf) = 0; opposite signs: no inf - inf)
-  double *slot_row = r.partial + ((static_cast<int64_t>(d) * T + I) * T + J) * kTile + lane;
+  double *slot_row = ps.slots + ((static_cast<int64_t>(d) * T + I) * T + J) * kTile + lane;
   double row = 0.0;
   if (k == 0) {  // the own tile: the first rotation skips the self term (:141); both orders of a pair are met
     xj = wave_rotate(xj);
@@ -628,7 +669,7 @@ __global__ __launch_bounds__(kTile *kPairWaves) void loo_round_pairs_kernel(cons
     }
     slot_store(slot_row, row);
     slots_delivered();
-    pairs_arrive(r, d, I, -1, lane, bw_eval);
+    pairs_arrive(r, ps, d, I, -1, lane, bw_eval);
     return;
   }
   double col = 0.0;
@@ -641,9 +682,9 @@ __global__ __launch_bounds__(kTile *kPairWaves) void loo_round_pairs_kernel(cons
     xj = wave_rotate(xj);
   }
   slot_store(slot_row, row);
-  slot_store(r.partial + ((static_cast<int64_t>(d) * T + J) * T + I) * kTile + lane, col);  // (64 rotations: home again)
+  slot_store(ps.slots + ((static_cast<int64_t>(d) * T + J) * T + I) * kTile + lane, col);  // (64 rotations: home again)
   slots_delivered();
-  pairs_arrive(r, d, I, J, lane, bw_eval);
+  pairs_arrive(r, ps, d, I, J, lane, bw_eval);
 }
 
 // Round, second launch: p_q = w * (sum over groups) / norm / (1 - w); block partial of W_q * log p_q
@@ -727,10 +768,11 @@ extern "C" int kdehip_auto_bandwidth(int64_t D64, int64_t N, const double *point
   auto al = [](size_t x) { return (x + 255) & ~static_cast<size_t>(255); };
   const size_t off_x = al(sizeof(double) * N * D);
   const size_t off_part = al(off_x + sizeof(double) * N * D);
-  const size_t off_h = al(off_part + sizeof(double) * D * r.ngroups * (pairs ? int64_t(ntiles) * kTile : N));
-  const size_t off_state = al(off_h + sizeof(double) * 2 * D * r.nfb);
+  r.joint = pairs && !std::getenv("KDEHIP_NOJOINT") ? 1 : 0;
+  const size_t off_h = al(off_part + sizeof(double) * D * r.ngroups * (pairs ? (r.joint ? 2 : 1) * int64_t(ntiles) * kTile : N));
+  const size_t off_state = al(off_h + sizeof(double) * 4 * D * r.nfb);
   const size_t off_arr = al(off_state + sizeof(Golden) * 2 * D);
-  const size_t total = off_arr + sizeof(unsigned) * D * ntiles;
+  const size_t total = off_arr + (pairs ? sizeof(unsigned) * 2 * D * ntiles * kCounterStride : 0);
   DevBuf dev;
   KDEHIP_CHECK(dev.alloc(total));
   unsigned char *base = dev.as<unsigned char>();
@@ -783,7 +825,7 @@ extern "C" int kdehip_auto_bandwidth(int64_t D64, int64_t N, const double *point
     for (auto &t2 : th) t2.join();
     KDEHIP_CHECK(hipMemcpy(const_cast<double *>(r.x), xo.data(), sizeof(double) * D * N, hipMemcpyHostToDevice));
     KDEHIP_CHECK(hipMemcpy(r.state, g.data(), sizeof(Golden) * D, hipMemcpyHostToDevice));
-    if (pairs) KDEHIP_CHECK(hipMemset(r.arrivals, 0, sizeof(unsigned) * D * ntiles));
+    if (pairs) KDEHIP_CHECK(hipMemset(r.arrivals, 0, sizeof(unsigned) * 2 * D * ntiles * kCounterStride));
   }
   auto t_prep = tnow();
 
@@ -793,10 +835,13 @@ extern "C" int kdehip_auto_bandwidth(int64_t D64, int64_t N, const double *point
   const dim3 gridB(static_cast<unsigned>(r.nfb), static_cast<unsigned>(D));
   const int pair_items = ntiles * (ntiles / 2 + 1);  // per dimension: the diagonal and the offsets 1 .. T/2 of every tile
   const dim3 gridP(static_cast<unsigned>((pair_items + kPairWaves - 1) / kPairWaves), 1, static_cast<unsigned>(D));
-  for (int batch = 20; batches < 16; batch = 8) {
+  const dim3 gridP2(gridP.x, 1, static_cast<unsigned>(2 * D));  // the joint first launch
+  for (int batch = r.joint ? 19 : 20; batches < 16; batch = 8) {  // (20 evaluations: the first launch of `pairs` runs two)
     for (int k = 0; k < batch; ++k) {
       if (pairs) {
-        hipLaunchKernelGGL(loo_round_pairs_kernel, gridP, dim3(kTile * kPairWaves), 0, nullptr, r);
+        if (r.joint && r.round == 0) hipLaunchKernelGGL(loo_round_pairs_kernel<1>, gridP2, dim3(kTile * kPairWaves), 0, nullptr, r);
+        else if (r.joint && r.round == 1) hipLaunchKernelGGL(loo_round_pairs_kernel<2>, gridP, dim3(kTile * kPairWaves), 0, nullptr, r);
+        else hipLaunchKernelGGL(loo_round_pairs_kernel<0>, gridP, dim3(kTile * kPairWaves), 0, nullptr, r);
       } else {
         hipLaunchKernelGGL(loo_round_partial_kernel, gridA, dim3(kLooThreads), 0, nullptr, r);
         hipLaunchKernelGGL(loo_round_entropy_kernel<kLooThreads>, gridB, dim3(kLooThreads), 0, nullptr, r);
