@@ -533,8 +533,9 @@ __global__ __launch_bounds__(kLooThreads) void loo_round_partial_kernel(const Lo
 // sum of its T slots in source order -- fixed, whatever the order the items finish in.  That total, W*log p and the
 // tile's share of the log-likelihood (evalAvgLogL, src/DualTree01.jl:450-474) are the work of whichever wavefront
 // delivers a tile's LAST slot (a counter per tile): no second launch, and the search state of the next round is
-// advanced in the next launch's prologue.  (Measured at 6 x 2048: the arithmetic of a round fell from 21 to 9.5 us; the
-// hand-over beyond the L2 -- store acknowledgement, count, 32 loads -- costs 10 of them back: 25.8 -> 23.5 us a round.)
+// advanced in the next launch's prologue.  (Measured at 6 x 2048, scripts in profiles/r03_loocv.md: the arithmetic of a
+// round fell from 21 us to 8.7 us for the median wavefront, 16.7 us for the last one -- some SIMDs are dealt 5-6 of the
+// 3264 items, others 2; the hand-over costs 0.4 us per step and 3 us for the last tile's loads: 25.8 -> 21.3 us a round.)
 constexpr int kTile = 64;
 constexpr int kPairWaves = 4;
 constexpr int64_t kFusedMaxN = 4096;
@@ -768,7 +769,7 @@ extern "C" int kdehip_auto_bandwidth(int64_t D64, int64_t N, const double *point
   auto al = [](size_t x) { return (x + 255) & ~static_cast<size_t>(255); };
   const size_t off_x = al(sizeof(double) * N * D);
   const size_t off_part = al(off_x + sizeof(double) * N * D);
-  r.joint = pairs && !std::getenv("KDEHIP_NOJOINT") ? 1 : 0;
+  r.joint = pairs ? 1 : 0;
   const size_t off_h = al(off_part + sizeof(double) * D * r.ngroups * (pairs ? (r.joint ? 2 : 1) * int64_t(ntiles) * kTile : N));
   const size_t off_state = al(off_h + sizeof(double) * 4 * D * r.nfb);
   const size_t off_arr = al(off_state + sizeof(Golden) * 2 * D);

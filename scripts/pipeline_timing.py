@@ -10,11 +10,11 @@ def T(f, n=5):
     f(); t = time.perf_counter()
     for _ in range(n): r = f()
     return (time.perf_counter() - t) / n * 1e3, r
-t_tree, trees = T(lambda: [kdehip.kde(p, b) for p, b in zip(pts, bws)])
+t_tree, trees = T(lambda: [kdehip.kde(p, b) for p, b in zip(pts, bws)], 20)
 t_plan, plan = T(lambda: kdehip.ProductPlan(trees))
 t_samp, (pGM, ind) = T(lambda: plan.sample(Nout, Niter=Niter, seed=1))
-t_bw, bw = T(lambda: kdehip.auto_bandwidth(pGM), 3)
-t_final, _ = T(lambda: kdehip.kde(pGM, bw))
+t_bw, bw = T(lambda: kdehip.auto_bandwidth(pGM), 20)
+t_final, _ = T(lambda: kdehip.kde(pGM, bw), 20)
 t_eval, _ = T(lambda: kdehip.evaluateDualTree(trees[0], pGM))
 print(f"{sys.argv[1] if len(sys.argv)>1 else 'c3'}: host trees of {M} inputs {t_tree:.2f} ms | plan (pack+upload) {t_plan:.2f} ms | "
       f"sample {Nout} chains incl. alloc+D2H {t_samp:.2f} ms | LOOCV bandwidth of pGM ({D}x{Nout}) {t_bw:.2f} ms | "
