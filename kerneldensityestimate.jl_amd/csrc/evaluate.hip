@@ -534,10 +534,10 @@ __global__ __launch_bounds__(kLooThreads) void loo_round_partial_kernel(const Lo
 // tile's share of the log-likelihood (evalAvgLogL, src/DualTree01.jl:450-474) are the work of whichever wavefront
 // delivers a tile's LAST slot (a counter per tile): no second launch, and the search state of the next round is
 // advanced in the next launch's prologue.  (Measured at 6 x 2048, scripts in profiles/r03_loocv.md: the arithmetic of a
-// round fell from 21 us to 8.7 us for the median wavefront, 16.7 us for the last one -- some SIMDs are dealt 5-6 of the
-// 3264 items, others 2; the hand-over costs 0.4 us per step and 3 us for the last tile's loads: 25.8 -> 21.3 us a round.)
+// round fell from 21 us to 4 items of 2.9 us per SIMD = 11.6 us (3264 items on 1024 SIMDs: 3.2 each would do); the
+// hand-over costs 0.4 us per step and 3.5 us for the last tile's loads: 25.8 -> 19 us a round.)
 constexpr int kTile = 64;
-constexpr int kPairWaves = 4;
+constexpr int kPairWaves = 16;  // (items of 16 wavefronts fill a CU evenly -- 4 per SIMD; workgroups of 4 were dealt 2-6 to a CU)
 constexpr int64_t kFusedMaxN = 4096;
 __device__ __forceinline__ double wave_rotate(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
@@ -616,8 +616,7 @@ __global__ __launch_bounds__(kTile *kPairWaves) void loo_round_pairs_kernel(cons
   // the tile shares of this launch: plane (round+1)&1 of [4][D][nfb]; the second probe's land in plane 3
   ps.shares = r.hpart + (static_cast<int64_t>(probe ? 3 : ((r.round + 1) & 1)) * r.D + d) * r.nfb;
   constexpr bool follow = OPENING == 2;  // the launch after the joint one: two evaluations to book
-  static_assert(kTile * kPairWaves == 256, "one table entry per thread");
-  sExpTab[threadIdx.x] = kExp2Tab256[threadIdx.x];
+  if (threadIdx.x < 256) sExpTab[threadIdx.x] = kExp2Tab256[threadIdx.x];
   // the tile shares of the evaluation in flight: one load per thread (not T dependent ones by thread 0)
   if (static_cast<int>(threadIdx.x) < r.nfb) {
     sPart[0][threadIdx.x] = r.hpart[(static_cast<int64_t>(r.round & 1) * r.D + d) * r.nfb + threadIdx.x];
