@@ -238,7 +238,10 @@ void kdehip_philox_fill_normal(uint64_t seed, int64_t sample_begin, int64_t nsam
  * A Julia caller keeps using its own kde!; this entry serves hosts without the reference.
  * points: D x N column-major; ks: nks = 1 or D standard deviations (squared inside);
  * weights_in: N or NULL (= ones).  Outputs are caller-allocated: centers, ranges, means,
- * bandwidth: D*2N; weights and the five index arrays: 2N; bandwidthMin/Max: D*N. */
+ * bandwidth: D*2N; weights and the five index arrays: 2N; bandwidthMin/Max: D*N.
+ * Thread-safe.  From 512 points up the top levels hand their left subtree to a process-wide pool of at most 15
+ * worker threads (started on first use, asleep in between, never joined; csrc/host_pool.hpp): the arrays do not
+ * depend on the number of threads, and a process that fork()ed away from the workers builds serially. */
 int kdehip_make_density(int64_t D, int64_t N, const double *points, const double *ks, int64_t nks,
                         const double *weights_in, double *centers, double *ranges, double *weights,
                         int64_t *left_child, int64_t *right_child, int64_t *lowest_leaf,

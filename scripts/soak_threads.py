@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Thread-safety soak: several host threads call the blocking entry points concurrently on one device (one-shot
 products with device Philox and with caller streams, products of densities kept in HBM -- shared handles --, evaluation,
-LOOCV bandwidth); every result
+LOOCV bandwidth, `kde!(points)` with its tree built on the pooled host builder under the search); every result
 must equal the single-threaded one.   python scripts/soak_threads.py [threads] [calls per thread]"""
 import os
 import sys
@@ -27,12 +27,12 @@ for c in range(24):   # a pool of prepared problems with their single-threaded a
     K, R, nU, nN = oracle.rng_sizes(M, D, Np, Niter, Ns)
     randU, randN = rng.random(nU), rng.standard_normal(nN)
     pos = rng.standard_normal((D, 300))
-    x = rng.standard_normal((D, 400))
+    x = rng.standard_normal((D, int(rng.choice([400, 1500, 2500]))))
     jobs.append(dict(trees=trees, dd=[kdehip.DeviceDensity(t) for t in trees], Np=Np, Niter=Niter, randU=randU, randN=randN,
                      pos=pos, x=x, seed=c,
                      a=kdehip.prodAppxMSGibbsS(None, trees, None, None, Niter=Niter, Np=Np, seed=c),
                      b=kdehip.prodAppxMSGibbsS(None, trees, None, None, Niter=Niter, Np=Np, randU=randU, randN=randN),
-                     e=trees[0](pos), bw=kdehip.auto_bandwidth(x)))
+                     e=trees[0](pos), bw=kdehip.auto_bandwidth(x), kd=kdehip.kde_auto(x, overlap=False)))
 
 
 def worker(t):
@@ -40,7 +40,7 @@ def worker(t):
     bad = 0
     for _ in range(ncalls):
         j = jobs[int(r.integers(0, len(jobs)))]
-        kind = int(r.integers(0, 5))
+        kind = int(r.integers(0, 6))
         if kind == 0:
             got = kdehip.prodAppxMSGibbsS(None, j["trees"], None, None, Niter=j["Niter"], Np=j["Np"], seed=j["seed"])
             ok = np.array_equal(got[0], j["a"][0]) and np.array_equal(got[1], j["a"][1])
@@ -52,6 +52,10 @@ def worker(t):
         elif kind == 4:   # densities resident in HBM, handles shared by all threads; the plan queue is shared state
             got = kdehip.prodAppxMSGibbsS_resident(j["dd"], Np=j["Np"], Niter=j["Niter"], seed=j["seed"])
             ok = np.array_equal(got[0], j["a"][0]) and np.array_equal(got[1], j["a"][1])
+        elif kind == 5:   # kde!(points): the worker pool of the host tree builder is shared by every caller
+            got = kdehip.kde_auto(j["x"], overlap=bool(r.integers(0, 2)))
+            ok = all(np.array_equal(getattr(got, f), getattr(j["kd"], f)) for f in ("means", "bandwidth")) and \
+                all(np.array_equal(getattr(got.bt, f), getattr(j["kd"].bt, f)) for f in ("centers", "ranges", "weights", "left_child", "permutation"))
         else:
             ok = np.array_equal(kdehip.auto_bandwidth(j["x"]), j["bw"])
         bad += not ok
