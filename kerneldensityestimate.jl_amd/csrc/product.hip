@@ -159,7 +159,8 @@ struct PeerOutputs {
 
 int enqueue_philox(kdehip_product *plan, int64_t Np, int Niter, uint64_t seed, int64_t sample_offset,
                    int addEntropy, double *d_points, int64_t *d_indices, int32_t *d_labels, void *stream,
-                   bool private_plan = false, const PeerOutputs *peers = nullptr) {
+                   bool private_plan = false, const PeerOutputs *peers = nullptr, void *table_stream = nullptr,
+                   hipEvent_t tables_done = nullptr) {
   int rc = check_run(plan, Np, Niter, d_points, d_indices);
   if (rc != KDEHIP_OK) return rc;
   if (Np == 0) return KDEHIP_OK;
@@ -175,8 +176,13 @@ int enqueue_philox(kdehip_product *plan, int64_t Np, int Niter, uint64_t seed, i
   a.R = kdehip_product_randn_per_sample(plan);
   a.seed = seed; a.sample_offset = sample_offset;
   a.points = d_points; a.indices = d_indices; a.labels = d_labels;
-  rc = maybe_build_tables(plan, Np, a, stream, private_plan);
+  // (table_stream: a plan private to one call may fill its tables on another stream; the sampler waits for tables_done)
+  rc = maybe_build_tables(plan, Np, a, table_stream ? table_stream : stream, private_plan);
   if (rc != KDEHIP_OK) return rc;
+  if (table_stream) {
+    KDEHIP_CHECK(hipEventRecord(tables_done, static_cast<hipStream_t>(table_stream)));
+    KDEHIP_CHECK(hipStreamWaitEvent(static_cast<hipStream_t>(stream), tables_done, 0));
+  }
   if (peers) {
     a.npeers = peers->n;
     for (int k = 0; k < peers->n; ++k) { a.peer_points[k] = peers->points[k]; a.peer_indices[k] = peers->indices[k]; }
@@ -677,13 +683,36 @@ struct PendingPlan {
   hipEvent_t done;
   void *h_desc;
   size_t h_bytes;
+  hipEvent_t prepared = nullptr;  // tiles and tables are in place (recorded on the device's preparation stream)
 };
+
+// Preparing a product of resident densities (descriptor upload, tile gather, conditional tables: ~35 us of small,
+// latency-bound launches) does not depend on anything the caller's stream holds -- the densities are immutable, the
+// plan's block is its own -- so it runs on a stream of the library's and the sampler waits for it with an event.  A caller
+// that enqueues products back to back gets product k+1 prepared WHILE product k samples (the sampler leaves 112
+// registers per SIMD and 19 KB of LDS per CU free: the small kernels fit beside it).
+std::mutex g_prep_mu;
+hipStream_t g_prep_stream[64];
+bool g_prep_tried[64];
+hipStream_t prep_stream(int device) {  // (the device is current)
+  if (device < 0 || device >= 64) return nullptr;
+  std::lock_guard<std::mutex> lock(g_prep_mu);
+  if (!g_prep_tried[device]) {
+    g_prep_tried[device] = true;
+    if (hipStreamCreateWithFlags(&g_prep_stream[device], hipStreamNonBlocking) != hipSuccess) {
+      g_prep_stream[device] = nullptr;
+      (void)hipGetLastError();
+    }
+  }
+  return g_prep_stream[device];
+}
 std::mutex g_pending_mu;
 std::deque<PendingPlan> g_pending[64];
 constexpr size_t kMaxPending = 8;
 
 void release_pending(PendingPlan &pp) {
   (void)hipEventDestroy(pp.done);
+  if (pp.prepared) (void)hipEventDestroy(pp.prepared);
   if (pp.h_desc) cached_host_free(pp.h_desc, pp.h_bytes);
   if (pp.plan) {
     if (pp.plan->d_blob) cached_free(pp.plan->d_blob, pp.plan->blob_bytes);
@@ -716,9 +745,12 @@ void kdehip_internal_drain_pending() {  // kdehip_clear_cache: nothing may stay 
     if (guard.enter(d) == KDEHIP_OK) reap_pending(d, true);
 }
 
-int kdehip_prod_philox_device(int Ndens, kdehip_device_density *const *trees, int64_t Np, int Niter, uint64_t seed,
-                              int64_t sample_offset, int addEntropy, const uint8_t *partialDimMask, int precision,
-                              double *d_points, int64_t *d_indices, int32_t *d_labels, void *stream) {
+namespace {
+// own_prep: prepare on the library's stream (an asynchronous caller: the next product's preparation overlaps this
+// product's sampling); a blocking caller, who waits for every product, keeps everything on its own stream
+int prod_philox_device(int Ndens, kdehip_device_density *const *trees, int64_t Np, int Niter, uint64_t seed,
+                       int64_t sample_offset, int addEntropy, const uint8_t *partialDimMask, int precision,
+                       double *d_points, int64_t *d_indices, int32_t *d_labels, void *stream, bool own_prep) {
   if (Ndens < 1 || !trees) return set_error(KDEHIP_ERR_ARG, "need at least one density");
   if (Ndens > KDEHIP_MAX_DENS) return set_error(KDEHIP_ERR_UNSUPPORTED, "more than KDEHIP_MAX_DENS densities in one product");
   if (precision != 64 && precision != 32) return set_error(KDEHIP_ERR_ARG, "precision must be 64 or 32");
@@ -776,11 +808,16 @@ int kdehip_prod_philox_device(int Ndens, kdehip_device_density *const *trees, in
   const size_t off_tables = align256(off_data + static_cast<size_t>(p->host.data_elems) * esz);
   const size_t total = off_tables + static_cast<size_t>(p->host.tab_entries) * esz;
   PendingPlan pend{p, nullptr, nullptr, off_perm};
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipStream_t prep = own_prep ? prep_stream(device) : nullptr;
   hipError_t e = cached_malloc(&p->d_blob, total);
   if (e == hipSuccess) p->blob_bytes = total;
   if (e == hipSuccess) e = cached_host_malloc(&pend.h_desc, pend.h_bytes);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&pend.done, hipEventDisableTiming);
+  if (e == hipSuccess && prep) e = hipEventCreateWithFlags(&pend.prepared, hipEventDisableTiming);
   if (e != hipSuccess) {
+    if (pend.done) (void)hipEventDestroy(pend.done);
+    pend.done = nullptr;
     if (pend.h_desc) cached_host_free(pend.h_desc, pend.h_bytes);
     if (p->d_blob) cached_free(p->d_blob, total);
     delete p;
@@ -801,14 +838,15 @@ int kdehip_prod_philox_device(int Ndens, kdehip_device_density *const *trees, in
       jobs[idx] = FillJob{ds.hdr_off, ds.perm_off, trees[j]->fr.off[lj], ds.n, ds.B, ds.F, ds.uniform_bw, j, 0};
       if (ds.B > maxB) maxB = ds.B;
     }
-  hipStream_t st = static_cast<hipStream_t>(stream);
   bind_plan(p, off_lev, off_count, off_tab, off_perm, off_data, off_tables, total);
+  hipStream_t ps = prep ? prep : st;  // where the plan is prepared
   auto fail = [&](int code) {  // (nothing of this plan has been handed to the queue yet)
+    if (prep) (void)hipStreamSynchronize(prep);
     (void)hipStreamSynchronize(st);
     release_pending(pend);
     return code;
   };
-  if (hipMemcpyAsync(p->d_blob, hb, off_perm, hipMemcpyHostToDevice, st) != hipSuccess)
+  if (hipMemcpyAsync(p->d_blob, hb, off_perm, hipMemcpyHostToDevice, ps) != hipSuccess)
     return fail(set_error(KDEHIP_ERR_HIP, "device product: descriptor upload failed"));
   FillArgs fa{};
   for (int j = 0; j < M; ++j) {
@@ -819,10 +857,10 @@ int kdehip_prod_philox_device(int Ndens, kdehip_device_density *const *trees, in
   fa.data = p->d_data;
   fa.perm_out = p->d_perm;
   fa.D = D;
-  rc = launch_fill_tiles(precision, fa, static_cast<int>(nlev), maxB, st);
+  rc = launch_fill_tiles(precision, fa, static_cast<int>(nlev), maxB, ps);
   if (rc != KDEHIP_OK) return fail(rc);
   rc = enqueue_philox(p, Np, Niter, seed, sample_offset, addEntropy, d_points, d_indices, d_labels, stream,
-                      /*private_plan=*/true);
+                      /*private_plan=*/true, nullptr, prep, pend.prepared);
   if (rc != KDEHIP_OK) return fail(rc);
   if (hipEventRecord(pend.done, st) != hipSuccess) return fail(set_error(KDEHIP_ERR_HIP, "device product: hipEventRecord failed"));
   {
@@ -830,6 +868,14 @@ int kdehip_prod_philox_device(int Ndens, kdehip_device_density *const *trees, in
     if (device >= 0 && device < 64) g_pending[device].push_back(pend);
   }
   return KDEHIP_OK;
+}
+}  // namespace
+
+int kdehip_prod_philox_device(int Ndens, kdehip_device_density *const *trees, int64_t Np, int Niter, uint64_t seed,
+                              int64_t sample_offset, int addEntropy, const uint8_t *partialDimMask, int precision,
+                              double *d_points, int64_t *d_indices, int32_t *d_labels, void *stream) {
+  return prod_philox_device(Ndens, trees, Np, Niter, seed, sample_offset, addEntropy, partialDimMask, precision, d_points,
+                            d_indices, d_labels, stream, /*own_prep=*/true);
 }
 
 // The same with HOST output buffers, blocking: what a host without device arrays of its own (a Julia caller without
@@ -850,8 +896,9 @@ int kdehip_prod_philox_resident(int Ndens, kdehip_device_density *const *trees, 
   hipError_t e = cached_host_malloc(&h_out, span);
   if (e != hipSuccess) { cached_free(d_out, span); return set_error(KDEHIP_ERR_HIP, "pinned result block"); }
   unsigned char *w = static_cast<unsigned char *>(d_out);
-  rc = kdehip_prod_philox_device(Ndens, trees, Np, Niter, seed, 0, addEntropy, partialDimMask, precision,
-                                 reinterpret_cast<double *>(w), reinterpret_cast<int64_t *>(w + off_i), nullptr, call_stream());
+  rc = prod_philox_device(Ndens, trees, Np, Niter, seed, 0, addEntropy, partialDimMask, precision,
+                          reinterpret_cast<double *>(w), reinterpret_cast<int64_t *>(w + off_i), nullptr, call_stream(),
+                          /*own_prep=*/false);
   if (rc == KDEHIP_OK) e = hipMemcpyAsync(h_out, d_out, span, hipMemcpyDeviceToHost, call_stream());
   const hipError_t se = hipStreamSynchronize(call_stream());  // (also before the blocks go back to the caches on an error)
   if (rc == KDEHIP_OK && e == hipSuccess && se == hipSuccess) {

@@ -40,7 +40,7 @@ def worker(t):
     bad = 0
     for _ in range(ncalls):
         j = jobs[int(r.integers(0, len(jobs)))]
-        kind = int(r.integers(0, 6))
+        kind = int(r.integers(0, 7))
         if kind == 0:
             got = kdehip.prodAppxMSGibbsS(None, j["trees"], None, None, Niter=j["Niter"], Np=j["Np"], seed=j["seed"])
             ok = np.array_equal(got[0], j["a"][0]) and np.array_equal(got[1], j["a"][1])
@@ -52,6 +52,19 @@ def worker(t):
         elif kind == 4:   # densities resident in HBM, handles shared by all threads; the plan queue is shared state
             got = kdehip.prodAppxMSGibbsS_resident(j["dd"], Np=j["Np"], Niter=j["Niter"], seed=j["seed"])
             ok = np.array_equal(got[0], j["a"][0]) and np.array_equal(got[1], j["a"][1])
+        elif kind == 6:   # asynchronous products of resident densities: three in a row, prepared under each other
+            import torch
+            dev = torch.device("cuda", 0)
+            D, M, Np = j["trees"][0].bt.dims, len(j["trees"]), j["Np"]
+            outs = [(torch.zeros(D * Np, dtype=torch.float64, device=dev), torch.zeros(M * Np, dtype=torch.int64, device=dev))
+                    for _ in range(3)]
+            torch.cuda.synchronize()
+            st = torch.cuda.Stream(device=dev)
+            for P, I in outs:
+                kdehip.prodAppxMSGibbsS_device(j["dd"], P, I, Np=Np, Niter=j["Niter"], seed=j["seed"], stream=st.cuda_stream)
+            st.synchronize()
+            ok = all(np.array_equal(P.cpu().numpy().reshape(Np, D).T, j["a"][0]) and
+                     np.array_equal(I.cpu().numpy().reshape(Np, M).T, j["a"][1]) for P, I in outs)
         elif kind == 5:   # kde!(points): the worker pool of the host tree builder is shared by every caller
             got = kdehip.kde_auto(j["x"], overlap=bool(r.integers(0, 2)))
             ok = all(np.array_equal(getattr(got, f), getattr(j["kd"], f)) for f in ("means", "bandwidth")) and \

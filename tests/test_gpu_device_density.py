@@ -45,6 +45,7 @@ def test_device_resident_product_equals_host_packed_product(D, Ns, Np, Niter, we
     P = torch.zeros(D * Np, dtype=torch.float64, device=dev)
     I = torch.zeros(M * Np, dtype=torch.int64, device=dev)
     st = torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()   # (the zero fills ran on torch's stream, the products run on `st`)
     for rep in range(3):   # (plans of earlier calls are released by later ones)
         kdehip.prodAppxMSGibbsS_device(dd, P, I, Np=Np, Niter=Niter, seed=seed, precision=prec, stream=st.cuda_stream)
     st.synchronize()
@@ -95,3 +96,42 @@ def test_device_density_errors():
         kdehip.prodAppxMSGibbsS_device(dd, 0, 0, Np=0)
     with pytest.raises(kdehip.KdeHipError):
         kdehip.prodAppxMSGibbsS_device(dd[:2], None, None, Np=10)   # null outputs
+
+
+def test_back_to_back_products_prepared_under_each_other():
+    """An asynchronous caller enqueues product after product: the library prepares product k+1 (descriptor upload, tile
+    gather, conditional tables) on a stream of its own while product k samples (csrc/product.hip prep_stream).  Forty
+    products of four different shapes, interleaved on two caller streams and the legacy default stream, every one into
+    its own output arrays: each must equal the blocking call with the same seed -- no plan may see another's tiles,
+    tables or recycled blocks."""
+    import torch
+    dev = torch.device("cuda", 0)
+    shapes = [(6, [1000] * 4, 2048, 2), (2, [200, 150, 300], 700, 3), (3, [2500] * 3, 96, 1), (4, [64, 640], 1024, 4)]
+    probs = []
+    for k, (D, Ns, Np, Niter) in enumerate(shapes):
+        trees = _trees(40 + k, D, Ns)
+        probs.append((D, len(Ns), Np, Niter, [kdehip.DeviceDensity(t) for t in trees], trees))
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev), None]
+    runs = []
+    outs = []
+    for c in range(40):
+        D, M, Np, Niter, dd, trees = probs[c % len(probs)]
+        outs.append((torch.zeros(D * Np, dtype=torch.float64, device=dev), torch.zeros(M * Np, dtype=torch.int64, device=dev)))
+    torch.cuda.synchronize()   # (the fills ran on torch's stream; the products below run on others)
+    for c in range(40):
+        D, M, Np, Niter, dd, trees = probs[c % len(probs)]
+        P, I = outs[c]
+        st = streams[c % len(streams)]
+        kdehip.prodAppxMSGibbsS_device(dd, P, I, Np=Np, Niter=Niter, seed=1000 + c,
+                                       stream=None if st is None else st.cuda_stream)
+        runs.append((c, P, I))
+    torch.cuda.synchronize()
+    for c, P, I in runs:
+        D, M, Np, Niter, dd, trees = probs[c % len(probs)]
+        rp, ri = kdehip.prodAppxMSGibbsS(None, trees, None, None, Niter=Niter, Np=Np, seed=1000 + c)
+        assert np.array_equal(I.cpu().numpy().reshape(Np, M).T, ri), c
+        assert np.array_equal(P.cpu().numpy().reshape(Np, D).T, rp), c
+    for pr in probs:
+        for d in pr[4]:
+            d.close()
+    kdehip._clib.kdehip_clear_cache()
