@@ -8,6 +8,7 @@
 #include <cstring>
 
 #include "device_density.hpp"
+#include "host_pool.hpp"
 #include "kdehip_internal.hpp"
 
 namespace kdehip {
@@ -148,10 +149,27 @@ int pack_layout(int Ndens, const kdehip_density *trees, int ndims, const uint8_t
   std::vector<TileShape> shapes(static_cast<size_t>(M) * (L + 1));
   out.front.clear();
   int64_t nodes = 0;
-  Frontiers fr;
+  // (one density's frontiers do not depend on another's: large products expand them on the host pool's threads)
+  std::vector<Frontiers> frs(static_cast<size_t>(M));
+  std::vector<int> rcs(static_cast<size_t>(M), KDEHIP_OK);
+  int64_t points = 0;
+  for (int j = 0; j < M; ++j) points += trees[j].npts;
+  HostPool *pool = (M > 1 && points >= 8192) ? &HostPool::get() : nullptr;
+  const bool look = pmode == kPackChecked;
+  if (pool && pool->workers() > 0) {
+    std::vector<HostPool::Ticket> tickets;
+    for (int j = 1; j < M; ++j)
+      tickets.push_back(pool->submit([trees, j, D, L, look, &frs, &rcs] { rcs[j] = expand_frontiers(trees[j], D, L, look, frs[j]); }));
+    rcs[0] = expand_frontiers(trees[0], D, L, look, frs[0]);
+    for (auto &tk : tickets) pool->join(tk);
+  } else {
+    for (int j = 0; j < M; ++j) rcs[j] = expand_frontiers(trees[j], D, L, look, frs[j]);
+  }
+  for (int j = 0; j < M; ++j)
+    if (rcs[j] != KDEHIP_OK)  // (again on THIS thread: the error message is thread-local)
+      return expand_frontiers(trees[j], D, L, look, frs[j]);
   for (int j = 0; j < M; ++j) {
-    const int rc = expand_frontiers(trees[j], D, L, pmode == kPackChecked, fr);
-    if (rc != KDEHIP_OK) return rc;
+    const Frontiers &fr = frs[j];
     const int64_t base = static_cast<int64_t>(out.front.size());
     out.front.insert(out.front.end(), fr.ids.begin(), fr.ids.end());
     for (int l = 0; l <= L; ++l) {
@@ -314,85 +332,121 @@ int pack_layout_shapes(int M, int D, int L, const TileShape *shapes, const uint8
 // Returns whether every value met the conditions of the fast arithmetic form (finite means below 1e100, positive
 // finite variances whose products stay in range, finite non-negative weights): what pack_layout's kPackChecked mode
 // establishes beforehand, found here on the values that are being copied anyway.
+// what the values of one density's tiles say about the fast arithmetic form
+struct FillFindings {
+  bool bad = false;
+  double lo[KDEHIP_MAX_DIMS], hi[KDEHIP_MAX_DIMS];
+  FillFindings() { for (int d = 0; d < KDEHIP_MAX_DIMS; ++d) { lo[d] = INFINITY; hi[d] = 0.0; } }
+};
+
+// the tiles of density j: levels 0 .. L, contiguous in `data` (and in `perm`), no other density's elements touched
+template <typename T>
+static void fill_density(const PackedProduct &pp, const kdehip_density &t, int j, T *data, int32_t *perm, FillFindings &f) {
+  const int D = pp.D, L = pp.L;
+  bool bad = false;
+  double *lo = f.lo, *hi = f.hi;
+  for (int l = 0; l <= L; ++l) {
+    const size_t idx = static_cast<size_t>(j) * (L + 1) + l;
+    const LevelDesc &ds = pp.levels[idx];
+    const int32_t *cur = pp.front.data() + pp.front_off[idx];
+    const int64_t n = ds.n, B = ds.B;
+    const int F = ds.F;
+    const bool uni = ds.uniform_bw != 0;
+    const int64_t RS = static_cast<int64_t>(F) * 64 + 1;
+    T *hdr = data + ds.hdr_off;
+    for (int d = 0; d < kTileHeader; ++d)
+      hdr[d] = d < D ? static_cast<T>(t.bandwidth[(static_cast<int64_t>(cur[0]) - 1) * D + d]) : T(0);
+    for (int d = 0; d < D; ++d) {  // (the one bandwidth vector of a uniform tile; entry 0's otherwise)
+      const double v = t.bandwidth[(static_cast<int64_t>(cur[0]) - 1) * D + d];
+      bad |= !(v > 0.0) | !(v < INFINITY);
+      lo[d] = v < lo[d] ? v : lo[d];
+      hi[d] = v > hi[d] ? v : hi[d];
+    }
+    T *tile = hdr + kTileHeader;
+    int32_t *prow = perm + ds.perm_off;
+    for (int64_t i = 0; i < B; ++i) {
+      int64_t src[64];  // source offset (node - 1) of lane ln's entry in this row, -1 = padding
+      for (int ln = 0; ln < 64; ++ln) {
+        const int64_t z = static_cast<int64_t>(ln) * B + i;
+        src[ln] = z < n ? static_cast<int64_t>(cur[z]) - 1 : -1;
+      }
+      T *row = tile + i * RS;
+      for (int d = 0; d < D; ++d) {
+        T *dst = row + d * 64;
+        for (int ln = 0; ln < 64; ++ln) dst[ln] = src[ln] >= 0 ? static_cast<T>(t.means[src[ln] * D + d]) : T(0);
+        // (checked on the 64 contiguous values just written: vectorisable, unlike the gather above)
+        T amax = T(0), nan_acc = T(0);
+        for (int ln = 0; ln < 64; ++ln) {
+          const T a = dst[ln] < T(0) ? -dst[ln] : dst[ln];
+          amax = a > amax ? a : amax;
+          nan_acc += dst[ln] * T(0);  // 0 for a finite value, NaN otherwise
+        }
+        bad |= !(static_cast<double>(amax) < 1e100) | !(nan_acc == T(0));
+      }
+      if (!uni)
+        for (int d = 0; d < D; ++d) {
+          T *dst = row + (D + d) * 64;
+          for (int ln = 0; ln < 64; ++ln) dst[ln] = src[ln] >= 0 ? static_cast<T>(t.bandwidth[src[ln] * D + d]) : T(1);
+          T l = dst[0], h = dst[0], nan_acc = T(0);  // (padding entries carry variance 1: neutral for the range test)
+          for (int ln = 0; ln < 64; ++ln) {
+            l = dst[ln] < l ? dst[ln] : l;
+            h = dst[ln] > h ? dst[ln] : h;
+            nan_acc += dst[ln] * T(0);
+          }
+          bad |= !(l > T(0)) | !(static_cast<double>(h) < INFINITY) | !(nan_acc == T(0));
+          lo[d] = static_cast<double>(l) < lo[d] ? static_cast<double>(l) : lo[d];
+          hi[d] = static_cast<double>(h) > hi[d] ? static_cast<double>(h) : hi[d];
+        }
+      T *wdst = row + (F - 1) * 64;
+      for (int ln = 0; ln < 64; ++ln) wdst[ln] = src[ln] >= 0 ? static_cast<T>(t.weights[src[ln]]) : T(0);
+      {
+        T wl = wdst[0], wh = wdst[0], nan_acc = T(0);
+        for (int ln = 0; ln < 64; ++ln) {
+          wl = wdst[ln] < wl ? wdst[ln] : wl;
+          wh = wdst[ln] > wh ? wdst[ln] : wh;
+          nan_acc += wdst[ln] * T(0);
+        }
+        bad |= !(wl >= T(0)) | !(static_cast<double>(wh) < INFINITY) | !(nan_acc == T(0));
+      }
+      row[F * 64] = T(0);  // the pad element
+      int32_t *pdst = prow + i * 64;
+      for (int ln = 0; ln < 64; ++ln) pdst[ln] = src[ln] >= 0 ? static_cast<int32_t>(t.permutation[src[ln]]) : 0;
+    }
+    // gap up to the next tile's aligned start
+    const int64_t end = ds.hdr_off + kTileHeader + B * RS;
+    const int64_t next = (idx + 1 < pp.levels.size()) ? pp.levels[idx + 1].hdr_off : pp.data_elems;
+    for (int64_t e = end; e < next; ++e) data[e] = T(0);
+  }
+  f.bad = bad;
+}
+
+constexpr int64_t kParallelFillElems = 32 * 1024;  // smaller products are packed by the calling thread alone (< 20 us)
+
 template <typename T>
 static bool fill_tiles(const PackedProduct &pp, const kdehip_density *trees, T *data, int32_t *perm) {
-  const int D = pp.D, M = pp.M, L = pp.L;
+  const int D = pp.D, M = pp.M;
+  std::vector<FillFindings> part(static_cast<size_t>(M));
+  // the densities' tiles are independent: each is packed by a thread of the host pool (csrc/host_pool.hpp), the
+  // calling thread takes the first and whatever no worker has started by the time it is done
+  HostPool *pool = (M > 1 && pp.data_elems >= kParallelFillElems) ? &HostPool::get() : nullptr;
+  if (pool && pool->workers() > 0) {
+    std::vector<HostPool::Ticket> tickets;
+    tickets.reserve(static_cast<size_t>(M - 1));
+    for (int j = 1; j < M; ++j)
+      tickets.push_back(pool->submit([&pp, trees, j, data, perm, &part] { fill_density<T>(pp, trees[j], j, data, perm, part[j]); }));
+    fill_density<T>(pp, trees[0], 0, data, perm, part[0]);
+    for (auto &tk : tickets) pool->join(tk);
+  } else {
+    for (int j = 0; j < M; ++j) fill_density<T>(pp, trees[j], j, data, perm, part[j]);
+  }
   bool bad = false;
   double lo[KDEHIP_MAX_DIMS], hi[KDEHIP_MAX_DIMS];
   for (int d = 0; d < KDEHIP_MAX_DIMS; ++d) { lo[d] = INFINITY; hi[d] = 0.0; }
   for (int j = 0; j < M; ++j) {
-    const kdehip_density &t = trees[j];
-    for (int l = 0; l <= L; ++l) {
-      const size_t idx = static_cast<size_t>(j) * (L + 1) + l;
-      const LevelDesc &ds = pp.levels[idx];
-      const int32_t *cur = pp.front.data() + pp.front_off[idx];
-      const int64_t n = ds.n, B = ds.B;
-      const int F = ds.F;
-      const bool uni = ds.uniform_bw != 0;
-      const int64_t RS = static_cast<int64_t>(F) * 64 + 1;
-      T *hdr = data + ds.hdr_off;
-      for (int d = 0; d < kTileHeader; ++d)
-        hdr[d] = d < D ? static_cast<T>(t.bandwidth[(static_cast<int64_t>(cur[0]) - 1) * D + d]) : T(0);
-      for (int d = 0; d < D; ++d) {  // (the one bandwidth vector of a uniform tile; entry 0's otherwise)
-        const double v = t.bandwidth[(static_cast<int64_t>(cur[0]) - 1) * D + d];
-        bad |= !(v > 0.0) | !(v < INFINITY);
-        lo[d] = v < lo[d] ? v : lo[d];
-        hi[d] = v > hi[d] ? v : hi[d];
-      }
-      T *tile = hdr + kTileHeader;
-      int32_t *prow = perm + ds.perm_off;
-      for (int64_t i = 0; i < B; ++i) {
-        int64_t src[64];  // source offset (node - 1) of lane ln's entry in this row, -1 = padding
-        for (int ln = 0; ln < 64; ++ln) {
-          const int64_t z = static_cast<int64_t>(ln) * B + i;
-          src[ln] = z < n ? static_cast<int64_t>(cur[z]) - 1 : -1;
-        }
-        T *row = tile + i * RS;
-        for (int d = 0; d < D; ++d) {
-          T *dst = row + d * 64;
-          for (int ln = 0; ln < 64; ++ln) dst[ln] = src[ln] >= 0 ? static_cast<T>(t.means[src[ln] * D + d]) : T(0);
-          // (checked on the 64 contiguous values just written: vectorisable, unlike the gather above)
-          T amax = T(0), nan_acc = T(0);
-          for (int ln = 0; ln < 64; ++ln) {
-            const T a = dst[ln] < T(0) ? -dst[ln] : dst[ln];
-            amax = a > amax ? a : amax;
-            nan_acc += dst[ln] * T(0);  // 0 for a finite value, NaN otherwise
-          }
-          bad |= !(static_cast<double>(amax) < 1e100) | !(nan_acc == T(0));
-        }
-        if (!uni)
-          for (int d = 0; d < D; ++d) {
-            T *dst = row + (D + d) * 64;
-            for (int ln = 0; ln < 64; ++ln) dst[ln] = src[ln] >= 0 ? static_cast<T>(t.bandwidth[src[ln] * D + d]) : T(1);
-            T l = dst[0], h = dst[0], nan_acc = T(0);  // (padding entries carry variance 1: neutral for the range test)
-            for (int ln = 0; ln < 64; ++ln) {
-              l = dst[ln] < l ? dst[ln] : l;
-              h = dst[ln] > h ? dst[ln] : h;
-              nan_acc += dst[ln] * T(0);
-            }
-            bad |= !(l > T(0)) | !(static_cast<double>(h) < INFINITY) | !(nan_acc == T(0));
-            lo[d] = static_cast<double>(l) < lo[d] ? static_cast<double>(l) : lo[d];
-            hi[d] = static_cast<double>(h) > hi[d] ? static_cast<double>(h) : hi[d];
-          }
-        T *wdst = row + (F - 1) * 64;
-        for (int ln = 0; ln < 64; ++ln) wdst[ln] = src[ln] >= 0 ? static_cast<T>(t.weights[src[ln]]) : T(0);
-        {
-          T wl = wdst[0], wh = wdst[0], nan_acc = T(0);
-          for (int ln = 0; ln < 64; ++ln) {
-            wl = wdst[ln] < wl ? wdst[ln] : wl;
-            wh = wdst[ln] > wh ? wdst[ln] : wh;
-            nan_acc += wdst[ln] * T(0);
-          }
-          bad |= !(wl >= T(0)) | !(static_cast<double>(wh) < INFINITY) | !(nan_acc == T(0));
-        }
-        row[F * 64] = T(0);  // the pad element
-        int32_t *pdst = prow + i * 64;
-        for (int ln = 0; ln < 64; ++ln) pdst[ln] = src[ln] >= 0 ? static_cast<int32_t>(t.permutation[src[ln]]) : 0;
-      }
-      // gap up to the next tile's aligned start
-      const int64_t end = ds.hdr_off + kTileHeader + B * RS;
-      const int64_t next = (idx + 1 < pp.levels.size()) ? pp.levels[idx + 1].hdr_off : pp.data_elems;
-      for (int64_t e = end; e < next; ++e) data[e] = T(0);
+    bad |= part[j].bad;
+    for (int d = 0; d < D; ++d) {
+      lo[d] = part[j].lo[d] < lo[d] ? part[j].lo[d] : lo[d];
+      hi[d] = part[j].hi[d] > hi[d] ? part[j].hi[d] : hi[d];
     }
   }
   return !bad && variances_in_range(lo, hi, D, pp.precision);

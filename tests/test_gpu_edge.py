@@ -219,3 +219,21 @@ def test_allocation_cache_reuse_and_clear():
             assert np.allclose(p, oracle.eval_direct(op[0], kdehip.getPoints(gp[1])[:, :17]), rtol=1e-11)
         if rep == 1:
             _lib.lib.kdehip_clear_cache()
+
+
+@pytest.mark.parametrize("N", [300, 6000])   # packed by the calling thread alone / on the host pool's threads
+def test_malformed_tree_is_refused_with_its_message(N):
+    """A child array that makes a frontier outgrow its density (here: the root is its own two children) must be refused
+    by the packer -- with the message in the CALLING thread's error slot, also when the frontiers of a large product are
+    expanded on the library's worker threads (csrc/pack_levels.cpp, csrc/host_pool.hpp)."""
+    rng = np.random.default_rng(3)
+    good = [kdehip.kde(rng.standard_normal((2, N)), np.full(2, 0.3)) for _ in range(3)]
+    bad = kdehip.kde(rng.standard_normal((2, N)), np.full(2, 0.3))
+    bad.bt.left_child[0] = 1
+    bad.bt.right_child[0] = 1
+    for order in ([good[0], bad, good[1]], [bad, good[0], good[1]], [good[0], good[1], good[2], bad]):
+        with pytest.raises(kdehip.KdeHipError, match="malformed tree"):
+            kdehip.ProductPlan(order)
+    with kdehip.ProductPlan(good) as plan:   # (and the pool is none the worse for it)
+        p, i = plan.sample(64, Niter=1, seed=2)
+        assert np.isfinite(p).all()
