@@ -213,7 +213,8 @@ int kdehip_density_ndim(const kdehip_device_density *d);
  * -- everything that touches the outputs -- runs on `stream` (hipStream_t, NULL = default stream); the preparation of
  * the product (descriptor upload, tile gather, tables: it reads only the immutable densities and writes only the
  * plan's own block) runs on a stream of the library's, and `stream` waits for it: of products enqueued back to back,
- * number k+1 is prepared while number k samples.  d_points (double[ndims*Np]), d_indices (int64[Ndens*Np]) and the optional
+ * number k+1 is prepared while number k samples.  (Because of that second stream a call cannot be recorded by a stream
+ * capture on `stream`; graphs are made of the runs of a resident plan, kdehip_product_sample_*.)  d_points (double[ndims*Np]), d_indices (int64[Ndens*Np]) and the optional
  * d_labels (as kdehip_product_sample_philox) are device pointers on the densities' device.  Random numbers: the
  * device Philox stream keyed by (seed, sample_offset + s, draw).  The plan built for the call is released by a later
  * call (or kdehip_clear_cache) once its work has run; at most 8 such calls are in flight per device. */
