@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <random>
+#include <thread>
 #include <vector>
 #include "kdehip.h"
 #include "kdehip_internal.hpp"
@@ -39,6 +40,23 @@ int main() {
       ++cases;
     }
   }
-  printf("ok: %d pack_levels cases\n", cases);
+  // several callers at once: the tree builder and the packer share the library's worker threads (csrc/host_pool.hpp)
+  std::vector<std::thread> callers;
+  std::vector<int> failed(4, 0);
+  for (int c = 0; c < 4; ++c)
+    callers.emplace_back([c, &failed] {
+      std::mt19937_64 gc(100 + c);
+      for (int rep = 0; rep < 6; ++rep) {
+        const int D = 1 + (c + rep) % 6, M = 2 + rep % 4;
+        std::vector<Dens> ds; std::vector<kdehip_density> cd;
+        for (int j = 0; j < M; ++j) ds.push_back(make(D, 600 + 900 * ((j + c) % 4), gc));
+        for (auto &d : ds) { kdehip_density k{}; k.npts = d.N; k.ndim = d.D; k.means = d.means.data(); k.bandwidth = d.bw.data(); k.weights = d.w.data(); k.left_child = d.l.data(); k.right_child = d.r.data(); k.permutation = d.perm.data(); cd.push_back(k); }
+        PackedProduct out;
+        if (pack_levels(M, cd.data(), D, nullptr, 64, out)) failed[c] = 1;
+      }
+    });
+  for (auto &t : callers) t.join();
+  for (int f : failed) if (f) { printf("concurrent pack failed\n"); return 1; }
+  printf("ok: %d pack_levels cases, 4 concurrent callers\n", cases);
   return 0;
 }
