@@ -535,7 +535,7 @@ __global__ __launch_bounds__(kLooThreads) void loo_round_partial_kernel(const Lo
 // delivers a tile's LAST slot (a counter per tile): no second launch, and the search state of the next round is
 // advanced in the next launch's prologue.  (Measured at 6 x 2048, scripts in profiles/r03_loocv.md: the arithmetic of a
 // round fell from 21 us to 4 items of 2.9 us per SIMD = 11.6 us (3264 items on 1024 SIMDs: 3.2 each would do); the
-// hand-over costs 0.4 us per step and 3.5 us for the last tile's loads: 25.8 -> 19 us a round.)
+// hand-over costs 0.4 us per step and 3.5 us for the last tile's loads: 25.8 -> 17.9 us a round.)
 constexpr int kTile = 64;
 constexpr int kPairWaves = 16;  // (items of 16 wavefronts fill a CU evenly -- 4 per SIMD; workgroups of 4 were dealt 2-6 to a CU)
 constexpr int64_t kFusedMaxN = 4096;
@@ -554,12 +554,12 @@ __device__ __forceinline__ double slot_load(const double *p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void slots_delivered() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-// all T slots of `tile` are in place: total per query in source order, W*log p, the tile's share of the log-likelihood
 struct PairSet {  // where one probe of a launch keeps its slots [D][T][T][64], counters [D][T] and tile shares [T]
   double *slots;
   unsigned *arrivals;
   double *shares;
 };
+// all T slots of `tile` are in place: total per query in source order, W*log p, the tile's share of the log-likelihood
 __device__ __forceinline__ void pairs_finish_tile(const LooRound &r, const PairSet &ps, int d, int tile, int lane, double bw_eval) {
   const int T = r.ngroups;
   if (lane == 0) ps.arrivals[(d * T + tile) * kCounterStride] = 0;  // every slot is in: nobody counts on this tile again before the next round
