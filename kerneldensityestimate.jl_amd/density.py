@@ -21,16 +21,24 @@ class BallTree:
 
 class BallTreeDensity:
     """Fields of the reference `BallTreeDensity`; `bandwidth` holds VARIANCES (src/KDE01.jl:45)."""
-    __slots__ = ("bt", "multibandwidth", "means", "bandwidth", "bandwidthMin", "bandwidthMax")
+    __slots__ = ("bt", "multibandwidth", "means", "bandwidth", "bandwidthMin", "bandwidthMax", "_cstruct_cache")
 
     def __repr__(self):
         return f"BallTreeDensity(dims={Ndim(self)}, Npts={Npts(self)}, bws={np.round(getBW(self)[:, 0], 6)})"
 
     def _cstruct(self):
+        """The C view of the six arrays a product reads (kdehip_density); kept while the arrays are the same objects."""
         bt = self.bt
-        return _lib.CDensity(bt.num_points, bt.dims, ptr(self.means, f64p), ptr(self.bandwidth, f64p),
-                             ptr(bt.weights, f64p), ptr(bt.left_child, i64p), ptr(bt.right_child, i64p),
-                             ptr(bt.permutation, i64p))
+        key = (id(self.means), id(self.bandwidth), id(bt.weights), id(bt.left_child), id(bt.right_child),
+               id(bt.permutation), bt.num_points, bt.dims)
+        cached = getattr(self, "_cstruct_cache", None)
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        cs = _lib.CDensity(bt.num_points, bt.dims, ptr(self.means, f64p), ptr(self.bandwidth, f64p),
+                           ptr(bt.weights, f64p), ptr(bt.left_child, i64p), ptr(bt.right_child, i64p),
+                           ptr(bt.permutation, i64p))
+        self._cstruct_cache = (key, cs)
+        return cs
 
     # `bd(pos)`: evaluate the density at points (reference functor, src/DualTree01.jl:431-446)
     def __call__(self, pos, lvFlag=False, errTol=1e-3):

@@ -252,12 +252,12 @@ def prodAppxMSGibbsS_resident(trees, *, Np, Niter=3, seed=0, addEntropy=True, pa
     M, D = len(trees), trees[0].dims
     arr = (C.c_void_p * M)(*[t._h for t in trees])
     mask = _mask_array(partialDimMask, M, D)
-    pts = np.zeros(D * Np)
-    ind = np.ones(M * Np, dtype=np.int64)
+    pts = np.empty(D * Np)   # (every element is written by the call)
+    ind = np.empty(M * Np, dtype=np.int64)
     _lib.check(_lib.lib.kdehip_prod_philox_resident(M, arr, int(Np), int(Niter), C.c_uint64(int(seed) & (2 ** 64 - 1)),
                                                     int(bool(addEntropy)), None if mask is None else ptr(mask, u8p),
                                                     int(precision), ptr(pts, f64p), ptr(ind, i64p)))
-    return pts.reshape(Np, D).T.copy(), ind.reshape(Np, M).T.copy()
+    return pts.reshape(Np, D).T, ind.reshape(Np, M).T
 
 
 def philox_streams(seed, sample_begin, nsamples, K, R):
@@ -373,8 +373,8 @@ def prodAppxMSGibbsS(npd0, trees, anFcns=None, anParams=None, *deprecated_niter,
     trees = trees[:Ndens]
     arr = (_lib.CDensity * Ndens)(*[t._cstruct() for t in trees])
     mask = _mask_array(partialDimMask, Ndens, ndims)
-    pts = np.zeros(ndims * Np)
-    ind = np.ones(Ndens * Np, dtype=np.int64)
+    pts = np.empty(ndims * Np)   # (every element is written by the call)
+    ind = np.empty(Ndens * Np, dtype=np.int64)
     labels = np.zeros((Np, Ndens, nlevels(max(Npts(t) for t in trees))), dtype=np.int32) if trace else None
     _lib.check(_lib.lib.kdehip_prod_philox(int(Ndens), arr, int(Np), int(Niter), ptr(pts, f64p), ptr(ind, i64p),
                                            C.c_uint64(int(seed) & (2 ** 64 - 1)), int(bool(addEntropy)), int(ndims),
@@ -382,7 +382,8 @@ def prodAppxMSGibbsS(npd0, trees, anFcns=None, anParams=None, *deprecated_niter,
                                            int(ngpus), None if labels is None else ptr(labels, i32p)))
     if trace:
         glbs._fill(labels, Niter)
-    return pts.reshape(Np, ndims).T.copy(), ind.reshape(Np, Ndens).T.copy()
+    # (ndims, Np) and (Ndens, Np) as the reference returns them: column-major matrices -- views of the flat buffers
+    return pts.reshape(Np, ndims).T, ind.reshape(Np, Ndens).T
 
 
 def mul(trees, *, glbs=None, addEntropy=True, seed=None, device=0):
