@@ -12,6 +12,8 @@
 #include <cfloat>
 #include <cstdint>
 #include <cstring>
+#include <exception>
+#include <string>
 #include <utility>
 #include <vector>
 
@@ -107,7 +109,12 @@ class DensityBuilder {
       Scratch mine(D_);
       subtree(first, mid, a, next, depth - 1, mine);
     });
-    subtree(mid + 1, last, b, next_right, depth - 1, s);
+    try {
+      subtree(mid + 1, last, b, next_right, depth - 1, s);
+    } catch (...) {
+      try { pool.join(left); } catch (...) {}  // (the left side must not outlive this frame)
+      throw;
+    }
     pool.join(left);  // (runs it here if no worker has started it)
     summarize(id);
   }
@@ -294,9 +301,13 @@ extern "C" int kdehip_make_density(int64_t D, int64_t N, const double *points, c
       bandwidthMax[i * D + k] = var[static_cast<size_t>(k)];
     }
   }
-  DensityBuilder(D, N, points, centers, ranges, weights, left_child, right_child, lowest_leaf, highest_leaf,
-                 permutation, means, bandwidth)
-      .build(wnorm.data(), var.data());
+  try {
+    DensityBuilder(D, N, points, centers, ranges, weights, left_child, right_child, lowest_leaf, highest_leaf,
+                   permutation, means, bandwidth)
+        .build(wnorm.data(), var.data());
+  } catch (const std::exception &e) {  // (scratch allocation on this or a worker thread: nothing may cross the C boundary)
+    return set_error(KDEHIP_ERR_ALLOC, std::string("kdehip_make_density: ") + e.what());
+  }
   return KDEHIP_OK;
 }
 

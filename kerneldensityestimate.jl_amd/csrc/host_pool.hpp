@@ -10,10 +10,12 @@
 #include <atomic>
 #include <condition_variable>
 #include <deque>
+#include <exception>
 #include <functional>
 #include <memory>
 #include <mutex>
 #include <thread>
+#include <vector>
 
 #include <pthread.h>
 
@@ -24,6 +26,7 @@ class HostPool {
   struct Task {
     std::function<void()> fn;
     std::atomic<int> state{0};  // 0 queued, 1 claimed (running), 2 done
+    std::exception_ptr error;   // what fn threw, if anything (written before state 2; rethrown by join)
   };
   using Ticket = std::shared_ptr<Task>;
 
@@ -46,15 +49,21 @@ class HostPool {
     return t;
   }
 
-  // returns when the task has run -- on a worker, or here if none has started it yet
+  // returns when the task has run -- on a worker, or here if none has started it yet; an exception the task threw
+  // (an allocation failure, say) is thrown again here, in the thread that waits for the result
   void join(const Ticket &t) {
-    if (run_if_unclaimed(*t)) return;
-    for (int spin = 0; spin < 4096; ++spin) {
-      if (t->state.load(std::memory_order_acquire) == 2) return;
-      __builtin_ia32_pause();
+    if (!run_if_unclaimed(*t)) {
+      bool done = false;
+      for (int spin = 0; spin < 4096 && !done; ++spin) {
+        done = t->state.load(std::memory_order_acquire) == 2;
+        if (!done) cpu_relax();
+      }
+      if (!done) {
+        std::unique_lock<std::mutex> lock(done_mu_);
+        done_cv_.wait(lock, [&] { return t->state.load(std::memory_order_acquire) == 2; });
+      }
     }
-    std::unique_lock<std::mutex> lock(done_mu_);
-    done_cv_.wait(lock, [&] { return t->state.load(std::memory_order_acquire) == 2; });
+    if (t->error) std::rethrow_exception(t->error);
   }
 
  private:
@@ -75,10 +84,21 @@ class HostPool {
       if (HostPool *p = self_.load(std::memory_order_acquire)) p->nworkers_.store(0, std::memory_order_relaxed);
     });
   }
+  static void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#else
+    std::this_thread::yield();
+#endif
+  }
   static bool run_if_unclaimed(Task &t) {
     int expect = 0;
     if (!t.state.compare_exchange_strong(expect, 1, std::memory_order_acq_rel)) return false;
-    t.fn();
+    try {
+      t.fn();
+    } catch (...) {
+      t.error = std::current_exception();
+    }
     t.state.store(2, std::memory_order_release);
     return true;
   }
@@ -104,6 +124,33 @@ class HostPool {
   std::mutex mu_, done_mu_;
   std::condition_variable cv_, done_cv_;
   std::deque<Ticket> queue_;
+};
+
+// A group of tasks that refer to the caller's frame: wait() rethrows the first exception a task threw; leaving the frame
+// any other way (an exception of the caller's own work) still waits for every task first.
+class TaskGroup {
+ public:
+  explicit TaskGroup(HostPool &pool) : pool_(pool) {}
+  TaskGroup(const TaskGroup &) = delete;
+  TaskGroup &operator=(const TaskGroup &) = delete;
+  ~TaskGroup() {
+    for (auto &t : tickets_) {
+      try { pool_.join(t); } catch (...) {}
+    }
+  }
+  void run(std::function<void()> fn) { tickets_.push_back(pool_.submit(std::move(fn))); }
+  void wait() {
+    std::exception_ptr first;
+    for (auto &t : tickets_) {
+      try { pool_.join(t); } catch (...) { if (!first) first = std::current_exception(); }
+    }
+    tickets_.clear();
+    if (first) std::rethrow_exception(first);
+  }
+
+ private:
+  HostPool &pool_;
+  std::vector<HostPool::Ticket> tickets_;
 };
 
 }  // namespace kdehip

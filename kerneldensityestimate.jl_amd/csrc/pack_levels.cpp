@@ -157,11 +157,11 @@ int pack_layout(int Ndens, const kdehip_density *trees, int ndims, const uint8_t
   HostPool *pool = (M > 1 && points >= 8192) ? &HostPool::get() : nullptr;
   const bool look = pmode == kPackChecked;
   if (pool && pool->workers() > 0) {
-    std::vector<HostPool::Ticket> tickets;
+    TaskGroup group(*pool);
     for (int j = 1; j < M; ++j)
-      tickets.push_back(pool->submit([trees, j, D, L, look, &frs, &rcs] { rcs[j] = expand_frontiers(trees[j], D, L, look, frs[j]); }));
+      group.run([trees, j, D, L, look, &frs, &rcs] { rcs[j] = expand_frontiers(trees[j], D, L, look, frs[j]); });
     rcs[0] = expand_frontiers(trees[0], D, L, look, frs[0]);
-    for (auto &tk : tickets) pool->join(tk);
+    group.wait();
   } else {
     for (int j = 0; j < M; ++j) rcs[j] = expand_frontiers(trees[j], D, L, look, frs[j]);
   }
@@ -430,12 +430,11 @@ static bool fill_tiles(const PackedProduct &pp, const kdehip_density *trees, T *
   // calling thread takes the first and whatever no worker has started by the time it is done
   HostPool *pool = (M > 1 && pp.data_elems >= kParallelFillElems) ? &HostPool::get() : nullptr;
   if (pool && pool->workers() > 0) {
-    std::vector<HostPool::Ticket> tickets;
-    tickets.reserve(static_cast<size_t>(M - 1));
+    TaskGroup group(*pool);
     for (int j = 1; j < M; ++j)
-      tickets.push_back(pool->submit([&pp, trees, j, data, perm, &part] { fill_density<T>(pp, trees[j], j, data, perm, part[j]); }));
+      group.run([&pp, trees, j, data, perm, &part] { fill_density<T>(pp, trees[j], j, data, perm, part[j]); });
     fill_density<T>(pp, trees[0], 0, data, perm, part[0]);
-    for (auto &tk : tickets) pool->join(tk);
+    group.wait();
   } else {
     for (int j = 0; j < M; ++j) fill_density<T>(pp, trees[j], j, data, perm, part[j]);
   }
