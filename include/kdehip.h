@@ -291,6 +291,15 @@ int kdehip_evaluate(const kdehip_density *bd, const double *pos, int64_t Nq, int
  * deviations; nevals (optional): number of likelihood evaluations. */
 int kdehip_auto_bandwidth(int64_t D, int64_t N, const double *points, double *bw_out, int32_t *nevals,
                           int device);
+/* `kde!(points)` in one call (src/KDE01.jl:3-27: LOOCV bandwidth per dimension, then kde!(points, bwds)): the host tree
+ * builder runs on the library's worker threads WHILE the GPU searches the bandwidth -- topology, bounding boxes,
+ * weights and means do not depend on it -- and the variances are filled in afterwards.  Arrays as
+ * kdehip_make_density (unit weights), bw_out and nevals as kdehip_auto_bandwidth; bit-identical to the two calls one
+ * after the other.  N >= 2. */
+int kdehip_make_density_auto(int64_t D, int64_t N, const double *points, double *bw_out, int32_t *nevals, int device,
+                             double *centers, double *ranges, double *weights, int64_t *left_child, int64_t *right_child,
+                             int64_t *lowest_leaf, int64_t *highest_leaf, int64_t *permutation, double *means,
+                             double *bandwidth, double *bandwidthMin, double *bandwidthMax);
 
 #ifdef __cplusplus
 }

@@ -12,9 +12,6 @@ from ._lib import f64p, ptr
 from .density import BallTreeDensity, kde
 
 
-_OVERLAP_MIN_POINTS = 1024
-
-
 def auto_bandwidth(points, device=0, return_evals=False):
     """Per-dimension LOOCV bandwidth (standard deviations) that `kde!(points)` selects."""
     pts = np.asarray(points, dtype=np.float64)
@@ -31,40 +28,29 @@ def auto_bandwidth(points, device=0, return_evals=False):
 def kde_auto(points, device=0, overlap=None) -> BallTreeDensity:
     """`kde!(points)`: LOOCV bandwidth per dimension, then `kde!(points, bwds)` (src/KDE01.jl:24).
 
-    The tree's topology, bounding boxes, weights and means do not depend on the bandwidth: the host builder runs
-    WHILE the GPU searches the bandwidth (the search is a chain of ~20 dependent launches; the blocking C call releases
-    the GIL), and the variances are filled in afterwards (kdehip_density_set_bandwidth) -- bit-identical to building with
-    the final bandwidth.  `overlap`: None = where it pays (large densities: starting a host thread costs about what the
-    pooled builder needs for 2048 points, csrc/host_pool.hpp)."""
-    import threading
+    The tree's topology, bounding boxes, weights and means do not depend on the bandwidth: the host builder runs on the
+    library's worker threads WHILE the GPU searches the bandwidth, and the variances are filled in afterwards
+    (kdehip_make_density_auto) -- bit-identical to building with the final bandwidth.  `overlap=False`: the two steps one
+    after the other (what the tests compare with)."""
     pts = np.asarray(points, dtype=np.float64)
     if pts.ndim == 1:
         pts = pts.reshape(1, -1)
     D, N = pts.shape
     if overlap is None:
-        overlap = N >= _OVERLAP_MIN_POINTS
+        overlap = True
     if N < 2 or not overlap:
         return kde(pts, auto_bandwidth(pts, device=device))
-    box = {}
-
-    def search():
-        try:
-            box["bw"] = auto_bandwidth(pts, device=device)
-        except BaseException as e:  # noqa: BLE001  (re-raised in the caller's thread)
-            box["err"] = e
-    th = threading.Thread(target=search)
-    th.start()
-    bd = kde(pts, np.ones(D))   # (one density: the host builder is the faster one; placeholder bandwidth)
-    th.join()
-    if "err" in box:
-        raise box["err"]
-    bw = np.ascontiguousarray(box["bw"], dtype=np.float64)
+    from .density import _empty_density
+    flat = np.ascontiguousarray(pts.T).ravel()
+    bd = _empty_density(D, N)
     bt = bd.bt
+    bw = np.empty(D)
     i64p = _lib.i64p
-    _lib.check(_lib.lib.kdehip_density_set_bandwidth(D, N, ptr(bw, f64p), bw.size, ptr(bt.weights, f64p),
-                                                     ptr(bt.left_child, i64p), ptr(bt.right_child, i64p),
-                                                     ptr(bd.means, f64p), ptr(bd.bandwidth, f64p),
-                                                     ptr(bd.bandwidthMin, f64p), ptr(bd.bandwidthMax, f64p)))
+    _lib.check(_lib.lib.kdehip_make_density_auto(
+        D, N, ptr(flat, f64p), ptr(bw, f64p), None, int(device), ptr(bt.centers, f64p), ptr(bt.ranges, f64p),
+        ptr(bt.weights, f64p), ptr(bt.left_child, i64p), ptr(bt.right_child, i64p), ptr(bt.lowest_leaf, i64p),
+        ptr(bt.highest_leaf, i64p), ptr(bt.permutation, i64p), ptr(bd.means, f64p), ptr(bd.bandwidth, f64p),
+        ptr(bd.bandwidthMin, f64p), ptr(bd.bandwidthMax, f64p)))
     return bd
 
 

@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "fastexp.hpp"
+#include "host_pool.hpp"
 #include "kdehip_internal.hpp"
 
 namespace kdehip {
@@ -872,4 +873,35 @@ extern "C" int kdehip_auto_bandwidth(int64_t D64, int64_t N, const double *point
                  static_cast<long long>(N), us(t_begin, t_prep), rounds, batches, us(t_prep, tnow()));
   }
   return KDEHIP_OK;
+}
+
+// kde!(points) (src/KDE01.jl:3-27) with the tree built under the bandwidth search: the builder is a task of the host
+// pool (and hands its own subtrees on from there), the search keeps this thread until the GPU is done.
+extern "C" int kdehip_make_density_auto(int64_t D, int64_t N, const double *points, double *bw_out, int32_t *nevals, int device,
+                                        double *centers, double *ranges, double *weights, int64_t *left_child,
+                                        int64_t *right_child, int64_t *lowest_leaf, int64_t *highest_leaf,
+                                        int64_t *permutation, double *means, double *bandwidth, double *bandwidthMin,
+                                        double *bandwidthMax) {
+  using namespace kdehip;
+  if (D < 1 || N < 2) return set_error(KDEHIP_ERR_ARG, "kdehip_make_density_auto: need D >= 1 and N >= 2");
+  if (!points || !bw_out || !centers || !ranges || !weights || !left_child || !right_child || !lowest_leaf ||
+      !highest_leaf || !permutation || !means || !bandwidth || !bandwidthMin || !bandwidthMax)
+    return set_error(KDEHIP_ERR_ARG, "kdehip_make_density_auto: null pointer");
+  int tree_rc = KDEHIP_OK, rc = KDEHIP_OK;
+  try {
+    TaskGroup group(HostPool::get());
+    group.run([&] {
+      const double one = 1.0;  // (placeholder bandwidth: only `bandwidth`, bandwidthMin/Max depend on it)
+      tree_rc = kdehip_make_density(D, N, points, &one, 1, nullptr, centers, ranges, weights, left_child, right_child,
+                                    lowest_leaf, highest_leaf, permutation, means, bandwidth, bandwidthMin, bandwidthMax);
+    });
+    rc = kdehip_auto_bandwidth(D, N, points, bw_out, nevals, device);
+    group.wait();
+  } catch (const std::exception &e) {
+    return set_error(KDEHIP_ERR_ALLOC, std::string("kdehip_make_density_auto: ") + e.what());
+  }
+  if (rc != KDEHIP_OK) return rc;  // (message set by the search, on this thread)
+  if (tree_rc != KDEHIP_OK) return set_error(tree_rc, "kdehip_make_density_auto: the tree build failed");
+  return kdehip_density_set_bandwidth(D, N, bw_out, D, weights, left_child, right_child, means, bandwidth, bandwidthMin,
+                                      bandwidthMax);
 }

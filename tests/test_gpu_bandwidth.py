@@ -127,15 +127,27 @@ def test_star_product():
 
 
 def test_kde_auto_builds_its_tree_under_the_search_and_equals_the_sequential_form():
-    """`kde!(points)` = LOOCV bandwidth, then `kde!(points, bw)` (src/KDE01.jl:3-27).  The mirror builds the tree on the host
-    WHILE the GPU searches (topology and means do not depend on the bandwidth) and fills the variances in afterwards:
-    every array must be bit-identical to the two steps run one after the other."""
+    """`kde!(points)` = LOOCV bandwidth, then `kde!(points, bw)` (src/KDE01.jl:3-27).  kdehip_make_density_auto builds the
+    tree on the library's host threads WHILE the GPU searches (topology and means do not depend on the bandwidth) and
+    fills the variances in afterwards: every array must be bit-identical to the two steps run one after the other."""
     rng = np.random.default_rng(21)
-    for D, N, overlap in [(1, 100, True), (3, 257, True), (6, 2048, True), (6, 2048, None), (2, 9000, None), (3, 1000, None)]:
+    for D, N in [(1, 2), (1, 100), (3, 257), (6, 2048), (2, 9000), (3, 1000), (8, 513)]:
         pts = rng.standard_normal((D, N)) * rng.uniform(0.5, 2.0, size=(D, 1))
-        a = kdehip.kde_auto(pts, overlap=overlap)   # (None: the mirror's own choice -- from 1024 points up)
-        b = kdehip.kde(pts, kdehip.auto_bandwidth(pts))
-        for f in ("means", "bandwidth", "bandwidthMin", "bandwidthMax"):
-            assert np.array_equal(getattr(a, f), getattr(b, f)), (D, N, f)
-        for f in ("centers", "ranges", "weights", "left_child", "right_child", "permutation"):
-            assert np.array_equal(getattr(a.bt, f), getattr(b.bt, f)), (D, N, f)
+        a = kdehip.kde_auto(pts)
+        b = kdehip.kde_auto(pts, overlap=False)
+        c = kdehip.kde(pts, kdehip.auto_bandwidth(pts))
+        for other in (b, c):
+            for f in ("means", "bandwidth", "bandwidthMin", "bandwidthMax"):
+                assert np.array_equal(getattr(a, f), getattr(other, f)), (D, N, f)
+            for f in ("centers", "ranges", "weights", "left_child", "right_child", "lowest_leaf", "highest_leaf", "permutation"):
+                assert np.array_equal(getattr(a.bt, f), getattr(other.bt, f)), (D, N, f)
+    with pytest.raises(kdehip.KdeHipError):   # N >= 2 (the mirror routes a single point to the sequential form instead)
+        import ctypes as C
+        from kdehip import _lib
+        one = np.zeros(1)
+        z = np.zeros(4)
+        zi = np.zeros(4, dtype=np.int64)
+        P, Q = _lib.f64p, _lib.i64p
+        _lib.check(_lib.lib.kdehip_make_density_auto(1, 1, _lib.ptr(one, P), _lib.ptr(z, P), None, 0, _lib.ptr(z, P), _lib.ptr(z, P),
+                                                     _lib.ptr(z, P), _lib.ptr(zi, Q), _lib.ptr(zi, Q), _lib.ptr(zi, Q), _lib.ptr(zi, Q),
+                                                     _lib.ptr(zi, Q), _lib.ptr(z, P), _lib.ptr(z, P), _lib.ptr(z, P), _lib.ptr(z, P)))
