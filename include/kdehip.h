@@ -227,6 +227,11 @@ int kdehip_prod_philox_device(int Ndens, kdehip_device_density *const *trees, in
  * nor the upload of the tiles per product (sample offset 0). */
 int kdehip_prod_philox_resident(int Ndens, kdehip_device_density *const *trees, int64_t Np, int Niter, uint64_t seed,
                                 int addEntropy, const uint8_t *partialDimMask, int precision, double *pts, int64_t *ind);
+/* Diagnostic: while enabled, every kdehip_prod_philox_device call brackets its sampling launch with a pair of timing
+ * events on the caller's stream; kdehip_profile_sampler_read waits for the device's calls in flight and returns the sum
+ * of those durations and their count since the switch was last set (which also resets them). */
+void kdehip_profile_sampler(int enable);
+int kdehip_profile_sampler_read(int device, double *total_ms, int64_t *launches);
 
 /* ---- (3) host twin of the device RNG ----------------------------------------------------------
  * Fills the arrays a caller would pass as randU / randN so that a streams-run (or the Julia

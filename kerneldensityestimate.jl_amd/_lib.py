@@ -95,6 +95,8 @@ SIGNATURES = {
     "kdehip_make_densities_device": (C.c_int, [C.c_int, C.c_int64, i64p] + [C.POINTER(C.c_void_p)] * 2 + [C.c_int64] +
                                      [C.POINTER(C.c_void_p)] * 13 + [C.c_int]),
     "kdehip_density_set_bandwidth": (C.c_int, [C.c_int64, C.c_int64, f64p, C.c_int64, f64p, i64p, i64p, f64p, f64p, f64p, f64p]),
+    "kdehip_profile_sampler": (None, [C.c_int]),
+    "kdehip_profile_sampler_read": (C.c_int, [C.c_int, f64p, i64p]),
     "kdehip_make_density_auto": (C.c_int, [C.c_int64, C.c_int64, f64p, f64p, i32p, C.c_int, f64p, f64p, f64p, i64p, i64p, i64p,
                                            i64p, i64p, f64p, f64p, f64p, f64p]),
     "kdehip_make_density": (C.c_int, [C.c_int64, C.c_int64, f64p, f64p, C.c_int64, f64p, f64p, f64p, f64p,
