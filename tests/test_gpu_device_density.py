@@ -135,3 +135,32 @@ def test_back_to_back_products_prepared_under_each_other():
         for d in pr[4]:
             d.close()
     kdehip._clib.kdehip_clear_cache()
+
+
+def test_sampler_profile_counts_the_launches_it_brackets():
+    """kdehip_profile_sampler: while enabled, every asynchronous device product has its sampling launch bracketed by timing
+    events on the caller's stream (what bench.py reports as the kernel's duration in its loop)."""
+    import ctypes as C
+    import torch
+    dev = torch.device("cuda", 0)
+    D, Ns, Np = 3, [400, 300], 512
+    trees = _trees(77, D, Ns)
+    dd = [kdehip.DeviceDensity(t) for t in trees]
+    P = torch.zeros(D * Np, dtype=torch.float64, device=dev)
+    I = torch.zeros(len(Ns) * Np, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    lib = kdehip._clib
+    ms, n = C.c_double(-1.0), C.c_int64(-1)
+    lib.kdehip_profile_sampler(1)
+    for c in range(3):
+        kdehip.prodAppxMSGibbsS_device(dd, P, I, Np=Np, Niter=2, seed=c)
+    assert lib.kdehip_profile_sampler_read(0, C.byref(ms), C.byref(n)) == 0
+    assert n.value == 3 and 0.0 < ms.value < 100.0
+    lib.kdehip_profile_sampler(0)   # (off, and the statistics start over)
+    kdehip.prodAppxMSGibbsS_device(dd, P, I, Np=Np, Niter=2, seed=9)
+    assert lib.kdehip_profile_sampler_read(0, C.byref(ms), C.byref(n)) == 0
+    assert n.value == 0 and ms.value == 0.0
+    ref_p, ref_i = kdehip.prodAppxMSGibbsS(None, trees, None, None, Niter=2, Np=Np, seed=9)
+    assert np.array_equal(P.cpu().numpy().reshape(Np, D).T, ref_p)
+    for d in dd:
+        d.close()
