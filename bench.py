@@ -82,14 +82,16 @@ def usable_cores():
 def load_traffic(workload):
     """The committed PMC profile of this workload (profiles/traffic_latest.json): HBM bytes per launch and the
     issue-slot counters, or an empty dict."""
-    p = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    try:
-        with open(p) as f:
-            t = json.load(f)
-        if t.get("workload") == workload:
-            return t
-    except (OSError, ValueError):
-        pass
+    for name in (f"traffic_{workload}.json", "traffic_latest.json"):
+        p = os.path.join(ROOT, "profiles", name)
+        try:
+            with open(p) as f:
+                t = json.load(f)
+            if t.get("workload") == workload:
+                t["_file"] = "profiles/" + name
+                return t
+        except (OSError, ValueError):
+            pass
     return {}
 
 
@@ -108,9 +110,15 @@ def main():
                     help="ONE process driving G GPUs through the C ABI's multi-device plans (kdehip_product_multi_*: the route a "
                          "Julia host takes; all-gather fused into the kernel epilogue as peer stores) instead of one process "
                          "per GPU + RCCL.  With KDEHIP_ALIAS_DEVICES=1 the G logical devices wrap around the visible ones.")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="B independent products of the configuration's shape per step in ONE library call "
+                         "(kdehip_prod_philox_batch: the serving pattern of many small products), with the same B products "
+                         "enqueued one by one beside it")
     args = ap.parse_args()
     if args.inproc_gpus > 0:
         return inproc_multi(args)
+    if args.batch > 0:
+        return batch_mode(args)
 
     import torch
     import torch.distributed as dist
@@ -213,7 +221,7 @@ def main():
         one_call(args.warmup + args.steps + i)
     drain()
     _ms, _n = _C.c_double(0.0), _C.c_int64(0)
-    kdehip._clib.kdehip_profile_sampler_read(dev_index, _C.byref(_ms), _C.byref(_n))
+    kdehip._clib.kdehip_profile_sampler_read(dev_index, _C.c_void_p(stream.cuda_stream), _C.byref(_ms), _C.byref(_n))
     kdehip._clib.kdehip_profile_sampler(0)
     kern_region_ms = _ms.value / _n.value if _n.value > 0 else None
     if use_dist:
@@ -299,6 +307,10 @@ def main():
                          # wavefronts issued per chain against the 4-cycle issue slots of their lifetime
                          "issue": prof.get("issue"),
                          "valu_floor": valu_floor,
+                         # traffic / issue / valu_floor above are REPLAYED from a committed rocprofv3 --pmc profile of this
+                         # workload (counters cannot be collected inside a timed run); kernel_ms and frac are live
+                         "profile_replayed_from": ({"file": prof.get("_file"), "tag": prof.get("tag"), "commit": prof.get("commit"),
+                                                    "date": prof.get("date")} if prof else None),
                          "note": "working set is LDS/L2 resident (HBM traffic ~0.1 % of peak): bound by vector issue + per-step latency"},
             # SURVEY.md 8(d)'s figure, kept for continuity: algorithmic bytes / kernel time against 8 TB/s.  NOT a roofline
             # (the bytes never come from HBM; the ratio exceeds 1).
@@ -377,6 +389,92 @@ def inproc_multi(args):
         "all_devices_hold_the_same_result": bool(same),
     }
     mp.close()
+    print(json.dumps(out), flush=True)
+
+
+def batch_mode(args):
+    """bench.py --config c2 --batch 64: a step = B independent products of the configuration's shape (different densities,
+    different seeds) in ONE kdehip_prod_philox_batch call from HBM-resident densities; `back_to_back` = the same B products
+    as B kdehip_prod_philox_device calls on one stream.  roofline = algorithmic flops of all B products over the duration of
+    the call's device work (HIP events on the stream around the call: descriptor upload + tile gather + the sampling launch)."""
+    import torch
+    import kdehip
+    D, M, N, Nout, Niter, prec, cid = CONFIGS[args.config]
+    if args.nout > 0:
+        Nout = args.nout
+    B = args.batch
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    stream = torch.cuda.current_stream(dev)
+    dds, outs = [], []
+    for b in range(B):
+        pts_all, bw_all = synth_inputs(kdehip, D, M, N, 1000 * cid + b)
+        trees = [kdehip.kde(p, w) for p, w in zip(pts_all, bw_all)]
+        dds.append([kdehip.DeviceDensity(t) for t in trees])
+        outs.append((torch.zeros(D * Nout, dtype=torch.float64, device=dev), torch.zeros(M * Nout, dtype=torch.int64, device=dev)))
+        if b == 0:
+            plan = kdehip.ProductPlan(trees, precision=prec)
+            E, Bytes = plan.evals_per_sample(Niter), plan.bytes_per_eval
+            kname = plan.kernel_name(Nout)
+            plan.close()
+    seed = 20260101
+
+    pb = kdehip.ProductBatch([dict(trees=dds[b], d_points=outs[b][0], d_indices=outs[b][1], Np=Nout, Niter=Niter, seed=seed + b)
+                              for b in range(B)], precision=prec)   # (the argument block is marshalled once)
+
+    def batched(i):
+        pb.enqueue(stream=stream.cuda_stream, sample_offset=i * Nout)
+
+    def one_by_one(i):
+        for b in range(B):
+            kdehip.prodAppxMSGibbsS_device(dds[b], outs[b][0], outs[b][1], Np=Nout, Niter=Niter, seed=seed + b,
+                                           sample_offset=i * Nout, precision=prec, stream=stream.cuda_stream)
+
+    def timed(f, steps, warmup):
+        for i in range(warmup):
+            f(i)
+        torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        t0 = time.perf_counter()
+        for i in range(steps):
+            ev[i][0].record(stream)
+            f(warmup + i)
+            ev[i][1].record(stream)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps * 1e3, float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    # parity of the batched call with the single calls, product by product (bit for bit)
+    batched(0)
+    torch.cuda.synchronize()
+    got = [(p.clone(), q.clone()) for p, q in outs]
+    one_by_one(0)
+    torch.cuda.synchronize()
+    identical = all(torch.equal(g[0], o[0]) and torch.equal(g[1], o[1]) for g, o in zip(got, outs))
+    ms_b, dev_b = timed(batched, args.steps, args.warmup)
+    ms_s, dev_s = timed(one_by_one, max(3, args.steps // 4), max(1, args.warmup // 2))
+    flops = float(B) * Nout * E * (6 * D + 4)
+    peak_tf = VALU_PEAK_TFLOPS[prec]
+    ach = flops / (dev_b * 1e-3) / 1e12
+    out = {
+        "metric": "gibbs_product_samples_per_sec", "value": B * Nout / (ms_b * 1e-3), "unit": "samples/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_b, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64" if prec == 64 else "f32", "data": "synthetic",
+        "value_is": f"{B} independent prodAppxMSGibbsS-equivalent calls per step in ONE kdehip_prod_philox_batch call, densities "
+                    "resident in HBM, outputs left in HBM",
+        "config": {"workload": f"{args.config} x {B}: {B} products of {D}-D, {M} densities x {N} pts, Nout={Nout} each, Niter={Niter}, fp{prec}",
+                   "batch": B, "evals_per_sample": E, "bytes_per_eval": Bytes},
+        "roofline": {"bound": "valu", "achieved": ach, "peak": peak_tf, "unit": "TFLOP/s", "frac": ach / peak_tf, "traffic": None,
+                     "kernel": kname + " (BATCH instantiation, 16 chains per workgroup)", "kernel_ms": dev_b,
+                     "kernel_ms_is": "HIP events on the stream around the whole batched call: descriptor upload + tile gather + "
+                                     "ONE sampling launch",
+                     "algorithmic_flops_per_launch": flops},
+        "back_to_back": {"ms_per_step": ms_s, "device_ms": dev_s, "samples_per_sec": B * Nout / (ms_s * 1e-3),
+                         "what": f"the same {B} products as {B} kdehip_prod_philox_device calls on one stream",
+                         "batched_speedup": ms_s / ms_b},
+        "batched_equals_single_calls_bit_for_bit": bool(identical),
+    }
+    for dd in dds:
+        for d in dd:
+            d.close()
     print(json.dumps(out), flush=True)
 
 

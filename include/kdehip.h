@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define KDEHIP_VERSION 300 /* 0.3.0 */
+#define KDEHIP_VERSION 400 /* 0.4.0 */
 
 enum {
   KDEHIP_OK = 0,
@@ -217,7 +217,8 @@ int kdehip_density_ndim(const kdehip_device_density *d);
  * capture on `stream`; graphs are made of the runs of a resident plan, kdehip_product_sample_*.)  d_points (double[ndims*Np]), d_indices (int64[Ndens*Np]) and the optional
  * d_labels (as kdehip_product_sample_philox) are device pointers on the densities' device.  Random numbers: the
  * device Philox stream keyed by (seed, sample_offset + s, draw).  The plan built for the call is released by a later
- * call (or kdehip_clear_cache) once its work has run; at most 8 such calls are in flight per device. */
+ * call (or kdehip_clear_cache) once its work has run; at most 8 such calls are in flight per device and stream (a
+ * caller beyond that waits for the oldest call of ITS OWN stream, never for another stream's work).  Devices 0..63. */
 int kdehip_prod_philox_device(int Ndens, kdehip_device_density *const *trees, int64_t Np, int Niter, uint64_t seed,
                               int64_t sample_offset, int addEntropy, const uint8_t *partialDimMask, int precision,
                               double *d_points, int64_t *d_indices, int32_t *d_labels, void *stream);
@@ -227,11 +228,66 @@ int kdehip_prod_philox_device(int Ndens, kdehip_device_density *const *trees, in
  * nor the upload of the tiles per product (sample offset 0). */
 int kdehip_prod_philox_resident(int Ndens, kdehip_device_density *const *trees, int64_t Np, int Niter, uint64_t seed,
                                 int addEntropy, const uint8_t *partialDimMask, int precision, double *pts, int64_t *ind);
-/* Diagnostic: while enabled, every kdehip_prod_philox_device call brackets its sampling launch with a pair of timing
- * events on the caller's stream; kdehip_profile_sampler_read waits for the device's calls in flight and returns the sum
- * of those durations and their count since the switch was last set (which also resets them). */
+
+/* ---- (2d) the resident chain: products feed products without leaving HBM -----------------------------------
+ * The reference's `*` is `pGM, = prodAppxMSGibbsS(...); kde!(pGM)` (src/MSGibbs01.jl:707-726), and in a belief-propagation
+ * sweep its result is an input of the next products.  kdehip_prod_philox_device leaves pGM in HBM; these entries turn it
+ * into the next product's input there.
+ *
+ * kdehip_density_from_device_points = `kde!(points)` (src/KDE01.jl:3-27) on a D x N column-major matrix that lives on
+ * `device` (d_points; `stream` = the hipStream_t that produced it, waited for): the LOOCV bandwidth search reads the device
+ * matrix as it is, the ball tree (src/BallTree01.jl:415-434) is built by the library's pooled host builder from ONE 8*D*N
+ * byte copy that comes down while the search runs, and the density's block goes straight back up.  Blocking; the result
+ * is bit for bit the density kdehip_make_density_auto builds from the same points.  bw_out (D standard deviations) and
+ * nevals are optional.  N >= 2. */
+int kdehip_density_from_device_points(kdehip_device_density **out, const double *d_points, int64_t D, int64_t N,
+                                      int device, void *stream, double *bw_out, int32_t *nevals);
+/* `*(trees; addEntropy)` (src/MSGibbs01.jl:707-726) on handles: Np = round(mean Npts), Niter = 5, device Philox keyed by
+ * `seed`, then kde!(pGM) -- the product matrix never leaves the device; one density with addEntropy = 0 is the reference's
+ * shortcut (:713-716: kde! of its own points).  Blocking, on the calling thread's stream.  Same numbers as
+ * kdehip_prod_philox(seed) followed by kdehip_make_density_auto on the host. */
+int kdehip_mul_device(kdehip_device_density **out, int Ndens, kdehip_device_density *const *trees, uint64_t seed,
+                      int addEntropy, double *bw_out, int32_t *nevals);
+/* The reference's arrays of a density the library built (the two entries above), shaped as in kdehip_make_density; any
+ * pointer may be NULL; bw_out: its D LOOCV bandwidths (standard deviations).  A density that came from
+ * kdehip_density_upload has no such mirror (KDEHIP_ERR_UNSUPPORTED): its arrays are the caller's. */
+int kdehip_density_download(const kdehip_device_density *d, double *centers, double *ranges, double *weights,
+                            int64_t *left_child, int64_t *right_child, int64_t *lowest_leaf, int64_t *highest_leaf,
+                            int64_t *permutation, double *means, double *bandwidth, double *bandwidthMin,
+                            double *bandwidthMax, double *bw_out);
+
+/* ---- (2e) many products in one call ----------------------------------------------------------------------------
+ * The serving pattern of a belief-propagation host: dozens of independent 100-300-chain products per sweep, each of which
+ * fills a fraction of the device and is latency bound.  One call lays all of them out in one device block (one descriptor
+ * upload, one gather launch for every tile) and samples each (dimension count, density count) group of fp64 products of
+ * 2..4 densities with every dimension active in ONE launch -- workgroups indexed by (product, chain block), each fetching
+ * its product's plan through the scalar cache.  Every product's result is bit for bit that of kdehip_prod_philox_device
+ * with the same arguments.  Products outside that domain (fp32, masks, 1 or more than 4 densities) are enqueued one by one
+ * inside the same call.  Enqueue only, everything on `stream`; all densities on one device. */
+typedef struct kdehip_batch_item {
+  int32_t Ndens;
+  int32_t Niter;
+  kdehip_device_density *const *trees;  /* Ndens handles */
+  int64_t Np;
+  uint64_t seed;
+  int64_t sample_offset;
+  int32_t addEntropy;
+  int32_t reserved_;
+  const uint8_t *partialDimMask;        /* Ndens*ndims bytes or NULL */
+  double *d_points;                     /* device, double[ndims*Np]  */
+  int64_t *d_indices;                   /* device, int64[Ndens*Np]   */
+  int32_t *d_labels;                    /* device, optional          */
+} kdehip_batch_item;
+int kdehip_prod_philox_batch(int nprod, const kdehip_batch_item *items, int precision, void *stream);
+
+/* ---- diagnostics (not part of the drop-in surface; bench.py and the tests use them) -----------------------------
+ * While enabled, every kdehip_prod_philox_device call brackets its sampling launch with a pair of timing events on the
+ * caller's stream; kdehip_profile_sampler_read waits for the device's calls in flight and returns the sum of those
+ * durations and their count for the calls that were enqueued on `stream` since the switch was last set (which also resets
+ * the sums).  The switch is process-wide; the sums are kept per device and caller stream, so concurrent callers on
+ * streams of their own do not mix. */
 void kdehip_profile_sampler(int enable);
-int kdehip_profile_sampler_read(int device, double *total_ms, int64_t *launches);
+int kdehip_profile_sampler_read(int device, void *stream, double *total_ms, int64_t *launches);
 
 /* ---- (3) host twin of the device RNG ----------------------------------------------------------
  * Fills the arrays a caller would pass as randU / randN so that a streams-run (or the Julia

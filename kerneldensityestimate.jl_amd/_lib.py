@@ -30,6 +30,15 @@ class CDensity(C.Structure):
     ]
 
 
+class CBatchItem(C.Structure):
+    """struct kdehip_batch_item"""
+    _fields_ = [
+        ("Ndens", C.c_int32), ("Niter", C.c_int32), ("trees", C.POINTER(C.c_void_p)), ("Np", C.c_int64),
+        ("seed", C.c_uint64), ("sample_offset", C.c_int64), ("addEntropy", C.c_int32), ("reserved_", C.c_int32),
+        ("partialDimMask", u8p), ("d_points", C.c_void_p), ("d_indices", C.c_void_p), ("d_labels", C.c_void_p),
+    ]
+
+
 class CProductInfo(C.Structure):
     """struct kdehip_product_info_t"""
     _fields_ = [
@@ -96,7 +105,13 @@ SIGNATURES = {
                                      [C.POINTER(C.c_void_p)] * 13 + [C.c_int]),
     "kdehip_density_set_bandwidth": (C.c_int, [C.c_int64, C.c_int64, f64p, C.c_int64, f64p, i64p, i64p, f64p, f64p, f64p, f64p]),
     "kdehip_profile_sampler": (None, [C.c_int]),
-    "kdehip_profile_sampler_read": (C.c_int, [C.c_int, f64p, i64p]),
+    "kdehip_profile_sampler_read": (C.c_int, [C.c_int, C.c_void_p, f64p, i64p]),
+    "kdehip_density_from_device_points": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_int64, C.c_int64, C.c_int,
+                                                    C.c_void_p, f64p, i32p]),
+    "kdehip_mul_device": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p), C.c_uint64, C.c_int, f64p, i32p]),
+    "kdehip_density_download": (C.c_int, [C.c_void_p, f64p, f64p, f64p, i64p, i64p, i64p, i64p, i64p, f64p, f64p, f64p,
+                                          f64p, f64p]),
+    "kdehip_prod_philox_batch": (C.c_int, [C.c_int, C.POINTER(CBatchItem), C.c_int, C.c_void_p]),
     "kdehip_make_density_auto": (C.c_int, [C.c_int64, C.c_int64, f64p, f64p, i32p, C.c_int, f64p, f64p, f64p, i64p, i64p, i64p,
                                            i64p, i64p, f64p, f64p, f64p, f64p]),
     "kdehip_make_density": (C.c_int, [C.c_int64, C.c_int64, f64p, f64p, C.c_int64, f64p, f64p, f64p, f64p,

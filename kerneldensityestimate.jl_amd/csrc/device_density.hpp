@@ -32,28 +32,19 @@ int pack_layout_shapes(int M, int D, int L, const TileShape *shapes, const uint8
 // whether D variances in [lo, 2*hi] keep the product/rsqrt arithmetic inside the range of the precision
 bool variances_in_range(const double *bw_lo, const double *bw_hi, int D, int precision);
 
-// One tile of the plan image as the gather kernel of pack_device.hip sees it (what pack_layout_shapes decided).
+// One tile of a plan image as the gather kernel of pack_device.hip sees it (what pack_layout_shapes decided): where its
+// frontier's nodes come from (the density's arrays in HBM) and where header, rows and permutation row go.  Absolute
+// pointers: one launch fills the tiles of any number of products (kdehip_prod_philox_batch).
 struct FillJob {
-  int64_t hdr_off;    // element offset of the tile header in the plan's data
-  int64_t perm_off;   // offset of its permutation row
-  int64_t front_off;  // offset of the frontier's node ids in the density's `front` array
-  int32_t n, B, F, uniform;
-  int32_t dens;       // which density
-  int32_t pad_;
+  const double *means, *bandwidth, *weights;
+  const int64_t *perm;
+  const int32_t *front;  // the frontier's node ids (1-based)
+  void *hdr;             // T*: the tile header
+  int32_t *perm_out;     // the tile's permutation row
+  int32_t n, B, F, uniform, D, pad_;
 };
-static_assert(sizeof(FillJob) == 48, "FillJob layout");
-struct FillArgs {
-  const double *means[KDEHIP_MAX_DENS];
-  const double *bandwidth[KDEHIP_MAX_DENS];
-  const double *weights[KDEHIP_MAX_DENS];
-  const int64_t *perm[KDEHIP_MAX_DENS];
-  const int32_t *front[KDEHIP_MAX_DENS];
-  const FillJob *jobs;
-  void *data;  // T[...]
-  int32_t *perm_out;
-  int32_t D;
-};
-int launch_fill_tiles(int precision, const FillArgs &a, int ntiles, int maxB, void *stream);
+static_assert(sizeof(FillJob) == 80, "FillJob layout");
+int launch_fill_tiles(int precision, const FillJob *d_jobs, int ntiles, int maxB, void *stream);
 
 }  // namespace kdehip
 
@@ -69,4 +60,19 @@ struct kdehip_device_density {
   const double *means = nullptr, *bandwidth = nullptr, *weights = nullptr;
   const int64_t *perm = nullptr;
   const int32_t *front = nullptr;
+  // A density the library built itself (kdehip_density_from_device_points) keeps the reference's twelve arrays as a
+  // host mirror for kdehip_density_download: hf = centers, ranges, means, bandwidth (2ND each), bandwidthMin,
+  // bandwidthMax (ND each), weights (2N); hi = left, right, lowest, highest, permutation (2N each)
+  bool built = false;
+  std::vector<double> hf;
+  std::vector<int64_t> hi;
+  double bw[KDEHIP_MAX_DIMS] = {};  // its LOOCV bandwidth (standard deviations)
 };
+
+namespace kdehip {
+// kdehip_prod_philox_device with everything -- preparation and sampling -- on ONE stream (product.hip): what a blocking
+// caller that waits for the product anyway uses (kdehip_mul_device).
+int prod_philox_device_blocking_stream(int Ndens, kdehip_device_density *const *trees, int64_t Np, int Niter, uint64_t seed,
+                                       int64_t sample_offset, int addEntropy, const uint8_t *partialDimMask, int precision,
+                                       double *d_points, int64_t *d_indices, void *stream);
+}  // namespace kdehip

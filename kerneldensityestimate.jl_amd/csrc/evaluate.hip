@@ -215,11 +215,12 @@ extern "C" int kdehip_evaluate(const kdehip_density *bd, const double *pos, int6
   DeviceGuard guard;
   int rc = guard.enter(device);
   if (rc != KDEHIP_OK) return rc;
+  hipStream_t st = hipStreamPerThread;  // the calling thread's own stream, like every blocking entry point (kdehip.h)
 
   const GroupSplit gs = split_chunks(N, Nq, 1);
   const int nchunks = gs.ngroups;  // partial sums per query
   // ONE pinned image [points | weights | queries or output positions] goes up in one DMA, the results come back in
-  // one; everything is enqueued on the null stream and the host waits once (pageable hipMemcpy calls, one per
+  // one; everything is enqueued on the calling thread's stream and the host waits once (pageable hipMemcpy calls, one per
   // array, cost more than the kernel for anything below ~10^8 kernel evaluations).
   const size_t o_src = 0;
   const size_t o_w = o_src + sizeof(double) * N * D;
@@ -247,7 +248,7 @@ extern "C" int kdehip_evaluate(const kdehip_density *bd, const double *pos, int6
   KDEHIP_CHECK(d_part.alloc(sizeof(double) * nchunks * Nq));
   KDEHIP_CHECK(d_out.alloc(sizeof(double) * Nq));
   unsigned char *du = d_up.as<unsigned char>();
-  KDEHIP_CHECK(hipMemcpyAsync(du, h, up_bytes, hipMemcpyHostToDevice, nullptr));
+  KDEHIP_CHECK(hipMemcpyAsync(du, h, up_bytes, hipMemcpyHostToDevice, st));
   const double *d_src = reinterpret_cast<const double *>(du + o_src);
   const double *d_w = reinterpret_cast<const double *>(du + o_w);
   EvalBatch eb{};
@@ -261,13 +262,13 @@ extern "C" int kdehip_evaluate(const kdehip_density *bd, const double *pos, int6
   fp.partial = d_part.as<double>(); fp.w = d_w;
   fp.out_idx = leave_one_out ? reinterpret_cast<const int64_t *>(du + o_q) : nullptr;
   fp.out = d_out.as<double>(); fp.inv_norm = 1.0 / gauss_norm(bw, D); fp.Nq = Nq; fp.nchunks = nchunks;
-  rc = launch_partial_dims(D, eb, 1, Nq, gs.ngroups, leave_one_out ? 1 : 0, nullptr);
-  if (rc != KDEHIP_OK) { (void)hipDeviceSynchronize(); return rc; }
-  hipLaunchKernelGGL(eval_finish_kernel, dim3(static_cast<unsigned>((Nq + 255) / 256), 1), dim3(256), 0, nullptr,
+  rc = launch_partial_dims(D, eb, 1, Nq, gs.ngroups, leave_one_out ? 1 : 0, st);
+  if (rc != KDEHIP_OK) { (void)hipStreamSynchronize(st); return rc; }
+  hipLaunchKernelGGL(eval_finish_kernel, dim3(static_cast<unsigned>((Nq + 255) / 256), 1), dim3(256), 0, st,
                      fb, leave_one_out ? 1 : 0);
   hipError_t le = hipGetLastError();
-  if (le == hipSuccess) le = hipMemcpyAsync(h + o_out, d_out.p, sizeof(double) * Nq, hipMemcpyDeviceToHost, nullptr);
-  const hipError_t se = hipStreamSynchronize(nullptr);  // (also before the scratch goes back to the cache on an error)
+  if (le == hipSuccess) le = hipMemcpyAsync(h + o_out, d_out.p, sizeof(double) * Nq, hipMemcpyDeviceToHost, st);
+  const hipError_t se = hipStreamSynchronize(st);  // (also before the scratch goes back to the cache on an error)
   KDEHIP_CHECK(le);
   KDEHIP_CHECK(se);
   std::memcpy(p_out, h + o_out, sizeof(double) * Nq);
@@ -730,15 +731,14 @@ __global__ void loo_finalize_kernel(const LooRound r) {
 
 }  // namespace
 
-extern "C" int kdehip_auto_bandwidth(int64_t D64, int64_t N, const double *points, double *bw_out,
-                                     int32_t *nevals_out, int device) {
-  if (!points || !bw_out) return set_error(KDEHIP_ERR_ARG, "null argument");
-  if (D64 < 1 || D64 > KDEHIP_MAX_DIMS) return set_error(KDEHIP_ERR_UNSUPPORTED, "ndims outside 1..KDEHIP_MAX_DIMS");
-  if (N < 2) return set_error(KDEHIP_ERR_ARG, "kde!(points) needs at least two points");
-  const int D = static_cast<int>(D64);
-  DeviceGuard guard;
-  int rc = guard.enter(device);
-  if (rc != KDEHIP_OK) return rc;
+// The search itself, on stream `st` of the current device (the caller holds the DeviceGuard).  `points` are the host's
+// copy of the D x N matrix, `d_points` (optional) the same matrix already in HBM -- the product a resident chain has just
+// sampled (kdehip_density_from_device_points): the marginals are then prepared straight from it, nothing is uploaded.
+// Marginals beyond kPrepMaxN points are prepared on the host and need `points`.
+int kdehip::auto_bandwidth_run(int D, int64_t N, const double *points, const double *d_points, void *stream,
+                               double *bw_out, int32_t *nevals_out) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (!points && !(d_points && N <= kPrepMaxN)) return set_error(KDEHIP_ERR_ARG, "auto_bandwidth_run: no host copy of the points");
   const bool timing = std::getenv("KDEHIP_TIMING") != nullptr;
   auto tnow = [] { return std::chrono::steady_clock::now(); };
   auto t_begin = tnow();
@@ -795,17 +795,20 @@ extern "C" int kdehip_auto_bandwidth(int64_t D64, int64_t N, const double *point
   // been enqueued before the device block and the pinned block go back to the caches (where another thread may be
   // handed them at once).  On the regular path the stream is already idle.
   struct DrainOnExit {
-    ~DrainOnExit() { (void)hipStreamSynchronize(nullptr); }
-  } drain_on_exit;
+    hipStream_t st;
+    ~DrainOnExit() { (void)hipStreamSynchronize(st); }
+  } drain_on_exit{st};
 
   if (N <= kPrepMaxN) {
-    std::memcpy(pin.p, points, sizeof(double) * N * D);
-    KDEHIP_CHECK(hipMemcpyAsync(d_pts, pin.p, sizeof(double) * N * D, hipMemcpyHostToDevice, nullptr));
+    if (!d_points) {
+      std::memcpy(pin.p, points, sizeof(double) * N * D);
+      KDEHIP_CHECK(hipMemcpyAsync(d_pts, pin.p, sizeof(double) * N * D, hipMemcpyHostToDevice, st));
+    }
     int64_t P = 1;
     while (P < N) P <<= 1;
     KDEHIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(loocv_prep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      static_cast<int>(sizeof(double) * 5 * P)));  // up to 80 KiB; per call = per device
-    hipLaunchKernelGGL(loocv_prep_kernel, dim3(D), dim3(kPrepThreads), sizeof(double) * 5 * P, nullptr, d_pts, N, D,
+    hipLaunchKernelGGL(loocv_prep_kernel, dim3(D), dim3(kPrepThreads), sizeof(double) * 5 * P, st, d_points ? d_points : d_pts, N, D,
                        const_cast<double *>(r.x), r.state, r.arrivals, ntiles);
     KDEHIP_CHECK(hipGetLastError());
   } else {
@@ -824,9 +827,10 @@ extern "C" int kdehip_auto_bandwidth(int64_t D64, int64_t N, const double *point
     for (int d = 1; d < D; ++d) th.emplace_back(prep, d);
     prep(0);
     for (auto &t2 : th) t2.join();
-    KDEHIP_CHECK(hipMemcpy(const_cast<double *>(r.x), xo.data(), sizeof(double) * D * N, hipMemcpyHostToDevice));
-    KDEHIP_CHECK(hipMemcpy(r.state, g.data(), sizeof(Golden) * D, hipMemcpyHostToDevice));
-    if (pairs) KDEHIP_CHECK(hipMemset(r.arrivals, 0, sizeof(unsigned) * 2 * D * ntiles * kCounterStride));
+    KDEHIP_CHECK(hipMemcpyAsync(const_cast<double *>(r.x), xo.data(), sizeof(double) * D * N, hipMemcpyHostToDevice, st));
+    KDEHIP_CHECK(hipMemcpyAsync(r.state, g.data(), sizeof(Golden) * D, hipMemcpyHostToDevice, st));
+    if (pairs) KDEHIP_CHECK(hipMemsetAsync(r.arrivals, 0, sizeof(unsigned) * 2 * D * ntiles * kCounterStride, st));
+    KDEHIP_CHECK(hipStreamSynchronize(st));  // (xo and g are pageable and leave scope)
   }
   auto t_prep = tnow();
 
@@ -840,20 +844,20 @@ extern "C" int kdehip_auto_bandwidth(int64_t D64, int64_t N, const double *point
   for (int batch = r.joint ? 19 : 20; batches < 16; batch = 8) {  // (20 evaluations: the first launch of `pairs` runs two)
     for (int k = 0; k < batch; ++k) {
       if (pairs) {
-        if (r.joint && r.round == 0) hipLaunchKernelGGL(loo_round_pairs_kernel<1>, gridP2, dim3(kTile * kPairWaves), 0, nullptr, r);
-        else if (r.joint && r.round == 1) hipLaunchKernelGGL(loo_round_pairs_kernel<2>, gridP, dim3(kTile * kPairWaves), 0, nullptr, r);
-        else hipLaunchKernelGGL(loo_round_pairs_kernel<0>, gridP, dim3(kTile * kPairWaves), 0, nullptr, r);
+        if (r.joint && r.round == 0) hipLaunchKernelGGL(loo_round_pairs_kernel<1>, gridP2, dim3(kTile * kPairWaves), 0, st, r);
+        else if (r.joint && r.round == 1) hipLaunchKernelGGL(loo_round_pairs_kernel<2>, gridP, dim3(kTile * kPairWaves), 0, st, r);
+        else hipLaunchKernelGGL(loo_round_pairs_kernel<0>, gridP, dim3(kTile * kPairWaves), 0, st, r);
       } else {
-        hipLaunchKernelGGL(loo_round_partial_kernel, gridA, dim3(kLooThreads), 0, nullptr, r);
-        hipLaunchKernelGGL(loo_round_entropy_kernel<kLooThreads>, gridB, dim3(kLooThreads), 0, nullptr, r);
+        hipLaunchKernelGGL(loo_round_partial_kernel, gridA, dim3(kLooThreads), 0, st, r);
+        hipLaunchKernelGGL(loo_round_entropy_kernel<kLooThreads>, gridB, dim3(kLooThreads), 0, st, r);
       }
       ++r.round;
       ++rounds;
     }
-    hipLaunchKernelGGL(loo_finalize_kernel, dim3(1), dim3(64), 0, nullptr, r);
+    hipLaunchKernelGGL(loo_finalize_kernel, dim3(1), dim3(64), 0, st, r);
     KDEHIP_CHECK(hipGetLastError());
-    KDEHIP_CHECK(hipMemcpyAsync(h_state, r.state + (r.round & 1) * D, sizeof(Golden) * D, hipMemcpyDeviceToHost, nullptr));
-    KDEHIP_CHECK(hipStreamSynchronize(nullptr));
+    KDEHIP_CHECK(hipMemcpyAsync(h_state, r.state + (r.round & 1) * D, sizeof(Golden) * D, hipMemcpyDeviceToHost, st));
+    KDEHIP_CHECK(hipStreamSynchronize(st));
     ++batches;
     bool done = true;
     for (int d = 0; d < D; ++d) done = done && h_state[d].phase == 3;
@@ -873,6 +877,17 @@ extern "C" int kdehip_auto_bandwidth(int64_t D64, int64_t N, const double *point
                  static_cast<long long>(N), us(t_begin, t_prep), rounds, batches, us(t_prep, tnow()));
   }
   return KDEHIP_OK;
+}
+
+extern "C" int kdehip_auto_bandwidth(int64_t D64, int64_t N, const double *points, double *bw_out,
+                                     int32_t *nevals_out, int device) {
+  if (!points || !bw_out) return set_error(KDEHIP_ERR_ARG, "null argument");
+  if (D64 < 1 || D64 > KDEHIP_MAX_DIMS) return set_error(KDEHIP_ERR_UNSUPPORTED, "ndims outside 1..KDEHIP_MAX_DIMS");
+  if (N < 2) return set_error(KDEHIP_ERR_ARG, "kde!(points) needs at least two points");
+  DeviceGuard guard;
+  const int rc = guard.enter(device);
+  if (rc != KDEHIP_OK) return rc;
+  return auto_bandwidth_run(static_cast<int>(D64), N, points, nullptr, hipStreamPerThread, bw_out, nevals_out);
 }
 
 // kde!(points) (src/KDE01.jl:3-27) with the tree built under the bandwidth search: the builder is a task of the host

@@ -74,6 +74,7 @@ LeanGeometry lean_geometry(int64_t Np, int variant, int precision, const PlanDev
   int launch_gibbs_d##d(int, int, const PlanDev &, const RunArgs &, void *);           \
   int launch_lean_d##d(int, int, const PlanDev &, const RunArgs &, void *);             \
   int launch_lean_hi_d##d(int, int, const PlanDev &, const RunArgs &, void *);          \
+  int launch_lean_batch_d##d(int, const PlanDev &, const RunArgs &, void *);            \
   int launch_lean_f32_d##d(int, int, const PlanDev &, const RunArgs &, void *);
 KDEHIP_DECL(1) KDEHIP_DECL(2) KDEHIP_DECL(3) KDEHIP_DECL(4) KDEHIP_DECL(5) KDEHIP_DECL(6) KDEHIP_DECL(7) KDEHIP_DECL(8)
 #undef KDEHIP_DECL
@@ -122,6 +123,23 @@ int launch_gibbs(int precision, int mode, const PlanDev &plan, const RunArgs &ar
     case 6: return launch_gibbs_d6(precision, mode, plan, args, stream);
     case 7: return launch_gibbs_d7(precision, mode, plan, args, stream);
     case 8: return launch_gibbs_d8(precision, mode, plan, args, stream);
+    default: return set_error(KDEHIP_ERR_UNSUPPORTED, "ndims outside 1..KDEHIP_MAX_DIMS");
+  }
+}
+
+// One launch for a group of fp64 products of M (2..4) densities and D dimensions (kdehip_prod_philox_batch): the BATCH
+// instantiations of gibbs_lean.hip, 16 chains per workgroup.  `plan` = any member's (the kernel takes each workgroup's
+// own from args.batch); args.Np = workgroups x 16.
+int launch_gibbs_batch(int D, int M, const PlanDev &plan, const RunArgs &args, void *stream) {
+  switch (D) {
+    case 1: return launch_lean_batch_d1(M, plan, args, stream);
+    case 2: return launch_lean_batch_d2(M, plan, args, stream);
+    case 3: return launch_lean_batch_d3(M, plan, args, stream);
+    case 4: return launch_lean_batch_d4(M, plan, args, stream);
+    case 5: return launch_lean_batch_d5(M, plan, args, stream);
+    case 6: return launch_lean_batch_d6(M, plan, args, stream);
+    case 7: return launch_lean_batch_d7(M, plan, args, stream);
+    case 8: return launch_lean_batch_d8(M, plan, args, stream);
     default: return set_error(KDEHIP_ERR_UNSUPPORTED, "ndims outside 1..KDEHIP_MAX_DIMS");
   }
 }

@@ -85,8 +85,68 @@ struct LeanTile {
 // TEAMS: the instantiation whose wavefronts can form teams (RunArgs.team = 2 or 4; 16-wavefront fp64 builds).  A kernel
 // of its own: with the team paths compiled in, a 16-wavefront build is up to 25 % slower even when every chain has one
 // wavefront (config 4 with 16,384 chains: 31 -> 39 ms), and that is the build large batches run.
-template <typename T, int D, int M, int WAVES, bool TEAMS = false>
-__global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan, RunArgs a) {
+// What a workgroup works on.  A plain launch: the kernel arguments, block = blockIdx.x.  A BATCHED launch
+// (kdehip_prod_philox_batch): workgroup b belongs to product batch_map[b]; its plan and run parameters come from that
+// product's BatchEntry -- three 64-byte scalar loads through the constant address space -- and its chains are numbered
+// from the product's first workgroup.
+template <bool BATCH>
+struct LaunchView {
+  const PlanDev &plan;
+  const RunArgs &a;
+  unsigned block;
+  __device__ __forceinline__ LaunchView(const PlanDev &p, const RunArgs &a_) : plan(p), a(a_), block(blockIdx.x) {}
+};
+// The run parameters of a batched workgroup: RunArgs' member names, scalars only (a copy of RunArgs itself -- with its
+// run-time-indexed peer arrays -- would have to live in scratch memory, and everything read from it would count as
+// divergent); no caller streams, no teams, no peers in a batched launch.
+struct BatchArgs {
+  int64_t Np;
+  int32_t Niter, addEntropy, variant, use_tables;
+  uint64_t seed;
+  int64_t sample_offset;
+  double *points;
+  int64_t *indices;
+  int32_t *labels;
+  static constexpr int32_t rng_philox = 1, team = 1, team_level = 0, team_min_rows = 0, npeers = 0;
+  static constexpr const double *randU = nullptr, *randN = nullptr;
+  static constexpr int64_t K = 0, R = 0, nU = 0, nN = 0;
+  double *peer_points[1];
+  int64_t *peer_indices[1];
+};
+template <>
+struct LaunchView<true> {
+  PlanDev plan;
+  BatchArgs a;
+  unsigned block;
+  __device__ __forceinline__ LaunchView(const PlanDev &, const RunArgs &a_) {
+    const int e = ((const __attribute__((address_space(4))) int *)(a_.batch_map))[blockIdx.x];
+    const auto *src = (const __attribute__((address_space(4))) kdehip_v16i *)(a_.batch + e);
+    const kdehip_v16i r0 = src[0], r1 = src[1], r2 = src[2];  // three s_load_dwordx16
+    BatchPlanHead h;
+    BatchRun be;
+    BatchFlags fl;
+    __builtin_memcpy(&h, &r0, sizeof(h));
+    __builtin_memcpy(&be, &r1, sizeof(be));
+    __builtin_memcpy(&fl, &r2, sizeof(fl));
+    plan.data = h.data; plan.perm = h.perm; plan.levels = h.levels; plan.tables = h.tables; plan.tabdesc = h.tabdesc;
+    plan.tab_rows_total = h.tab_rows_total;
+    plan.M = h.M; plan.L = h.L; plan.D = h.D; plan.Lt = h.Lt;
+    plan.deep_level[0] = be.deep_level[0]; plan.deep_level[1] = be.deep_level[1];
+    plan.deep_share[0] = be.deep_share[0]; plan.deep_share[1] = be.deep_share[1];
+    a.Np = be.Np; a.Niter = fl.Niter; a.addEntropy = fl.addEntropy; a.use_tables = fl.use_tables;
+    a.variant = a_.variant;
+    a.seed = be.seed; a.sample_offset = be.sample_offset;
+    a.points = be.points; a.indices = be.indices; a.labels = be.labels;
+    a.peer_points[0] = nullptr; a.peer_indices[0] = nullptr;
+    block = blockIdx.x - static_cast<unsigned>(fl.first_block);
+  }
+};
+
+template <typename T, int D, int M, int WAVES, bool TEAMS = false, bool BATCH = false>
+__global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, RunArgs a_) {
+  const LaunchView<BATCH> view(plan_, a_);
+  const PlanDev &plan = view.plan;
+  const auto &a = view.a;
   constexpr bool kPrefetchRows = (WAVES <= 12) || sizeof(T) == 4 || D <= 4;  // as in gibbs_kernel.hip
   constexpr bool kKeptRows = (WAVES <= 8);
   // wavefront teams (a chain on 2 or 4 wavefronts, RunArgs.team): the 16-wavefront fp64 builds
@@ -115,7 +175,7 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan, Ru
   const int chains_wg = WAVES >> tshift;
   const int tmember = wave / chains_wg;
   const int chain = wave - tmember * chains_wg;
-  int64_t s = static_cast<int64_t>(blockIdx.x) * (WAVES >> tshift) + chain;
+  int64_t s = static_cast<int64_t>(view.block) * (WAVES >> tshift) + chain;
   const bool in_range = s < a.Np;  // surplus wavefronts of the last workgroup replay the last chain and store nothing
   if (!in_range) s = a.Np - 1;
   const bool live = in_range && tmember == 0;
@@ -578,6 +638,30 @@ static int launch_lean_m_hi(const PlanDev &plan, const RunArgs &args_in, hipStre
     return set_error(KDEHIP_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString(e));
   return KDEHIP_OK;
 }
+
+#if !defined(KDEHIP_LEAN_HI) && !defined(KDEHIP_LEAN_F32) && !defined(KDEHIP_LEAN_DEV)
+// kdehip_prod_philox_batch: one launch for a group of fp64 products of M densities (gibbs_dispatch.cpp launch_gibbs_batch)
+template <int D, int M>
+static void launch_lean_batch_m(const PlanDev &plan, const RunArgs &args, hipStream_t stream) {
+  constexpr int W = 16;
+  hipLaunchKernelGGL((gibbs_lean_kernel<double, D, M, W, false, true>), dim3(static_cast<unsigned>(args.Np / W)), dim3(W * 64), 0,
+                     stream, plan, args);
+}
+int KDEHIP_CAT(launch_lean_batch_d, KDEHIP_DIM)(int M, const PlanDev &plan, const RunArgs &args, void *stream) {
+  constexpr int D = KDEHIP_DIM;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (args.Np <= 0) return KDEHIP_OK;
+  switch (M) {
+    case 2: launch_lean_batch_m<D, 2>(plan, args, st); break;
+    case 3: launch_lean_batch_m<D, 3>(plan, args, st); break;
+    case 4: launch_lean_batch_m<D, 4>(plan, args, st); break;
+    default: return set_error(KDEHIP_ERR_UNSUPPORTED, "batched launch: 2..4 densities");
+  }
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_error(KDEHIP_ERR_HIP, std::string("batched kernel launch failed: ") + hipGetErrorString(e));
+  return KDEHIP_OK;
+}
+#endif
 
 #if defined(KDEHIP_LEAN_HI)
 #define KDEHIP_LEAN_ENTRY launch_lean_hi_d

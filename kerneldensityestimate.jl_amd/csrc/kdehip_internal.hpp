@@ -90,6 +90,7 @@ struct PlanDev {
 };
 
 constexpr int kMaxPeers = 7;  // other GPUs of one node
+struct BatchEntry;
 struct RunArgs {
   int64_t Np;
   int32_t Niter;
@@ -119,7 +120,47 @@ struct RunArgs {
   int32_t npeers;
   double *peer_points[kMaxPeers];
   int64_t *peer_indices[kMaxPeers];
+  // A batched launch (kdehip_prod_philox_batch; the BATCH instantiations of gibbs_lean.hip): workgroup b belongs to
+  // product batch_map[b], whose plan and run parameters are entry batch_map[b] of `batch` (device memory, read through
+  // the scalar cache); everything above except rng_philox / variant is then taken from the entry.
+  const BatchEntry *batch;
+  const int32_t *batch_map;
 };
+
+// One product of a batched launch: what differs from product to product, in three 64-byte pieces (each is read with one
+// scalar load and unpacked on its own, like LevelDesc).
+struct BatchPlanHead {   // = the first 64 bytes of PlanDev
+  const void *data;
+  const int32_t *perm;
+  const LevelDesc *levels;
+  const void *tables;
+  const TabDesc *tabdesc;
+  int64_t tab_rows_total;
+  int32_t M, L, D, Lt;
+};
+struct BatchRun {
+  int32_t deep_level[2];   // (the tail of PlanDev)
+  float deep_share[2];
+  int64_t Np;
+  uint64_t seed;
+  int64_t sample_offset;
+  double *points;
+  int64_t *indices;
+  int32_t *labels;
+};
+struct BatchFlags {
+  int32_t Niter, addEntropy, use_tables;
+  int32_t first_block;   // the product's first workgroup in the launch
+  int32_t pad_[12];
+};
+struct BatchEntry {
+  BatchPlanHead head;
+  BatchRun run;
+  BatchFlags flags;
+};
+static_assert(sizeof(PlanDev) == 80, "PlanDev layout");
+static_assert(sizeof(BatchPlanHead) == 64 && sizeof(BatchRun) == 64 && sizeof(BatchFlags) == 64 && sizeof(BatchEntry) == 192,
+              "BatchEntry is read with three 64-byte scalar loads");
 
 // Host result of packing one product (precision-independent description + fp64 payload; the fp32
 // payload is a rounding of it).
@@ -192,6 +233,13 @@ class DeviceGuard {
 int device_cu_count();
 
 int launch_gibbs(int precision, int mode, const PlanDev &plan, const RunArgs &args, void *stream);
+// a group of fp64 products of M (2..4) densities in one launch (gibbs_dispatch.cpp; RunArgs.batch / batch_map)
+int launch_gibbs_batch(int D, int M, const PlanDev &plan, const RunArgs &args, void *stream);
+
+// kde!(points)'s LOOCV bandwidth search (evaluate.hip) on `stream` of the current device, from the host's copy of the
+// D x N matrix and/or a copy that already lives in HBM (`d_points`: nothing is uploaded then).  Blocking.
+int auto_bandwidth_run(int D, int64_t N, const double *points, const double *d_points, void *stream, double *bw_out,
+                       int32_t *nevals_out);
 
 // Chains per workgroup (= wavefronts per CU, one workgroup per CU at a time) of a sampling launch: 4, 8 or 16,
 // the width with the smallest estimated time rounds(width) * cost(width) unless `variant` pins it

@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "device_density.hpp"
+#include "host_pool.hpp"
 #include "kdehip_internal.hpp"
 
 using namespace kdehip;
@@ -37,16 +38,16 @@ namespace kdehip {
 // One wavefront per (tile, row): lane ln writes entry z = ln*B + row of the frontier (kdehip_internal.hpp "packed
 // per-level layout"), field by field -- 64 contiguous elements per store -- from the density's arrays in HBM.
 template <typename T>
-__global__ __launch_bounds__(64) void fill_tiles_kernel(FillArgs a) {
-  const FillJob job = a.jobs[blockIdx.y];
+__global__ __launch_bounds__(64) void fill_tiles_kernel(const FillJob *__restrict__ jobs) {
+  const FillJob job = jobs[blockIdx.y];
   const int row = blockIdx.x;
   if (row >= job.B) return;
   const int lane = threadIdx.x;
-  const int D = a.D, F = job.F, j = job.dens;
+  const int D = job.D, F = job.F;
   const int64_t RS = static_cast<int64_t>(F) * 64 + 1;
-  T *hdr = static_cast<T *>(a.data) + job.hdr_off;
-  const int32_t *front = a.front[j] + job.front_off;
-  const double *means = a.means[j], *bw = a.bandwidth[j];
+  T *hdr = static_cast<T *>(job.hdr);
+  const int32_t *front = job.front;
+  const double *means = job.means, *bw = job.bandwidth;
   if (row == 0 && lane < kTileHeader) {  // the bandwidth vector of entry 0 (= of every entry of a uniform tile)
     const int64_t n0 = static_cast<int64_t>(front[0]) - 1;
     hdr[lane] = lane < D ? static_cast<T>(bw[n0 * D + lane]) : T(0);
@@ -57,16 +58,19 @@ __global__ __launch_bounds__(64) void fill_tiles_kernel(FillArgs a) {
   for (int d = 0; d < D; ++d) r[d * 64 + lane] = src >= 0 ? static_cast<T>(means[src * D + d]) : T(0);
   if (!job.uniform)
     for (int d = 0; d < D; ++d) r[(D + d) * 64 + lane] = src >= 0 ? static_cast<T>(bw[src * D + d]) : T(1);
-  r[(F - 1) * 64 + lane] = src >= 0 ? static_cast<T>(a.weights[j][src]) : T(0);
+  r[(F - 1) * 64 + lane] = src >= 0 ? static_cast<T>(job.weights[src]) : T(0);
   if (lane == 0) r[F * 64] = T(0);  // the pad element
-  a.perm_out[job.perm_off + static_cast<int64_t>(row) * 64 + lane] = src >= 0 ? static_cast<int32_t>(a.perm[j][src]) : 0;
+  job.perm_out[static_cast<int64_t>(row) * 64 + lane] = src >= 0 ? static_cast<int32_t>(job.perm[src]) : 0;
 }
 
-int launch_fill_tiles(int precision, const FillArgs &a, int ntiles, int maxB, void *stream_) {
+int launch_fill_tiles(int precision, const FillJob *d_jobs, int ntiles, int maxB, void *stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  const dim3 grid(static_cast<unsigned>(maxB), static_cast<unsigned>(ntiles));
-  if (precision == 64) hipLaunchKernelGGL(fill_tiles_kernel<double>, grid, dim3(64), 0, stream, a);
-  else hipLaunchKernelGGL(fill_tiles_kernel<float>, grid, dim3(64), 0, stream, a);
+  for (int t0 = 0; t0 < ntiles; t0 += 65535) {  // (grid.y limit)
+    const int nt = ntiles - t0 < 65535 ? ntiles - t0 : 65535;
+    const dim3 grid(static_cast<unsigned>(maxB), static_cast<unsigned>(nt));
+    if (precision == 64) hipLaunchKernelGGL(fill_tiles_kernel<double>, grid, dim3(64), 0, stream, d_jobs + t0);
+    else hipLaunchKernelGGL(fill_tiles_kernel<float>, grid, dim3(64), 0, stream, d_jobs + t0);
+  }
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_error(KDEHIP_ERR_HIP, std::string("tile fill launch failed: ") + hipGetErrorString(e));
   return KDEHIP_OK;
@@ -76,28 +80,14 @@ int launch_fill_tiles(int precision, const FillArgs &a, int ntiles, int maxB, vo
 
 // ---- densities in HBM ----------------------------------------------------------------------------------------------
 
-extern "C" int kdehip_density_upload(kdehip_device_density **out, const kdehip_density *host, int device) {
-  if (!out) return set_error(KDEHIP_ERR_ARG, "null out pointer");
-  *out = nullptr;
-  if (!host) return set_error(KDEHIP_ERR_ARG, "null density");
-  const int64_t N = host->npts, D = host->ndim;
-  if (N < 1) return set_error(KDEHIP_ERR_ARG, "density with no points");
-  if (N > (int64_t(1) << 30)) return set_error(KDEHIP_ERR_UNSUPPORTED, "density too large");
-  if (D < 1 || D > KDEHIP_MAX_DIMS) return set_error(KDEHIP_ERR_UNSUPPORTED, "ndims outside 1..KDEHIP_MAX_DIMS");
-  if (!host->means || !host->bandwidth || !host->weights || !host->left_child || !host->right_child || !host->permutation)
-    return set_error(KDEHIP_ERR_ARG, "density with a null array");
-  kdehip_device_density *h = new (std::nothrow) kdehip_device_density();
-  if (!h) return set_error(KDEHIP_ERR_ALLOC, "out of host memory");
-  h->device = device;
-  h->N = N;
-  h->D = static_cast<int>(D);
-  h->Lown = nlevels_for(N);
-  // the frontiers of the density's own levels and what the arithmetic-form decision needs (every node is looked at once)
-  int rc = expand_frontiers(*host, h->D, h->Lown, /*look=*/true, h->fr);
-  if (rc != KDEHIP_OK) { delete h; return rc; }
-  DeviceGuard guard;
-  rc = guard.enter(device);
-  if (rc != KDEHIP_OK) { delete h; return rc; }
+namespace {
+
+// Frontiers, the arithmetic-form examination and the one device block of a density whose six arrays `host` describes
+// (h->device, N, D, Lown are set; the device is current).  Everything travels on `st`, which is waited for.
+int upload_common(kdehip_device_density *h, const kdehip_density &host, hipStream_t st) {
+  const int64_t N = h->N, D = h->D;
+  int rc = expand_frontiers(host, h->D, h->Lown, /*look=*/true, h->fr);
+  if (rc != KDEHIP_OK) return rc;
   auto al = [](size_t x) { return (x + 255) & ~static_cast<size_t>(255); };
   const size_t nd = sizeof(double) * 2 * N * D, n2 = sizeof(double) * 2 * N;
   const size_t o_mean = 0, o_bw = al(o_mean + nd), o_w = al(o_bw + nd), o_perm = al(o_w + n2);
@@ -108,23 +98,23 @@ extern "C" int kdehip_density_upload(kdehip_device_density **out, const kdehip_d
   if (e == hipSuccess) e = cached_malloc(&h->d_blob, total);
   if (e != hipSuccess) {
     if (pin) cached_host_free(pin, total);
-    delete h;
+    h->d_blob = nullptr;
     return set_error(KDEHIP_ERR_HIP, std::string("density upload: ") + hipGetErrorString(e));
   }
   h->blob_bytes = total;
   unsigned char *hp = static_cast<unsigned char *>(pin);
-  std::memcpy(hp + o_mean, host->means, nd);
-  std::memcpy(hp + o_bw, host->bandwidth, nd);
-  std::memcpy(hp + o_w, host->weights, n2);
-  std::memcpy(hp + o_perm, host->permutation, sizeof(int64_t) * 2 * N);
+  std::memcpy(hp + o_mean, host.means, nd);
+  std::memcpy(hp + o_bw, host.bandwidth, nd);
+  std::memcpy(hp + o_w, host.weights, n2);
+  std::memcpy(hp + o_perm, host.permutation, sizeof(int64_t) * 2 * N);
   std::memcpy(hp + o_front, h->fr.ids.data(), sizeof(int32_t) * h->fr.ids.size());
-  e = hipMemcpyAsync(h->d_blob, pin, total, hipMemcpyHostToDevice, nullptr);
-  if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+  e = hipMemcpyAsync(h->d_blob, pin, total, hipMemcpyHostToDevice, st);
+  const hipError_t se = hipStreamSynchronize(st);
   cached_host_free(pin, total);
-  if (e != hipSuccess) {
+  if (e != hipSuccess || se != hipSuccess) {
     cached_free(h->d_blob, total);
-    delete h;
-    return set_error(KDEHIP_ERR_HIP, std::string("density upload: ") + hipGetErrorString(e));
+    h->d_blob = nullptr;
+    return set_error(KDEHIP_ERR_HIP, std::string("density upload: ") + hipGetErrorString(e != hipSuccess ? e : se));
   }
   unsigned char *db = static_cast<unsigned char *>(h->d_blob);
   h->means = reinterpret_cast<const double *>(db + o_mean);
@@ -133,7 +123,185 @@ extern "C" int kdehip_density_upload(kdehip_device_density **out, const kdehip_d
   h->perm = reinterpret_cast<const int64_t *>(db + o_perm);
   h->front = reinterpret_cast<const int32_t *>(db + o_front);
   std::vector<int32_t>().swap(h->fr.ids);  // (the ids live on the device now; sizes, offsets and flags stay)
+  return KDEHIP_OK;
+}
+
+int check_shape(int64_t N, int64_t D) {
+  if (N < 1) return set_error(KDEHIP_ERR_ARG, "density with no points");
+  if (N > (int64_t(1) << 30)) return set_error(KDEHIP_ERR_UNSUPPORTED, "density too large");
+  if (D < 1 || D > KDEHIP_MAX_DIMS) return set_error(KDEHIP_ERR_UNSUPPORTED, "ndims outside 1..KDEHIP_MAX_DIMS");
+  return KDEHIP_OK;
+}
+
+// getPoints (src/KDE01.jl:91-101) of a resident density: the leaves back in the caller's original column order
+__global__ void unpermute_points_kernel(const double *__restrict__ means, const int64_t *__restrict__ perm, int64_t N, int D,
+                                        double *__restrict__ out) {
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= N * D) return;
+  const int64_t i = t / D;
+  const int k = static_cast<int>(t - i * D);
+  out[(perm[N + i] - 1) * D + k] = means[(N + i) * D + k];
+}
+
+}  // namespace
+
+extern "C" int kdehip_density_upload(kdehip_device_density **out, const kdehip_density *host, int device) {
+  if (!out) return set_error(KDEHIP_ERR_ARG, "null out pointer");
+  *out = nullptr;
+  if (!host) return set_error(KDEHIP_ERR_ARG, "null density");
+  const int64_t N = host->npts, D = host->ndim;
+  int rc = check_shape(N, D);
+  if (rc != KDEHIP_OK) return rc;
+  if (!host->means || !host->bandwidth || !host->weights || !host->left_child || !host->right_child || !host->permutation)
+    return set_error(KDEHIP_ERR_ARG, "density with a null array");
+  kdehip_device_density *h = new (std::nothrow) kdehip_device_density();
+  if (!h) return set_error(KDEHIP_ERR_ALLOC, "out of host memory");
+  h->device = device;
+  h->N = N;
+  h->D = static_cast<int>(D);
+  h->Lown = nlevels_for(N);
+  DeviceGuard guard;
+  rc = guard.enter(device);
+  if (rc == KDEHIP_OK) rc = upload_common(h, *host, hipStreamPerThread);
+  if (rc != KDEHIP_OK) { delete h; return rc; }
   *out = h;
+  return KDEHIP_OK;
+}
+
+// ---- the resident chain: kde!(pGM) of a product that is still in HBM, and `*` on handles --------------------------
+// src/MSGibbs01.jl:724-725: `pGM, = prodAppxMSGibbsS(...); return kde!(pGM)` -- the output of one product is the input
+// of the next ones (every message of a belief-propagation sweep).  With kdehip_prod_philox_device the sample matrix
+// never leaves the device; this entry turns it into the next product's input there: the LOOCV bandwidth search
+// (src/KDE01.jl:3-27) reads the device matrix as it is, the ball tree (src/BallTree01.jl:415-434: sequential
+// quick-selects, faster on the host's pooled builder than on the GPU for ONE density -- DESIGN.md f-3) is built from one
+// D x N copy that goes down while the search runs, and the density's block goes straight back up.  PCIe traffic per
+// link: 8*D*N bytes down, the density's block up; the caller's host never sees either.
+extern "C" int kdehip_density_from_device_points(kdehip_device_density **out, const double *d_points, int64_t D,
+                                                 int64_t N, int device, void *stream, double *bw_out, int32_t *nevals) {
+  if (!out) return set_error(KDEHIP_ERR_ARG, "null out pointer");
+  *out = nullptr;
+  if (!d_points) return set_error(KDEHIP_ERR_ARG, "null points");
+  int rc = check_shape(N, D);
+  if (rc != KDEHIP_OK) return rc;
+  if (N < 2) return set_error(KDEHIP_ERR_ARG, "kde!(points) needs at least two points");
+  DeviceGuard guard;
+  rc = guard.enter(device);
+  if (rc != KDEHIP_OK) return rc;
+  hipStream_t cs = hipStreamPerThread, ps = static_cast<hipStream_t>(stream);
+  if (ps != cs) KDEHIP_CHECK(hipStreamSynchronize(ps));  // the producer of d_points (blocking entry: the host waits anyway)
+  kdehip_device_density *h = new (std::nothrow) kdehip_device_density();
+  if (!h) return set_error(KDEHIP_ERR_ALLOC, "out of host memory");
+  struct Cleanup {
+    kdehip_device_density *h; void *pin = nullptr; size_t pin_bytes = 0;
+    ~Cleanup() { if (pin) cached_host_free(pin, pin_bytes); delete h; }
+  } cl{h};
+  h->device = device; h->N = N; h->D = static_cast<int>(D); h->Lown = nlevels_for(N);
+  cl.pin_bytes = sizeof(double) * N * D;
+  KDEHIP_CHECK(cached_host_malloc(&cl.pin, cl.pin_bytes));
+  KDEHIP_CHECK(hipMemcpyAsync(cl.pin, d_points, cl.pin_bytes, hipMemcpyDeviceToHost, cs));
+  KDEHIP_CHECK(hipStreamSynchronize(cs));
+  const double *pts = static_cast<const double *>(cl.pin);
+  // the reference's twelve arrays, kept as the handle's host mirror (kdehip_density_download)
+  const size_t nd = static_cast<size_t>(2 * N * D), n2 = static_cast<size_t>(2 * N);
+  try {
+    h->hf.assign(4 * nd + nd + n2, 0.0);
+    h->hi.assign(5 * n2, 0);
+  } catch (const std::exception &) { return set_error(KDEHIP_ERR_ALLOC, "out of host memory"); }
+  double *centers = h->hf.data(), *ranges = centers + nd, *means = ranges + nd, *bandwidth = means + nd;
+  double *bwmin = bandwidth + nd, *bwmax = bwmin + nd / 2, *weights = bwmax + nd / 2;
+  int64_t *left = h->hi.data(), *right = left + n2, *lowest = right + n2, *highest = lowest + n2, *perm = highest + n2;
+  double bw[KDEHIP_MAX_DIMS];
+  int tree_rc = KDEHIP_OK;
+  try {
+    TaskGroup group(HostPool::get());
+    group.run([&] {
+      const double one = 1.0;  // (placeholder: only `bandwidth`, bandwidthMin/Max depend on the bandwidth)
+      tree_rc = kdehip_make_density(D, N, pts, &one, 1, nullptr, centers, ranges, weights, left, right, lowest, highest,
+                                    perm, means, bandwidth, bwmin, bwmax);
+    });
+    rc = auto_bandwidth_run(static_cast<int>(D), N, pts, d_points, cs, bw, nevals);
+    group.wait();
+  } catch (const std::exception &e) {
+    return set_error(KDEHIP_ERR_ALLOC, std::string("kdehip_density_from_device_points: ") + e.what());
+  }
+  if (rc != KDEHIP_OK) return rc;
+  if (tree_rc != KDEHIP_OK) return set_error(tree_rc, "kdehip_density_from_device_points: the tree build failed");
+  rc = kdehip_density_set_bandwidth(D, N, bw, D, weights, left, right, means, bandwidth, bwmin, bwmax);
+  if (rc != KDEHIP_OK) return rc;
+  for (int k = 0; k < D; ++k) { h->bw[k] = bw[k]; if (bw_out) bw_out[k] = bw[k]; }
+  h->built = true;
+  const kdehip_density host{N, D, means, bandwidth, weights, left, right, perm};
+  rc = upload_common(h, host, cs);
+  if (rc != KDEHIP_OK) return rc;
+  cl.h = nullptr;
+  *out = h;
+  return KDEHIP_OK;
+}
+
+// `*(trees; addEntropy)` (src/MSGibbs01.jl:707-726) on handles: Np = round(mean Npts), Niter = 5, then kde!(pGM) -- and
+// the "hack fix for #70" (:713-716: one density, no entropy -> kde! of its own points).
+extern "C" int kdehip_mul_device(kdehip_device_density **out, int Ndens, kdehip_device_density *const *trees, uint64_t seed,
+                                 int addEntropy, double *bw_out, int32_t *nevals) {
+  if (!out) return set_error(KDEHIP_ERR_ARG, "null out pointer");
+  *out = nullptr;
+  if (Ndens < 1 || !trees) return set_error(KDEHIP_ERR_ARG, "need at least one density");
+  for (int j = 0; j < Ndens; ++j) {
+    if (!trees[j]) return set_error(KDEHIP_ERR_ARG, "null density");
+    if (trees[j]->D != trees[0]->D) return set_error(KDEHIP_ERR_DIM_MISMATCH, "kdes must have same dimension");
+    if (trees[j]->device != trees[0]->device) return set_error(KDEHIP_ERR_ARG, "densities on different devices");
+  }
+  const int D = trees[0]->D, device = trees[0]->device;
+  DeviceGuard guard;
+  int rc = guard.enter(device);
+  if (rc != KDEHIP_OK) return rc;
+  hipStream_t cs = hipStreamPerThread;
+  struct Scratch {
+    void *p = nullptr; size_t n = 0; hipStream_t st;
+    ~Scratch() { if (p) { (void)hipStreamSynchronize(st); cached_free(p, n); } }
+  } sc;
+  sc.st = cs;
+  if (Ndens == 1 && !addEntropy) {
+    const int64_t N = trees[0]->N;
+    sc.n = sizeof(double) * N * D;
+    KDEHIP_CHECK(cached_malloc(&sc.p, sc.n));
+    const int64_t items = N * D;
+    hipLaunchKernelGGL(unpermute_points_kernel, dim3(static_cast<unsigned>((items + 255) / 256)), dim3(256), 0, cs,
+                       trees[0]->means, trees[0]->perm, N, D, static_cast<double *>(sc.p));
+    KDEHIP_CHECK(hipGetLastError());
+    return kdehip_density_from_device_points(out, static_cast<const double *>(sc.p), D, N, device, cs, bw_out, nevals);
+  }
+  double sum = 0.0;  // numpts = round(Int, mean(Npts.(trees))): Julia rounds halves to even, like nearbyint
+  for (int j = 0; j < Ndens; ++j) sum += static_cast<double>(trees[j]->N);
+  const int64_t Np = static_cast<int64_t>(std::nearbyint(sum / static_cast<double>(Ndens)));
+  auto al = [](size_t x) { return (x + 255) & ~static_cast<size_t>(255); };
+  const size_t off_i = al(sizeof(double) * Np * D);
+  sc.n = off_i + sizeof(int64_t) * Np * Ndens;
+  KDEHIP_CHECK(cached_malloc(&sc.p, sc.n));
+  double *d_pts = static_cast<double *>(sc.p);
+  int64_t *d_ind = reinterpret_cast<int64_t *>(static_cast<unsigned char *>(sc.p) + off_i);
+  rc = prod_philox_device_blocking_stream(Ndens, trees, Np, /*Niter=*/5, seed, 0, addEntropy, nullptr, 64, d_pts, d_ind, cs);
+  if (rc != KDEHIP_OK) return rc;
+  return kdehip_density_from_device_points(out, d_pts, D, Np, device, cs, bw_out, nevals);
+}
+
+// The arrays of a density the library built (kdehip_density_from_device_points / kdehip_mul_device), shaped as in
+// kdehip_make_density; any pointer may be NULL.  A density that came from kdehip_density_upload has no mirror: its
+// arrays are the caller's.
+extern "C" int kdehip_density_download(const kdehip_device_density *h, double *centers, double *ranges, double *weights,
+                                       int64_t *left_child, int64_t *right_child, int64_t *lowest_leaf,
+                                       int64_t *highest_leaf, int64_t *permutation, double *means, double *bandwidth,
+                                       double *bandwidthMin, double *bandwidthMax, double *bw_out) {
+  if (!h) return set_error(KDEHIP_ERR_ARG, "null density");
+  if (!h->built) return set_error(KDEHIP_ERR_UNSUPPORTED, "this density was uploaded by the caller, who holds its arrays");
+  const size_t nd = static_cast<size_t>(2 * h->N * h->D), n2 = static_cast<size_t>(2 * h->N);
+  const double *f = h->hf.data();
+  const int64_t *i = h->hi.data();
+  auto cp = [](auto *dst, const auto *src, size_t n) { if (dst) std::memcpy(dst, src, n * sizeof(*src)); };
+  cp(centers, f, nd); cp(ranges, f + nd, nd); cp(means, f + 2 * nd, nd); cp(bandwidth, f + 3 * nd, nd);
+  cp(bandwidthMin, f + 4 * nd, nd / 2); cp(bandwidthMax, f + 4 * nd + nd / 2, nd / 2); cp(weights, f + 5 * nd, n2);
+  cp(left_child, i, n2); cp(right_child, i + n2, n2); cp(lowest_leaf, i + 2 * n2, n2); cp(highest_leaf, i + 3 * n2, n2);
+  cp(permutation, i + 4 * n2, n2);
+  if (bw_out) for (int k = 0; k < h->D; ++k) bw_out[k] = h->bw[k];
   return KDEHIP_OK;
 }
 

@@ -679,22 +679,29 @@ int kdehip_prod_philox(int Ndens, const kdehip_density *trees, int64_t Np, int N
 // ---- products of densities that live in HBM (pack_device.hip) ------------------------------------------------------
 namespace {
 
+constexpr int kMaxDevices = 64;  // devices the bookkeeping below has slots for (a node has 8)
+
 // Plans of enqueue-only calls live until the work that uses them has run: they wait here, with an event recorded behind
-// their last launch, and are released by later calls (or kdehip_clear_cache) once the event has fired.
+// their last launch, and are released by later calls (or kdehip_clear_cache) once the event has fired.  One entry = one
+// call: the plan of kdehip_prod_philox_device, or all plans of a kdehip_prod_philox_batch (they share one device block).
 struct PendingPlan {
-  kdehip_product *plan;
-  hipEvent_t done;
-  void *h_desc;
-  size_t h_bytes;
-  hipEvent_t prepared = nullptr;  // tiles and tables are in place (recorded on the device's preparation stream)
+  std::vector<kdehip_product *> plans;  // descriptors only when `d_blob` is set (the block below is theirs, shared)
+  void *d_blob = nullptr;               // a batch's one device block
+  size_t blob_bytes = 0;
+  hipEvent_t done = nullptr;
+  void *h_desc = nullptr;
+  size_t h_bytes = 0;
+  hipStream_t stream = nullptr;           // the caller's stream the work was enqueued on
+  hipEvent_t prepared = nullptr;          // tiles and tables are in place (recorded on the device's preparation stream)
   hipEvent_t t_begin = nullptr, t_end = nullptr;  // kdehip_profile_sampler: around the sampling launch, on the caller's stream
+  int device = 0;
 };
 
-// kdehip_profile_sampler: durations of the sampling launches of released plans, per device
+// kdehip_profile_sampler: durations of the sampling launches of released plans, per device and caller stream
 std::atomic<int> g_profile_sampler{0};
 std::mutex g_profile_mu;
-double g_profile_ms[64];
-long long g_profile_launches[64];
+struct ProfileSum { hipStream_t stream; double ms; long long launches; };
+std::vector<ProfileSum> g_profile[kMaxDevices];
 
 // Preparing a product of resident densities (descriptor upload, tile gather, conditional tables: ~35 us of small,
 // latency-bound launches) does not depend on anything the caller's stream holds -- the densities are immutable, the
@@ -702,10 +709,10 @@ long long g_profile_launches[64];
 // that enqueues products back to back gets product k+1 prepared WHILE product k samples (the sampler leaves 112
 // registers per SIMD and 19 KB of LDS per CU free: the small kernels fit beside it).
 std::mutex g_prep_mu;
-hipStream_t g_prep_stream[64];
-bool g_prep_tried[64];
+hipStream_t g_prep_stream[kMaxDevices];
+bool g_prep_tried[kMaxDevices];
 hipStream_t prep_stream(int device) {  // (the device is current)
-  if (device < 0 || device >= 64) return nullptr;
+  if (device < 0 || device >= kMaxDevices) return nullptr;
   std::lock_guard<std::mutex> lock(g_prep_mu);
   if (!g_prep_tried[device]) {
     g_prep_tried[device] = true;
@@ -717,43 +724,65 @@ hipStream_t prep_stream(int device) {  // (the device is current)
   return g_prep_stream[device];
 }
 std::mutex g_pending_mu;
-std::deque<PendingPlan> g_pending[64];
-constexpr size_t kMaxPending = 8;
+std::deque<PendingPlan> g_pending[kMaxDevices];
+constexpr size_t kMaxPending = 8;  // per (device, stream)
 
 void release_pending(PendingPlan &pp) {
-  if (pp.t_begin && pp.t_end && pp.plan) {  // (the plan's work is over: `done` was recorded behind t_end)
+  if (pp.t_begin && pp.t_end) {  // (the work is over: `done` was recorded behind t_end)
     float ms = 0.0f;
-    if (hipEventElapsedTime(&ms, pp.t_begin, pp.t_end) == hipSuccess && pp.plan->device >= 0 && pp.plan->device < 64) {
+    if (hipEventElapsedTime(&ms, pp.t_begin, pp.t_end) == hipSuccess && pp.device >= 0 && pp.device < kMaxDevices) {
       std::lock_guard<std::mutex> lock(g_profile_mu);
-      g_profile_ms[pp.plan->device] += ms;
-      g_profile_launches[pp.plan->device] += 1;
+      ProfileSum *ps = nullptr;
+      for (ProfileSum &c : g_profile[pp.device]) if (c.stream == pp.stream) ps = &c;
+      if (!ps) { g_profile[pp.device].push_back(ProfileSum{pp.stream, 0.0, 0}); ps = &g_profile[pp.device].back(); }
+      ps->ms += ms;
+      ps->launches += 1;
     }
     (void)hipGetLastError();
   }
   if (pp.t_begin) (void)hipEventDestroy(pp.t_begin);
   if (pp.t_end) (void)hipEventDestroy(pp.t_end);
-  (void)hipEventDestroy(pp.done);
+  if (pp.done) (void)hipEventDestroy(pp.done);
   if (pp.prepared) (void)hipEventDestroy(pp.prepared);
   if (pp.h_desc) cached_host_free(pp.h_desc, pp.h_bytes);
-  if (pp.plan) {
-    if (pp.plan->d_blob) cached_free(pp.plan->d_blob, pp.plan->blob_bytes);
-    if (pp.plan->d_work) cached_free(pp.plan->d_work, pp.plan->work_cap);
-    delete pp.plan;
+  for (kdehip_product *p : pp.plans) {
+    if (!p) continue;
+    if (!pp.d_blob && p->d_blob) cached_free(p->d_blob, p->blob_bytes);
+    if (p->d_work) cached_free(p->d_work, p->work_cap);
+    delete p;
   }
+  if (pp.d_blob) cached_free(pp.d_blob, pp.blob_bytes);
 }
-// (current device = `device`)  Releases what has finished; with more than kMaxPending plans in flight waits for the oldest.
-void reap_pending(int device, bool all) {
-  if (device < 0 || device >= 64) return;
-  std::lock_guard<std::mutex> lock(g_pending_mu);
-  auto &q = g_pending[device];
-  while (!q.empty()) {
-    PendingPlan &f = q.front();
-    if (all || q.size() > kMaxPending) (void)hipEventSynchronize(f.done);
-    else if (hipEventQuery(f.done) != hipSuccess) break;
-    release_pending(f);
-    q.pop_front();
+// (current device = `device`)  Releases every queued call whose work is over, wherever it sits in the queue.  A caller
+// with more than kMaxPending calls in flight ON ITS OWN STREAM then waits for the oldest of THOSE -- outside the lock,
+// and never for another stream's work: a stalled stream (a long kernel, an event another host thread records later)
+// holds up neither the other threads nor, through them, itself.  all = true (kdehip_clear_cache, the profile read-out):
+// wait for everything.
+void reap_pending(int device, bool all, hipStream_t mine = nullptr) {
+  if (device < 0 || device >= kMaxDevices) return;
+  for (;;) {
+    std::vector<PendingPlan> finished;
+    PendingPlan wait_for;
+    bool have_wait = false;
+    {
+      std::lock_guard<std::mutex> lock(g_pending_mu);
+      auto &q = g_pending[device];
+      size_t of_mine = 0;
+      for (auto it = q.begin(); it != q.end();) {
+        if (hipEventQuery(it->done) == hipSuccess) { finished.push_back(std::move(*it)); it = q.erase(it); }
+        else { if (!all && it->stream == mine) ++of_mine; ++it; }
+      }
+      (void)hipGetLastError();  // (hipEventQuery reports "not ready" as an error)
+      if (all ? !q.empty() : of_mine > kMaxPending) {
+        for (auto it = q.begin(); it != q.end(); ++it)
+          if (all || it->stream == mine) { wait_for = std::move(*it); q.erase(it); have_wait = true; break; }
+      }
+    }
+    for (PendingPlan &f : finished) release_pending(f);
+    if (!have_wait) return;
+    (void)hipEventSynchronize(wait_for.done);
+    release_pending(wait_for);
   }
-  (void)hipGetLastError();  // (hipEventQuery reports "not ready" as an error)
 }
 
 }  // namespace
@@ -762,29 +791,31 @@ void kdehip_internal_drain_pending() {  // kdehip_clear_cache: nothing may stay 
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return;
   DeviceGuard guard;
-  for (int d = 0; d < n && d < 64; ++d)
+  for (int d = 0; d < n && d < kMaxDevices; ++d)
     if (guard.enter(d) == KDEHIP_OK) reap_pending(d, true);
 }
 
 namespace {
-// own_prep: prepare on the library's stream (an asynchronous caller: the next product's preparation overlaps this
-// product's sampling); a blocking caller, who waits for every product, keeps everything on its own stream
-int prod_philox_device(int Ndens, kdehip_device_density *const *trees, int64_t Np, int Niter, uint64_t seed,
-                       int64_t sample_offset, int addEntropy, const uint8_t *partialDimMask, int precision,
-                       double *d_points, int64_t *d_indices, int32_t *d_labels, void *stream, bool own_prep) {
+
+// The layout of one product of resident densities inside a device block: [counter | levels | table descriptors] in the
+// block's head (what crosses PCIe), [permutation | tiles | tables] in its body (written by the GPU).
+struct ResidentLayout {
+  size_t off_lev = 0, off_count = 0, off_tab = 0, head_end = 0;  // head, relative to the head's start
+  size_t off_perm = 0, off_data = 0, off_tables = 0, body_end = 0;  // body, relative to the body's start
+};
+
+// Validates one product of resident densities and lays it out from the shapes of its densities' frontiers alone
+// (p->host, p->precision, p->mode, p->device are set; nothing is allocated).
+int layout_resident(int Ndens, kdehip_device_density *const *trees, const uint8_t *partialDimMask, int precision,
+                    kdehip_product *p, ResidentLayout &lay) {
   if (Ndens < 1 || !trees) return set_error(KDEHIP_ERR_ARG, "need at least one density");
   if (Ndens > KDEHIP_MAX_DENS) return set_error(KDEHIP_ERR_UNSUPPORTED, "more than KDEHIP_MAX_DENS densities in one product");
-  if (precision != 64 && precision != 32) return set_error(KDEHIP_ERR_ARG, "precision must be 64 or 32");
   for (int j = 0; j < Ndens; ++j) {
     if (!trees[j]) return set_error(KDEHIP_ERR_ARG, "null density");
     if (trees[j]->D != trees[0]->D) return set_error(KDEHIP_ERR_DIM_MISMATCH, "kdes must have same dimension");
     if (trees[j]->device != trees[0]->device) return set_error(KDEHIP_ERR_ARG, "densities on different devices");
   }
-  if (Np < 0) return set_error(KDEHIP_ERR_ARG, "Np must be >= 0");
-  if (Niter < 0) return set_error(KDEHIP_ERR_ARG, "Niter must be >= 0");
-  if (Np > 0 && (!d_points || !d_indices)) return set_error(KDEHIP_ERR_ARG, "null output pointer");
-  if (Np == 0) return KDEHIP_OK;
-  const int M = Ndens, D = trees[0]->D, device = trees[0]->device;
+  const int M = Ndens, D = trees[0]->D;
   int64_t maxN = 0;
   for (int j = 0; j < M; ++j) if (trees[j]->N > maxN) maxN = trees[j]->N;
   const int L = nlevels_for(maxN);
@@ -806,33 +837,88 @@ int prod_philox_device(int Ndens, kdehip_device_density *const *trees, int64_t N
     }
   }
   const bool fast = finite_ok && variances_in_range(lo, hi, D, precision);
-  kdehip_product *p = new (std::nothrow) kdehip_product();
-  if (!p) return set_error(KDEHIP_ERR_ALLOC, "out of host memory");
-  int rc = pack_layout_shapes(M, D, L, shapes.data(), partialDimMask, precision, fast, p->host);
-  if (rc != KDEHIP_OK) { delete p; return rc; }
-  DeviceGuard guard;
-  rc = guard.enter(device);
-  if (rc != KDEHIP_OK) { delete p; return rc; }
-  reap_pending(device, false);
-  p->device = device;
+  const int rc = pack_layout_shapes(M, D, L, shapes.data(), partialDimMask, precision, fast, p->host);
+  if (rc != KDEHIP_OK) return rc;
+  p->device = trees[0]->device;
   p->precision = precision;
   p->fast = p->host.fast;
   p->mode = !p->host.fast ? kModeGeneric : (p->host.all_active ? kModeFast : kModeFastMasked);
-  // the blob: [counter | levels | table descriptors | fill jobs | permutation | tiles | tables]
   const size_t nlev = p->host.levels.size(), ntab = p->host.tabdesc.size();
   const size_t esz = (precision == 64) ? sizeof(double) : sizeof(float);
-  const size_t off_lev = 256, off_count = off_lev - sizeof(unsigned long long);
-  const size_t off_tab = align256(off_lev + nlev * sizeof(LevelDesc));
-  const size_t off_jobs = align256(off_tab + ntab * sizeof(TabDesc));
-  const size_t off_perm = align256(off_jobs + nlev * sizeof(FillJob));
-  const size_t off_data = align256(off_perm + static_cast<size_t>(p->host.perm_elems) * sizeof(int32_t));
-  const size_t off_tables = align256(off_data + static_cast<size_t>(p->host.data_elems) * esz);
-  const size_t total = off_tables + static_cast<size_t>(p->host.tab_entries) * esz;
-  PendingPlan pend{p, nullptr, nullptr, off_perm};
+  lay.off_lev = 256;
+  lay.off_count = lay.off_lev - sizeof(unsigned long long);
+  lay.off_tab = align256(lay.off_lev + nlev * sizeof(LevelDesc));
+  lay.head_end = align256(lay.off_tab + ntab * sizeof(TabDesc));
+  lay.off_perm = 0;
+  lay.off_data = align256(static_cast<size_t>(p->host.perm_elems) * sizeof(int32_t));
+  lay.off_tables = align256(lay.off_data + static_cast<size_t>(p->host.data_elems) * esz);
+  lay.body_end = align256(lay.off_tables + static_cast<size_t>(p->host.tab_entries) * esz);
+  return KDEHIP_OK;
+}
+
+// Descriptors of product p into the pinned head at hb (its part starts at `head`), its fill jobs to `jobs`; binds the
+// plan's device pointers (block d_blob, head at `head`, body at `body`).  Returns the largest tile's rows per lane.
+int describe_resident(kdehip_product *p, kdehip_device_density *const *trees, const ResidentLayout &lay, void *d_blob,
+                      unsigned char *hb, size_t head, size_t body, FillJob *jobs) {
+  const int M = p->host.M, L = p->host.L, D = p->host.D;
+  const size_t nlev = p->host.levels.size(), ntab = p->host.tabdesc.size();
+  const size_t esz = (p->precision == 64) ? sizeof(double) : sizeof(float);
+  std::memset(hb + head, 0, lay.off_lev);
+  std::memcpy(hb + head + lay.off_lev, p->host.levels.data(), nlev * sizeof(LevelDesc));
+  std::memcpy(hb + head + lay.off_tab, p->host.tabdesc.data(), ntab * sizeof(TabDesc));
+  p->d_blob = d_blob;
+  bind_plan(p, head + lay.off_lev, head + lay.off_count, head + lay.off_tab, body + lay.off_perm, body + lay.off_data,
+            body + lay.off_tables, lay.head_end + lay.body_end);
+  int maxB = 1;
+  unsigned char *data = static_cast<unsigned char *>(p->d_data);
+  for (int j = 0; j < M; ++j)
+    for (int l = 0; l <= L; ++l) {
+      const size_t idx = static_cast<size_t>(j) * (L + 1) + l;
+      const LevelDesc &ds = p->host.levels[idx];
+      const kdehip_device_density &t = *trees[j];
+      const int lj = l < t.Lown ? l : t.Lown;
+      jobs[idx] = FillJob{t.means, t.bandwidth, t.weights, t.perm, t.front + t.fr.off[lj],
+                          data + static_cast<size_t>(ds.hdr_off) * esz, p->d_perm + ds.perm_off,
+                          ds.n, ds.B, ds.F, ds.uniform_bw, D, 0};
+      if (ds.B > maxB) maxB = ds.B;
+    }
+  return maxB;
+}
+
+// own_prep: prepare on the library's stream (an asynchronous caller: the next product's preparation overlaps this
+// product's sampling); a blocking caller, who waits for every product, keeps everything on its own stream
+int prod_philox_device(int Ndens, kdehip_device_density *const *trees, int64_t Np, int Niter, uint64_t seed,
+                       int64_t sample_offset, int addEntropy, const uint8_t *partialDimMask, int precision,
+                       double *d_points, int64_t *d_indices, int32_t *d_labels, void *stream, bool own_prep) {
+  if (precision != 64 && precision != 32) return set_error(KDEHIP_ERR_ARG, "precision must be 64 or 32");
+  if (Np < 0) return set_error(KDEHIP_ERR_ARG, "Np must be >= 0");
+  if (Niter < 0) return set_error(KDEHIP_ERR_ARG, "Niter must be >= 0");
+  if (Np > 0 && (!d_points || !d_indices)) return set_error(KDEHIP_ERR_ARG, "null output pointer");
+  kdehip_product *p = new (std::nothrow) kdehip_product();
+  if (!p) return set_error(KDEHIP_ERR_ALLOC, "out of host memory");
+  ResidentLayout lay;
+  int rc = layout_resident(Ndens, trees, partialDimMask, precision, p, lay);
+  if (rc != KDEHIP_OK || Np == 0) { delete p; return rc; }
+  const int device = p->device;
+  if (device < 0 || device >= kMaxDevices) { delete p; return set_error(KDEHIP_ERR_UNSUPPORTED, "device ordinal beyond the library's bookkeeping (64)"); }
+  DeviceGuard guard;
+  rc = guard.enter(device);
+  if (rc != KDEHIP_OK) { delete p; return rc; }
   hipStream_t st = static_cast<hipStream_t>(stream);
+  reap_pending(device, false, st);
+  // the block: head [counter | levels | table descriptors | fill jobs], body [permutation | tiles | tables]
+  const size_t nlev = p->host.levels.size();
+  const size_t off_jobs = lay.head_end, head_bytes = align256(off_jobs + nlev * sizeof(FillJob));
+  const size_t total = head_bytes + lay.body_end;
+  PendingPlan pend;
+  pend.plans.push_back(p);
+  pend.h_bytes = head_bytes;
+  pend.stream = st;
+  pend.device = device;
   hipStream_t prep = own_prep ? prep_stream(device) : nullptr;
-  hipError_t e = cached_malloc(&p->d_blob, total);
-  if (e == hipSuccess) p->blob_bytes = total;
+  void *blob = nullptr;
+  hipError_t e = cached_malloc(&blob, total);
+  if (e == hipSuccess) { p->d_blob = blob; p->blob_bytes = total; }
   if (e == hipSuccess) e = cached_host_malloc(&pend.h_desc, pend.h_bytes);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&pend.done, hipEventDisableTiming);
   if (e == hipSuccess && prep) e = hipEventCreateWithFlags(&pend.prepared, hipEventDisableTiming);
@@ -841,32 +927,13 @@ int prod_philox_device(int Ndens, kdehip_device_density *const *trees, int64_t N
     if (e == hipSuccess) e = hipEventCreate(&pend.t_end);
   }
   if (e != hipSuccess) {
-    if (pend.done) (void)hipEventDestroy(pend.done);
-    if (pend.prepared) (void)hipEventDestroy(pend.prepared);
-    if (pend.t_begin) (void)hipEventDestroy(pend.t_begin);
-    if (pend.t_end) (void)hipEventDestroy(pend.t_end);
-    pend.done = nullptr;
-    if (pend.h_desc) cached_host_free(pend.h_desc, pend.h_bytes);
-    if (p->d_blob) cached_free(p->d_blob, total);
-    delete p;
+    release_pending(pend);
     return set_error(KDEHIP_ERR_HIP, std::string("device product: ") + hipGetErrorString(e));
   }
-  // descriptors: a few KB from pinned memory, in front of the launches on the caller's stream
+  // descriptors: a few KB from pinned memory, in front of the launches
   unsigned char *hb = static_cast<unsigned char *>(pend.h_desc);
-  std::memset(hb, 0, off_lev);
-  std::memcpy(hb + off_lev, p->host.levels.data(), nlev * sizeof(LevelDesc));
-  std::memcpy(hb + off_tab, p->host.tabdesc.data(), ntab * sizeof(TabDesc));
-  FillJob *jobs = reinterpret_cast<FillJob *>(hb + off_jobs);
-  int maxB = 1;
-  for (int j = 0; j < M; ++j)
-    for (int l = 0; l <= L; ++l) {
-      const size_t idx = static_cast<size_t>(j) * (L + 1) + l;
-      const LevelDesc &ds = p->host.levels[idx];
-      const int lj = l < trees[j]->Lown ? l : trees[j]->Lown;
-      jobs[idx] = FillJob{ds.hdr_off, ds.perm_off, trees[j]->fr.off[lj], ds.n, ds.B, ds.F, ds.uniform_bw, j, 0};
-      if (ds.B > maxB) maxB = ds.B;
-    }
-  bind_plan(p, off_lev, off_count, off_tab, off_perm, off_data, off_tables, total);
+  const int maxB = describe_resident(p, trees, lay, blob, hb, 0, head_bytes, reinterpret_cast<FillJob *>(hb + off_jobs));
+  p->blob_bytes = total;
   hipStream_t ps = prep ? prep : st;  // where the plan is prepared
   auto fail = [&](int code) {  // (nothing of this plan has been handed to the queue yet)
     if (prep) (void)hipStreamSynchronize(prep);
@@ -874,18 +941,10 @@ int prod_philox_device(int Ndens, kdehip_device_density *const *trees, int64_t N
     release_pending(pend);
     return code;
   };
-  if (hipMemcpyAsync(p->d_blob, hb, off_perm, hipMemcpyHostToDevice, ps) != hipSuccess)
+  if (hipMemcpyAsync(blob, hb, head_bytes, hipMemcpyHostToDevice, ps) != hipSuccess)
     return fail(set_error(KDEHIP_ERR_HIP, "device product: descriptor upload failed"));
-  FillArgs fa{};
-  for (int j = 0; j < M; ++j) {
-    fa.means[j] = trees[j]->means; fa.bandwidth[j] = trees[j]->bandwidth; fa.weights[j] = trees[j]->weights;
-    fa.perm[j] = trees[j]->perm; fa.front[j] = trees[j]->front;
-  }
-  fa.jobs = reinterpret_cast<const FillJob *>(static_cast<unsigned char *>(p->d_blob) + off_jobs);
-  fa.data = p->d_data;
-  fa.perm_out = p->d_perm;
-  fa.D = D;
-  rc = launch_fill_tiles(precision, fa, static_cast<int>(nlev), maxB, ps);
+  rc = launch_fill_tiles(precision, reinterpret_cast<const FillJob *>(static_cast<unsigned char *>(blob) + off_jobs),
+                         static_cast<int>(nlev), maxB, ps);
   if (rc != KDEHIP_OK) return fail(rc);
   rc = enqueue_philox(p, Np, Niter, seed, sample_offset, addEntropy, d_points, d_indices, d_labels, stream,
                       /*private_plan=*/true, nullptr, prep, pend.prepared, pend.t_begin, pend.t_end);
@@ -893,11 +952,166 @@ int prod_philox_device(int Ndens, kdehip_device_density *const *trees, int64_t N
   if (hipEventRecord(pend.done, st) != hipSuccess) return fail(set_error(KDEHIP_ERR_HIP, "device product: hipEventRecord failed"));
   {
     std::lock_guard<std::mutex> lock(g_pending_mu);
-    if (device >= 0 && device < 64) g_pending[device].push_back(pend);
+    g_pending[device].push_back(std::move(pend));
   }
   return KDEHIP_OK;
 }
+
+// whether a product can ride in a batched launch of the register-resident sampler (gibbs_lean.hip, BATCH instantiations:
+// fp64 products of 2..4 densities with every dimension active)
+bool batchable(const kdehip_product *p) {
+  const int M = p->host.M, L = p->host.L, D = p->host.D;
+  return p->precision == 64 && p->mode == kModeFast && M >= 2 && M <= 4 && D * (L + 1) <= 128;
+}
+
 }  // namespace
+
+// Many products in ONE call (the serving pattern: a belief-propagation sweep issues dozens of 100-300-chain products, each
+// of which fills a fraction of the device and is latency bound): one device block, one descriptor upload, one gather launch
+// for all tiles, and ONE sampling launch per (dimension count, density count) group -- workgroups indexed by (product,
+// chain block), every workgroup fetching its product's plan through the scalar cache.  Each product's result is bit for
+// bit what kdehip_prod_philox_device gives for it (same layout, same kernel code, same Philox keys).  Products outside
+// the batched kernel's domain (fp32, masks, 1 or more than 4 densities) are enqueued one by one inside the same call.
+int kdehip_prod_philox_batch(int nprod, const kdehip_batch_item *items, int precision, void *stream) {
+  if (nprod < 0 || (nprod > 0 && !items)) return set_error(KDEHIP_ERR_ARG, "kdehip_prod_philox_batch: bad item list");
+  if (precision != 64 && precision != 32) return set_error(KDEHIP_ERR_ARG, "precision must be 64 or 32");
+  if (nprod == 0) return KDEHIP_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  PendingPlan pend;
+  pend.stream = st;
+  struct Abort {  // on an error before the hand-over to the queue: nothing has been enqueued that uses the block
+    PendingPlan *pp; bool armed = true;
+    ~Abort() { if (armed) release_pending(*pp); }
+  } abort_guard{&pend};
+  std::vector<ResidentLayout> lays(nprod);
+  std::vector<size_t> head_at(nprod), body_at(nprod), jobs_at(nprod);
+  size_t head = 0, body = 0, njobs = 0;
+  int device = -1;
+  for (int i = 0; i < nprod; ++i) {
+    const kdehip_batch_item &it = items[i];
+    if (it.Np < 0) return set_error(KDEHIP_ERR_ARG, "Np must be >= 0");
+    if (it.Niter < 0) return set_error(KDEHIP_ERR_ARG, "Niter must be >= 0");
+    if (it.sample_offset < 0) return set_error(KDEHIP_ERR_ARG, "sample_offset must be >= 0");
+    if (it.Np > 0 && (!it.d_points || !it.d_indices)) return set_error(KDEHIP_ERR_ARG, "null output pointer");
+    kdehip_product *p = new (std::nothrow) kdehip_product();
+    if (!p) return set_error(KDEHIP_ERR_ALLOC, "out of host memory");
+    pend.plans.push_back(p);
+    const int rc = layout_resident(it.Ndens, it.trees, it.partialDimMask, precision, p, lays[i]);
+    if (rc != KDEHIP_OK) return rc;
+    if (device < 0) device = p->device;
+    if (p->device != device) return set_error(KDEHIP_ERR_ARG, "kdehip_prod_philox_batch: products on different devices");
+    head_at[i] = head; head += lays[i].head_end;
+    body_at[i] = body; body += lays[i].body_end;
+    jobs_at[i] = njobs; njobs += p->host.levels.size();
+  }
+  if (device < 0 || device >= kMaxDevices) return set_error(KDEHIP_ERR_UNSUPPORTED, "device ordinal beyond the library's bookkeeping (64)");
+  pend.device = device;
+  // groups of batchable products by (D, M); everything else runs one by one
+  struct Group { int D, M; std::vector<int> members; int64_t blocks = 0; size_t ent_at = 0, map_at = 0; };
+  std::vector<Group> groups;
+  std::vector<int> singles;
+  constexpr int kBatchWaves = 16;  // chains per workgroup of the batched instantiations
+  for (int i = 0; i < nprod; ++i) {
+    if (items[i].Np == 0) continue;
+    kdehip_product *p = pend.plans[i];
+    if (!batchable(p)) { singles.push_back(i); continue; }
+    Group *g = nullptr;
+    for (Group &c : groups) if (c.D == p->host.D && c.M == p->host.M) g = &c;
+    if (!g) { groups.push_back(Group{p->host.D, p->host.M, {}, 0, 0, 0}); g = &groups.back(); }
+    g->members.push_back(i);
+    g->blocks += (items[i].Np + kBatchWaves - 1) / kBatchWaves;
+  }
+  for (size_t k = 0; k < groups.size();)  // a group of one gains nothing from the batched kernel
+    if (groups[k].members.size() == 1) { singles.push_back(groups[k].members[0]); groups.erase(groups.begin() + k); } else ++k;
+  const size_t off_jobs = head;
+  size_t at = align256(off_jobs + njobs * sizeof(FillJob));
+  for (Group &g : groups) {
+    if (g.blocks > (int64_t(1) << 31) - 1) return set_error(KDEHIP_ERR_UNSUPPORTED, "kdehip_prod_philox_batch: too many chains for one launch");
+    g.ent_at = at; at = align256(at + g.members.size() * sizeof(BatchEntry));
+    g.map_at = at; at = align256(at + static_cast<size_t>(g.blocks) * sizeof(int32_t));
+  }
+  const size_t head_bytes = at, total = head_bytes + body;
+  DeviceGuard guard;
+  int rc = guard.enter(device);
+  if (rc != KDEHIP_OK) return rc;
+  reap_pending(device, false, st);
+  pend.h_bytes = head_bytes;
+  pend.blob_bytes = total;
+  hipError_t e = cached_malloc(&pend.d_blob, total);
+  if (e != hipSuccess) pend.d_blob = nullptr;
+  if (e == hipSuccess) e = cached_host_malloc(&pend.h_desc, pend.h_bytes);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&pend.done, hipEventDisableTiming);
+  if (e != hipSuccess) return set_error(KDEHIP_ERR_HIP, std::string("batched products: ") + hipGetErrorString(e));
+  unsigned char *hb = static_cast<unsigned char *>(pend.h_desc), *db = static_cast<unsigned char *>(pend.d_blob);
+  int maxB = 1;
+  for (int i = 0; i < nprod; ++i) {
+    const int b = describe_resident(pend.plans[i], items[i].trees, lays[i], pend.d_blob, hb, head_at[i], head_bytes + body_at[i],
+                                    reinterpret_cast<FillJob *>(hb + off_jobs) + jobs_at[i]);
+    if (b > maxB) maxB = b;
+  }
+  for (Group &g : groups) {
+    BatchEntry *ent = reinterpret_cast<BatchEntry *>(hb + g.ent_at);
+    int32_t *map = reinterpret_cast<int32_t *>(hb + g.map_at);
+    int32_t block = 0;
+    for (size_t k = 0; k < g.members.size(); ++k) {
+      const int i = g.members[k];
+      const kdehip_batch_item &it = items[i];
+      BatchEntry be{};
+      const PlanDev &pd = pend.plans[i]->dev;
+      be.head = BatchPlanHead{pd.data, pd.perm, pd.levels, pd.tables, pd.tabdesc, pd.tab_rows_total, pd.M, pd.L, pd.D, pd.Lt};
+      be.run.deep_level[0] = pd.deep_level[0]; be.run.deep_level[1] = pd.deep_level[1];
+      be.run.deep_share[0] = pd.deep_share[0]; be.run.deep_share[1] = pd.deep_share[1];
+      be.run.Np = it.Np; be.run.seed = it.seed; be.run.sample_offset = it.sample_offset;
+      be.run.points = it.d_points; be.run.indices = it.d_indices; be.run.labels = it.d_labels;
+      be.flags.Niter = it.Niter; be.flags.addEntropy = it.addEntropy ? 1 : 0; be.flags.use_tables = 0;
+      be.flags.first_block = block;
+      ent[k] = be;
+      const int32_t nb = static_cast<int32_t>((it.Np + kBatchWaves - 1) / kBatchWaves);
+      for (int32_t q = 0; q < nb; ++q) map[block + q] = static_cast<int32_t>(k);
+      block += nb;
+    }
+  }
+  auto fail = [&](int code) {  // work may have been enqueued: wait for it before the block goes back to the cache
+    (void)hipStreamSynchronize(st);
+    return code;
+  };
+  if (hipMemcpyAsync(pend.d_blob, hb, head_bytes, hipMemcpyHostToDevice, st) != hipSuccess)
+    return fail(set_error(KDEHIP_ERR_HIP, "batched products: descriptor upload failed"));
+  rc = launch_fill_tiles(precision, reinterpret_cast<const FillJob *>(db + off_jobs), static_cast<int>(njobs), maxB, st);
+  if (rc != KDEHIP_OK) return fail(rc);
+  for (const Group &g : groups) {
+    RunArgs a{};
+    a.rng_philox = 1;
+    a.batch = reinterpret_cast<const BatchEntry *>(db + g.ent_at);
+    a.batch_map = reinterpret_cast<const int32_t *>(db + g.map_at);
+    a.Np = g.blocks * kBatchWaves;  // (the launcher's grid: g.blocks workgroups)
+    rc = launch_gibbs_batch(g.D, g.M, pend.plans[g.members[0]]->dev, a, st);
+    if (rc != KDEHIP_OK) return fail(rc);
+  }
+  for (int i : singles) {
+    const kdehip_batch_item &it = items[i];
+    rc = enqueue_philox(pend.plans[i], it.Np, it.Niter, it.seed, it.sample_offset, it.addEntropy, it.d_points, it.d_indices,
+                        it.d_labels, stream, /*private_plan=*/true);
+    if (rc != KDEHIP_OK) return fail(rc);
+  }
+  if (hipEventRecord(pend.done, st) != hipSuccess) return fail(set_error(KDEHIP_ERR_HIP, "batched products: hipEventRecord failed"));
+  abort_guard.armed = false;
+  {
+    std::lock_guard<std::mutex> lock(g_pending_mu);
+    g_pending[device].push_back(std::move(pend));
+  }
+  return KDEHIP_OK;
+}
+
+}  // extern "C"
+int kdehip::prod_philox_device_blocking_stream(int Ndens, kdehip_device_density *const *trees, int64_t Np, int Niter,
+                                               uint64_t seed, int64_t sample_offset, int addEntropy,
+                                               const uint8_t *partialDimMask, int precision, double *d_points,
+                                               int64_t *d_indices, void *stream) {
+  return prod_philox_device(Ndens, trees, Np, Niter, seed, sample_offset, addEntropy, partialDimMask, precision, d_points,
+                            d_indices, nullptr, stream, /*own_prep=*/false);
+}
+extern "C" {
 
 int kdehip_prod_philox_device(int Ndens, kdehip_device_density *const *trees, int64_t Np, int Niter, uint64_t seed,
                               int64_t sample_offset, int addEntropy, const uint8_t *partialDimMask, int precision,
@@ -910,18 +1124,22 @@ int kdehip_prod_philox_device(int Ndens, kdehip_device_density *const *trees, in
 // stream (what bench.py reports as the kernel's duration INSIDE its timed region).
 void kdehip_profile_sampler(int enable) {
   std::lock_guard<std::mutex> lock(g_profile_mu);
-  for (int d = 0; d < 64; ++d) { g_profile_ms[d] = 0.0; g_profile_launches[d] = 0; }
+  for (int d = 0; d < kMaxDevices; ++d) g_profile[d].clear();
   g_profile_sampler.store(enable ? 1 : 0, std::memory_order_relaxed);
 }
-int kdehip_profile_sampler_read(int device, double *total_ms, int64_t *launches) {
-  if (device < 0 || device >= 64) return set_error(KDEHIP_ERR_ARG, "device ordinal outside 0..63");
+int kdehip_profile_sampler_read(int device, void *stream, double *total_ms, int64_t *launches) {
+  if (device < 0 || device >= kMaxDevices) return set_error(KDEHIP_ERR_ARG, "device ordinal outside 0..63");
   DeviceGuard guard;
   const int rc = guard.enter(device);
   if (rc != KDEHIP_OK) return rc;
   reap_pending(device, true);  // (waits for the plans still in flight: their launches count too)
   std::lock_guard<std::mutex> lock(g_profile_mu);
-  if (total_ms) *total_ms = g_profile_ms[device];
-  if (launches) *launches = g_profile_launches[device];
+  double ms = 0.0;
+  long long n = 0;
+  for (const ProfileSum &c : g_profile[device])
+    if (c.stream == static_cast<hipStream_t>(stream)) { ms += c.ms; n += c.launches; }
+  if (total_ms) *total_ms = ms;
+  if (launches) *launches = n;
   return KDEHIP_OK;
 }
 
@@ -966,7 +1184,41 @@ struct kdehip_product_multi {
   std::vector<hipEvent_t> done;   // per device: its slice has been written to every device
   std::vector<hipEvent_t> ready;  // per device: the work queued on its stream before this call is over (its arrays may be overwritten)
   bool peer_stores = true;        // every device can store into every other device's memory (else: peer copies)
+  int last_transfers = -1;        // copy-engine transfers per device of the last product (-1: none yet)
 };
+
+namespace {
+// Whether a kernel on `writer` may store through `p`, an array on another device, once peer access is enabled.
+// KDEHIP_PEER_STORES=0 forces the copy path (a caller whose allocator this check cannot see through), =1 skips the check.
+bool peer_can_store(const void *p, int writer) {
+  static const int forced = [] { const char *e = std::getenv("KDEHIP_PEER_STORES"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+  if (forced >= 0) return forced == 1;
+  hipMemLocation loc{};
+  loc.type = hipMemLocationTypeDevice;
+  loc.id = writer;
+  // a stream-ordered allocation: its pool must grant the writer read-write access
+  hipMemPool_t pool = nullptr;
+  if (hipPointerGetAttribute(&pool, HIP_POINTER_ATTRIBUTE_MEMPOOL_HANDLE, const_cast<void *>(p)) == hipSuccess && pool) {
+    hipMemAccessFlags fl = hipMemAccessFlagsProtNone;
+    const bool ok = hipMemPoolGetAccess(&fl, pool, &loc) == hipSuccess && fl == hipMemAccessFlagsProtReadWrite;
+    (void)hipGetLastError();
+    return ok;
+  }
+  (void)hipGetLastError();
+  // a virtual-memory mapping (hipMemMap): hipMemGetAccess knows it; plain hipMalloc memory makes the query fail
+  unsigned long long vf = 0;
+  if (hipMemGetAccess(&vf, &loc, const_cast<void *>(p)) == hipSuccess) {
+    (void)hipGetLastError();
+    return vf == static_cast<unsigned long long>(hipMemAccessFlagsProtReadWrite);
+  }
+  (void)hipGetLastError();
+  // plain device memory of another device of this process: covered by hipDeviceEnablePeerAccess
+  hipPointerAttribute_t at{};
+  const bool ok = hipPointerGetAttributes(&at, p) == hipSuccess && at.type == hipMemoryTypeDevice;
+  (void)hipGetLastError();
+  return ok;
+}
+}  // namespace
 
 int kdehip_product_multi_create(kdehip_product_multi **out, int Ndens, const kdehip_density *trees, int ndims,
                                 const uint8_t *partialDimMask, int precision, int first_device, int ngpus) {
@@ -1043,6 +1295,20 @@ int kdehip_product_multi_sample_philox(kdehip_product_multi *mp, int64_t Np, int
     if (!d_points[g] || !d_indices[g]) return set_error(KDEHIP_ERR_ARG, "null output pointer");
   DeviceGuard guard;
   auto stream_of = [&](int g) { return static_cast<hipStream_t>(streams ? streams[g] : nullptr); };
+  // The fused gather stores into the CALLER's arrays on the other devices.  hipDeviceEnablePeerAccess maps plain hipMalloc
+  // memory only: an array from a stream-ordered pool (hipMallocAsync) is reachable from a peer only if its pool grants
+  // that device access, one made of virtual-memory mappings only if hipMemSetAccess did.  Looked at per call (the
+  // caller may pass other arrays every time); anything that cannot be shown reachable takes the copy path.
+  bool peer_stores = mp->peer_stores;
+  for (int h = 0; h < G && peer_stores && G > 1; ++h)
+    for (int g = 0; g < G && peer_stores; ++g) {
+      // (KDEHIP_PEER_CHECK_ALIASED=1: tests on one GPU run the look-up on aliased devices too)
+      static const bool check_aliased = [] { const char *e = std::getenv("KDEHIP_PEER_CHECK_ALIASED"); return e && e[0] == '1'; }();
+      if (g == h || (phys(mp->first_device + g) == phys(mp->first_device + h) && !check_aliased)) continue;
+      if (!peer_can_store(d_points[h], phys(mp->first_device + g)) || !peer_can_store(d_indices[h], phys(mp->first_device + g)))
+        peer_stores = false;
+    }
+  mp->last_transfers = (peer_stores || G == 1) ? 0 : 2 * (G - 1);
   // (1) Device g is about to write into EVERY device's arrays: whatever is queued on the other devices' streams --
   // consumers of the previous product, typically -- must be over first (write after read).
   if (G > 1) {
@@ -1064,7 +1330,7 @@ int kdehip_product_multi_sample_philox(kdehip_product_multi *mp, int64_t Np, int
       if (h != g) KDEHIP_CHECK(hipStreamWaitEvent(st, mp->ready[h], 0));
     if (hi > lo) {
       PeerOutputs peers;
-      if (mp->peer_stores)
+      if (peer_stores)
         for (int h = 0; h < G; ++h) {
           if (h == g) continue;
           peers.points[peers.n] = d_points[h] + lo * D;
@@ -1076,7 +1342,7 @@ int kdehip_product_multi_sample_philox(kdehip_product_multi *mp, int64_t Np, int
                           d_indices[g] + lo * M, nullptr, st, /*private_plan=*/false, &peers);
       if (rc != KDEHIP_OK) return rc;
       mp->plans[g]->async_pending.store(true);
-      if (!mp->peer_stores)
+      if (!peer_stores)
         for (int h = 0; h < G; ++h) {
           if (h == g) continue;
           KDEHIP_CHECK(hipMemcpyPeerAsync(d_points[h] + lo * D, phys(mp->first_device + h), d_points[g] + lo * D,
@@ -1100,6 +1366,7 @@ int kdehip_product_multi_sample_philox(kdehip_product_multi *mp, int64_t Np, int
 
 int kdehip_product_multi_transfers_per_product(const kdehip_product_multi *mp) {
   if (!mp) return -1;
+  if (mp->last_transfers >= 0) return mp->last_transfers;  // what the last product did (its arrays were looked at)
   return mp->peer_stores ? 0 : 2 * (mp->ngpus - 1);
 }
 

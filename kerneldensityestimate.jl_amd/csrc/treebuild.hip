@@ -491,15 +491,15 @@ extern "C" int kdehip_make_densities_device(int nb, int64_t D, const int64_t *Ns
     J.perm = reinterpret_cast<int64_t *>(db + off[j].pm);
     J.nodes_by_depth = reinterpret_cast<int32_t *>(db + off[j].scratch);
   }
-  KDEHIP_CHECK(hipMemcpyAsync(d_base, h_base, in_total, hipMemcpyHostToDevice, nullptr));
+  KDEHIP_CHECK(hipMemcpyAsync(d_base, h_base, in_total, hipMemcpyHostToDevice, hipStreamPerThread));
   const TreeLds L = tree_lds(maxN, static_cast<int>(D));
   // (per call: the attribute belongs to the function ON THE CURRENT DEVICE, and concurrent host threads get here)
   KDEHIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(tree_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    static_cast<int>(kTreeLdsLimit)));
-  hipLaunchKernelGGL(tree_build_kernel, dim3(nb), dim3(kTB), L.total, nullptr, batch, L);
+  hipLaunchKernelGGL(tree_build_kernel, dim3(nb), dim3(kTB), L.total, hipStreamPerThread, batch, L);
   KDEHIP_CHECK(hipGetLastError());
-  KDEHIP_CHECK(hipMemcpyAsync(hb + out_begin, db + out_begin, out_end - out_begin, hipMemcpyDeviceToHost, nullptr));
-  KDEHIP_CHECK(hipStreamSynchronize(nullptr));
+  KDEHIP_CHECK(hipMemcpyAsync(hb + out_begin, db + out_begin, out_end - out_begin, hipMemcpyDeviceToHost, hipStreamPerThread));
+  KDEHIP_CHECK(hipStreamSynchronize(hipStreamPerThread));
   for (int j = 0; j < nb; ++j) {
     const int64_t N = Ns[j];
     const size_t nd = sizeof(double) * 2 * N * D, n2 = sizeof(double) * 2 * N;

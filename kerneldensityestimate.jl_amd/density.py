@@ -29,10 +29,12 @@ class BallTreeDensity:
     def _cstruct(self):
         """The C view of the six arrays a product reads (kdehip_density); kept while the arrays are the same objects."""
         bt = self.bt
-        key = (id(self.means), id(self.bandwidth), id(bt.weights), id(bt.left_child), id(bt.right_child),
-               id(bt.permutation), bt.num_points, bt.dims)
+        # the array OBJECTS are part of the key (compared with `is`): that also pins their lifetime, so the id of a freed
+        # array can never be taken over by a new one while the cached struct still points at the old memory
+        key = (self.means, self.bandwidth, bt.weights, bt.left_child, bt.right_child, bt.permutation, bt.num_points, bt.dims)
         cached = getattr(self, "_cstruct_cache", None)
-        if cached is not None and cached[0] == key:
+        if cached is not None and len(cached[0]) == len(key) and all(a is b for a, b in zip(cached[0][:6], key[:6])) \
+                and cached[0][6:] == key[6:]:
             return cached[1]
         cs = _lib.CDensity(bt.num_points, bt.dims, ptr(self.means, f64p), ptr(self.bandwidth, f64p),
                            ptr(bt.weights, f64p), ptr(bt.left_child, i64p), ptr(bt.right_child, i64p),

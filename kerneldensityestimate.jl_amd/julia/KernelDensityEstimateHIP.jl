@@ -9,7 +9,8 @@
 #
 # or, to route every existing caller (`*`, IncrementalInference, ...) through the GPU:
 #
-#   KernelDensityEstimateHIP.enable!()      # overrides KernelDensityEstimate.prodAppxMSGibbsS and .gibbs1
+#   KernelDensityEstimateHIP.enable!()      # overrides KernelDensityEstimate.prodAppxMSGibbsS, .gibbs1,
+#                                           # kde!(points) and evaluateDualTree: the WHOLE `*` runs on the GPU
 #
 # After enable!() a call of the reference's `prodAppxMSGibbsS` WITHOUT `randU=`/`randN=` (what `*` and every
 # JuliaRobotics caller does) no longer draws `rand(Np*Ndens*(Niter+2)*Nlevels)` / `randn(...)` on the host
@@ -18,7 +19,9 @@
 # reference's consumption order through the `gibbs1` override.
 #
 # NOTE: Julia is not installed in the build container, so this file has been written against the
-# C ABI but never executed; tests/ exercise the same entry points through the Python mirror.
+# C ABI but never executed; tests/ exercise the same entry points through the Python mirror, and
+# tests/test_julia_shim_syntax.py checks block structure, every ccall against include/kdehip.h and the list of
+# methods enable!() overrides.
 module KernelDensityEstimateHIP
 
 using KernelDensityEstimate
@@ -64,6 +67,22 @@ reference_gibbs1(args...; kw...) =
 const ORIGINAL_PROD = Ref{Any}(nothing)
 reference_prodAppxMSGibbsS(args...; kw...) =
   ORIGINAL_PROD[] === nothing ? KDE.prodAppxMSGibbsS(args...; kw...) : ORIGINAL_PROD[](args...; kw...)
+
+# ... and for the callers either side of the product: `kde!(points)` (LOOCV bandwidth; the second half of `*`,
+# src/MSGibbs01.jl:725) and `evaluateDualTree` (src/DualTree01.jl:370-421)
+const ORIGINAL_KDE_AUTO = Ref{Any}(nothing)
+reference_kde_auto(args...) = ORIGINAL_KDE_AUTO[] === nothing ? KDE.kde!(args...) : ORIGINAL_KDE_AUTO[](args...)
+const ORIGINAL_EVAL = Ref{Any}(nothing)
+const ORIGINAL_EVAL_BD = Ref{Any}(nothing)
+reference_evaluateDualTree(args...) =
+  ORIGINAL_EVAL[] === nothing ? KDE.evaluateDualTree(args...) : ORIGINAL_EVAL[](args...)
+reference_evaluateDualTree_bd(args...) =
+  ORIGINAL_EVAL_BD[] === nothing ? KDE.evaluateDualTree(args...) : ORIGINAL_EVAL_BD[](args...)
+
+isEuclidOps(addop, diffop) = all(f -> f === +, addop) && all(f -> f === -, diffop)
+# the direct evaluation kernel stands for the reference's default only (FORCE_EVAL_DIRECT = true,
+# src/KernelDensityEstimate.jl:54; setForceEvalDirect!(false) brings the dual-tree recursion back: reference path)
+directEval() = KDE.FORCE_EVAL_DIRECT
 
 isEuclid(addop, diffop, getMu, getLambda) =
   all(f -> f === +, addop) && all(f -> f === -, diffop) &&
@@ -206,6 +225,17 @@ mutable struct DeviceDensity
     finalizer(free!, d)
     return d
   end
+  function DeviceDensity(handle::Ptr{Cvoid}, npts::Int, ndim::Int)   # a density the library built (resident chain)
+    d = new(handle, npts, ndim)
+    finalizer(free!, d)
+    return d
+  end
+end
+# handle -> DeviceDensity for densities the library built itself (the resident chain below)
+function DeviceDensity(handle::Ptr{Cvoid})
+  d = ccall((:kdehip_density_npts, libkdehip), Int64, (Ptr{Cvoid},), handle)
+  k = ccall((:kdehip_density_ndim, libkdehip), Cint, (Ptr{Cvoid},), handle)
+  return DeviceDensity(handle, Int(d), Int(k))
 end
 function free!(d::DeviceDensity)
   if d.handle != C_NULL
@@ -213,6 +243,51 @@ function free!(d::DeviceDensity)
     d.handle = C_NULL
   end
   nothing
+end
+
+"""
+    *(trees::Vector{DeviceDensity}; addEntropy=true, seed=nothing) -> DeviceDensity
+
+The reference's `*` (src/MSGibbs01.jl:707-726: product with Niter = 5 and Np = round(mean Npts), then `kde!(pGM)`) on
+densities that live in HBM, result in HBM (`kdehip_mul_device`): the sample matrix never leaves the device -- the
+bandwidth search reads it there, the tree is built from one copy that comes down meanwhile, the new density's block
+goes straight back up.  A belief-propagation sweep chains such products without PCIe traffic per message besides that.
+`BallTreeDensity(d)` downloads the reference's arrays when the host wants them.
+"""
+function Base.:*(trees::Vector{DeviceDensity}; addEntropy::Bool=true, seed::Union{Nothing,UInt64}=nothing)
+  h = Ref{Ptr{Cvoid}}(C_NULL)
+  handles = Ptr{Cvoid}[t.handle for t in trees]
+  s = seed === nothing ? rand(UInt64) : seed
+  GC.@preserve trees handles begin
+    check(ccall((:kdehip_mul_device, libkdehip), Cint,
+                (Ref{Ptr{Cvoid}}, Cint, Ptr{Ptr{Cvoid}}, UInt64, Cint, Ptr{Float64}, Ptr{Int32}),
+                h, length(trees), handles, s, addEntropy ? 1 : 0, C_NULL, C_NULL))
+  end
+  return DeviceDensity(h[])
+end
+Base.:*(p::DeviceDensity, q::DeviceDensity) = *([p; q])
+
+"""
+    BallTreeDensity(d::DeviceDensity)
+
+The reference's struct for a density that was BUILT on the device (`*` above): `kdehip_density_download` returns the
+twelve arrays of `BallTreeDensity` / `BallTree` (src/BallTreeDensity01.jl:11-24, src/BallTree01.jl:10-28).
+"""
+function KDE.BallTreeDensity(d::DeviceDensity)
+  N, D = d.npts, d.ndim
+  centers, ranges, means, bandwidth = zeros(2N * D), zeros(2N * D), zeros(2N * D), zeros(2N * D)
+  bwmin, bwmax, weights = zeros(N * D), zeros(N * D), zeros(2N)
+  left, right, lowest, highest, perm = zeros(Int, 2N), zeros(Int, 2N), zeros(Int, 2N), zeros(Int, 2N), zeros(Int, 2N)
+  check(ccall((:kdehip_density_download, libkdehip), Cint,
+              (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64},
+               Ptr{Int64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+              d.handle, centers, ranges, weights, left, right, lowest, highest, perm, means, bandwidth, bwmin, bwmax, C_NULL))
+  # the field order of the reference's constructors (src/BallTree01.jl:453-457, src/BallTreeDensity01.jl:225-226)
+  bt = KDE.BallTree(D, N, centers, ranges, weights, left, right, lowest, highest, perm, 0, KDE.swapDensity!,
+                    KDE.calcStatsDensity!, [])
+  bd = KDE.BallTreeDensity(bt, KDE.GaussianKer, 0, means, bandwidth, bwmin, bwmax, bt.calcStatsHandle, bt.swapHandle)
+  bd.bt.data = bd   # the circular reference the reference keeps "for emulating polymorphism"
+  return bd
 end
 
 function prodAppxMSGibbsS(npd0, trees::Vector{DeviceDensity}, anFcns, anParams;
@@ -260,6 +335,7 @@ own explicit-bandwidth constructor builds the density.
 """
 function kde!(points::AbstractMatrix{Float64}; device::Int=0)
   D, N = size(points)
+  (N < 2 || D > 8) && return reference_kde_auto(points)   # (the library's limits: the reference path)
   bw = zeros(D)
   nev = Ref{Int32}(0)
   pts = Matrix{Float64}(points)
@@ -289,6 +365,16 @@ function enable!()
   invoke_original_prod(args...; kw...) = Base.invoke_in_world(mp.primary_world, origprod, args...; kw...)
   ORIGINAL_GIBBS1[] = invoke_original
   ORIGINAL_PROD[] = invoke_original_prod
+  # kde!(points, addop, diffop) (src/KDE01.jl:3-27) and the matrix / density forms of evaluateDualTree
+  # (src/DualTree01.jl:370-421): found by their signatures, invoked in the world they were defined in
+  origkde = KDE.kde!
+  mk = which(origkde, Tuple{Matrix{Float64},Tuple,Tuple})
+  ORIGINAL_KDE_AUTO[] = (args...) -> Base.invoke_in_world(mk.primary_world, origkde, args...)
+  origeval = KDE.evaluateDualTree
+  me = which(origeval, Tuple{BallTreeDensity,Matrix{Float64},Bool,Float64,Tuple,Tuple})
+  ORIGINAL_EVAL[] = (args...) -> Base.invoke_in_world(me.primary_world, origeval, args...)
+  mb = which(origeval, Tuple{BallTreeDensity,BallTreeDensity,Bool,Float64,Tuple,Tuple})
+  ORIGINAL_EVAL_BD[] = (args...) -> Base.invoke_in_world(mb.primary_world, origeval, args...)
   @eval KDE function gibbs1(Ndens::Int, trees::Array{BallTreeDensity,1}, Np::Int, Niter::Int,
                             pts::Array{Float64,1}, ind::Array{Int}, randU::Array{Float64,1},
                             randN::Array{Float64,1}; addop=(+,), diffop=(-,), getMu=(getEuclidMu,),
@@ -318,7 +404,42 @@ function enable!()
                                Np=Np, maxNp=maxNp, Nlevels=Nlevels, randU=randU, randN=randN,
                                partialDimMask=partialDimMask)
   end
+  # kde!(points) -- the second half of `*` (src/MSGibbs01.jl:725) and of every README usage: the LOOCV bandwidth search
+  # on the GPU (kdehip_auto_bandwidth), then the reference's own explicit-bandwidth constructor
+  @eval KDE function kde!(points::A, addop::Tuple=(+,), diffop::Tuple=(-,)) where {A <: AbstractArray{Float64,2}}
+    if $(isEuclidOps)(addop, diffop) && size(points, 2) >= 2 && size(points, 1) <= 8
+      return $(kde!)(points)
+    end
+    return $(reference_kde_auto)(points, addop, diffop)
+  end
+  # evaluateDualTree(bd, pos::Matrix) / bd(pos) / evaluateDualTree(bd, pos::BallTreeDensity): direct evaluation on the GPU
+  # while the reference's own default FORCE_EVAL_DIRECT = true stands and the operators are Euclidean
+  @eval KDE function evaluateDualTree(bd::BallTreeDensity, pos::Array{Float64,2}, lvFlag::Bool=false, errTol::Float64=1e-3,
+                                      addop=(+,), diffop=(-,))
+    if $(isEuclidOps)(addop, diffop) && $(directEval)() && bd.bt.dims <= 8 && bd.multibandwidth == 0
+      return $(evaluateDualTree)(bd, pos, lvFlag)
+    end
+    return $(reference_evaluateDualTree)(bd, pos, lvFlag, errTol, addop, diffop)
+  end
+  @eval KDE function evaluateDualTree(bd::BallTreeDensity, pos::BallTreeDensity, lvFlag::Bool=false, errTol::Float64=1e-3,
+                                      addop=(+,), diffop=(-,))
+    if $(isEuclidOps)(addop, diffop) && $(directEval)() && bd.bt.dims <= 8 && bd.multibandwidth == 0
+      bd.bt.dims == pos.bt.dims || error("bd and pos must have the same dimension")
+      return $(evaluateDualTree)(bd, getPoints(pos), lvFlag)
+    end
+    return $(reference_evaluateDualTree_bd)(bd, pos, lvFlag, errTol, addop, diffop)
+  end
   nothing
 end
+
+"""
+    overridden_methods()
+
+What `enable!()` replaces in `KernelDensityEstimate` (pinned by tests/test_julia_shim_syntax.py): after it, an unchanged
+caller of `*` runs product, bandwidth search and evaluation on the GPU; the trees are still built by the reference's own
+`kde!(points, bw)`.
+"""
+overridden_methods() = ["gibbs1", "prodAppxMSGibbsS", "kde!", "evaluateDualTree(bd, pos::Array{Float64,2})",
+                        "evaluateDualTree(bd, pos::BallTreeDensity)"]
 
 end # module

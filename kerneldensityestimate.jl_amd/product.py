@@ -198,17 +198,53 @@ class MultiProductPlan:
 
 
 class DeviceDensity:
-    """A BallTreeDensity uploaded ONCE and kept in HBM (kdehip_density_upload): products of such densities are laid
-    out by the GPU and move nothing but a few KB of descriptors over PCIe (`prodAppxMSGibbsS_device`)."""
+    """A BallTreeDensity kept in HBM: uploaded ONCE (kdehip_density_upload), or built there from a product that never left
+    the device (`from_device_points`, `mul_device`).  Products of such densities are laid out by the GPU and move nothing
+    but a few KB of descriptors over PCIe (`prodAppxMSGibbsS_device`)."""
 
-    def __init__(self, tree: BallTreeDensity, device=0):
-        h = C.c_void_p()
-        cs = tree._cstruct()
-        _lib.check(_lib.lib.kdehip_density_upload(C.byref(h), C.byref(cs), int(device)))
+    def __init__(self, tree: BallTreeDensity = None, device=0, _handle=None):
+        if _handle is None:
+            h = C.c_void_p()
+            cs = tree._cstruct()
+            _lib.check(_lib.lib.kdehip_density_upload(C.byref(h), C.byref(cs), int(device)))
+        else:
+            h = _handle
         self._h = h
         self.device = int(device)
         self.num_points = int(_lib.lib.kdehip_density_npts(h))
         self.dims = int(_lib.lib.kdehip_density_ndim(h))
+        self.bw = None      # LOOCV bandwidth (standard deviations) of a density built on the device
+        self.nevals = None  # likelihood evaluations of that search
+
+    @classmethod
+    def from_device_points(cls, d_points, D, N, device=0, stream=None):
+        """`kde!(points)` (reference src/KDE01.jl:3-27) of a D x N column-major matrix that lives in HBM (a torch tensor or
+        an address; `stream` = the stream that produced it): LOOCV bandwidth search on the device matrix, ball tree from one
+        copy that comes down meanwhile, the density's block straight back up (kdehip_density_from_device_points)."""
+        h = C.c_void_p()
+        bw = np.empty(int(D))
+        ne = C.c_int32(0)
+        _lib.check(_lib.lib.kdehip_density_from_device_points(C.byref(h), ProductPlan._addr(d_points), int(D), int(N),
+                                                              int(device), ProductPlan._addr(stream), ptr(bw, f64p),
+                                                              C.byref(ne)))
+        out = cls(device=device, _handle=h)
+        out.bw, out.nevals = bw, int(ne.value)
+        return out
+
+    def download(self) -> BallTreeDensity:
+        """The reference's arrays of a density that was built on the device (kdehip_density_download)."""
+        from .density import _empty_density
+        i64p = _lib.i64p
+        bd = _empty_density(self.dims, self.num_points)
+        bt = bd.bt
+        _lib.check(_lib.lib.kdehip_density_download(
+            self._h, ptr(bt.centers, f64p), ptr(bt.ranges, f64p), ptr(bt.weights, f64p), ptr(bt.left_child, i64p),
+            ptr(bt.right_child, i64p), ptr(bt.lowest_leaf, i64p), ptr(bt.highest_leaf, i64p), ptr(bt.permutation, i64p),
+            ptr(bd.means, f64p), ptr(bd.bandwidth, f64p), ptr(bd.bandwidthMin, f64p), ptr(bd.bandwidthMax, f64p), None))
+        return bd
+
+    def __mul__(self, other):
+        return mul_device([self, other])
 
     def close(self):
         if getattr(self, "_h", None):
@@ -226,6 +262,70 @@ class DeviceDensity:
 
     def __exit__(self, *exc):
         self.close()
+
+
+def mul_device(trees, *, addEntropy=True, seed=None) -> DeviceDensity:
+    """`*(trees; addEntropy)` (reference src/MSGibbs01.jl:707-726) on `DeviceDensity` handles, result in HBM: product with
+    Niter = 5 and Np = round(mean(Npts)), then `kde!(pGM)` -- the sample matrix never leaves the device
+    (kdehip_mul_device).  Same numbers as `mul(host trees, seed=seed)`."""
+    trees = list(trees)
+    if seed is None:
+        seed = int.from_bytes(os.urandom(8), "little")
+    M = len(trees)
+    arr = (C.c_void_p * M)(*[t._h for t in trees])
+    h = C.c_void_p()
+    bw = np.empty(trees[0].dims)
+    ne = C.c_int32(0)
+    _lib.check(_lib.lib.kdehip_mul_device(C.byref(h), M, arr, C.c_uint64(int(seed) & (2 ** 64 - 1)), int(bool(addEntropy)),
+                                          ptr(bw, f64p), C.byref(ne)))
+    out = DeviceDensity(device=trees[0].device, _handle=h)
+    out.bw, out.nevals = bw, int(ne.value)
+    return out
+
+
+class ProductBatch:
+    """The argument block of one `kdehip_prod_philox_batch` call, built once: a host that issues the same set of products
+    sweep after sweep (only seeds / sample offsets change) does not pay the Python-side marshalling per call."""
+
+    def __init__(self, products, precision=64):
+        n = len(products)
+        self.n = n
+        self.precision = int(precision)
+        self.items = (_lib.CBatchItem * max(1, n))()
+        self._keep = []
+        for k, pr in enumerate(products):
+            trees = list(pr["trees"])
+            M = len(trees)
+            arr = (C.c_void_p * M)(*[t._h for t in trees])
+            mask = _mask_array(pr.get("partialDimMask"), M, trees[0].dims)
+            self._keep.append((arr, mask, trees, pr["d_points"], pr["d_indices"], pr.get("d_labels")))
+            it = self.items[k]
+            it.Ndens, it.Niter = M, int(pr.get("Niter", 3))
+            it.trees = arr
+            it.Np = int(pr["Np"])
+            it.seed = int(pr.get("seed", 0)) & (2 ** 64 - 1)
+            it.sample_offset = int(pr.get("sample_offset", 0))
+            it.addEntropy = int(bool(pr.get("addEntropy", True)))
+            it.partialDimMask = None if mask is None else ptr(mask, u8p)
+            it.d_points = ProductPlan._addr(pr["d_points"])
+            it.d_indices = ProductPlan._addr(pr["d_indices"])
+            it.d_labels = ProductPlan._addr(pr.get("d_labels"))
+
+    def enqueue(self, stream=None, sample_offset=None):
+        """one library call for all products (enqueue only); `sample_offset` (optional) replaces every product's"""
+        if sample_offset is not None:
+            for k in range(self.n):
+                self.items[k].sample_offset = int(sample_offset)
+        _lib.check(_lib.lib.kdehip_prod_philox_batch(self.n, self.items, self.precision, ProductPlan._addr(stream)))
+
+
+def prodAppxMSGibbsS_batch(products, *, precision=64, stream=None):
+    """Many `prodAppxMSGibbsS` calls on `DeviceDensity` inputs in ONE library call (kdehip_prod_philox_batch): one device
+    block, one gather launch, and one sampling launch per (dimension count, density count) group of fp64 products of 2..4
+    densities.  `products`: dicts with the keywords of `prodAppxMSGibbsS_device` (trees, d_points, d_indices, Np, and
+    optionally Niter=3, seed=0, sample_offset=0, addEntropy=True, partialDimMask, d_labels).  Every product gets the
+    numbers the single call would give it.  Enqueues on `stream` and returns."""
+    ProductBatch(products, precision).enqueue(stream)
 
 
 def prodAppxMSGibbsS_device(trees, d_points, d_indices, *, Np, Niter=3, seed=0, sample_offset=0, addEntropy=True,
@@ -342,6 +442,8 @@ def prodAppxMSGibbsS(npd0, trees, anFcns=None, anParams=None, *deprecated_niter,
     `maxNp` / `Nlevels` only size the reference's default random arrays (:659-662; `gibbs1` recomputes the level
     count from the trees, :568) and are accepted and ignored; a fifth positional argument is the deprecated
     positional `Niter` (:632-643).
+    The returned matrices are column-major (Fortran-ordered) VIEWS of the flat result buffers, like Julia's: pass them
+    through `np.ascontiguousarray` before handing their `.ctypes` pointer to C code that expects row-major data.
     """
     if deprecated_niter:
         if len(deprecated_niter) > 1:

@@ -154,11 +154,11 @@ def test_sampler_profile_counts_the_launches_it_brackets():
     lib.kdehip_profile_sampler(1)
     for c in range(3):
         kdehip.prodAppxMSGibbsS_device(dd, P, I, Np=Np, Niter=2, seed=c)
-    assert lib.kdehip_profile_sampler_read(0, C.byref(ms), C.byref(n)) == 0
+    assert lib.kdehip_profile_sampler_read(0, None, C.byref(ms), C.byref(n)) == 0
     assert n.value == 3 and 0.0 < ms.value < 100.0
     lib.kdehip_profile_sampler(0)   # (off, and the statistics start over)
     kdehip.prodAppxMSGibbsS_device(dd, P, I, Np=Np, Niter=2, seed=9)
-    assert lib.kdehip_profile_sampler_read(0, C.byref(ms), C.byref(n)) == 0
+    assert lib.kdehip_profile_sampler_read(0, None, C.byref(ms), C.byref(n)) == 0
     assert n.value == 0 and ms.value == 0.0
     ref_p, ref_i = kdehip.prodAppxMSGibbsS(None, trees, None, None, Niter=2, Np=Np, seed=9)
     assert np.array_equal(P.cpu().numpy().reshape(Np, D).T, ref_p)

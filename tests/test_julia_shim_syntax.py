@@ -206,3 +206,28 @@ def test_enable_routes_default_rng_callers_to_the_device_rng():
     assert re.search(r"randU\s*=\s*nothing", override) and re.search(r"randN\s*=\s*nothing", override)
     front = code[code.index("function prodAppxMSGibbsS("):code.index("function enable!()")]
     assert ":kdehip_prod_philox" in front and "gibbs1(Ndens, trees, Np, Niter, points, indices, randU, randN" in front
+
+
+def test_enable_overrides_the_whole_star_operator():
+    """The reference's `*` is product THEN `kde!(pGM)` (src/MSGibbs01.jl:724-725 -> src/KDE01.jl:3-27 ->
+    src/CrossValidation.jl:110-120): enable!() must replace both halves, and `evaluateDualTree` (src/DualTree01.jl:370-421),
+    or an unchanged caller gets a GPU product followed by the reference's CPU bandwidth search.  The list of overridden
+    methods is pinned here."""
+    code = strip_code(open(SHIM).read())
+    enable = code[code.index("function enable!()"):code.index("overridden_methods() =")]
+    installed = [(m.group(1), enable[m.end():m.end() + 160]) for m in re.finditer(r"@eval KDE function\s+([A-Za-z_!0-9]+)\(", enable)]
+    names = [n for n, _ in installed]
+    assert names == ["gibbs1", "prodAppxMSGibbsS", "kde!", "evaluateDualTree", "evaluateDualTree"], names
+    sig = dict((n + str(k), a) for k, (n, a) in enumerate(installed))
+    assert "points::A" in sig["kde!2"] and "addop::Tuple" in sig["kde!2"] and "diffop::Tuple" in sig["kde!2"]
+    assert "pos::Array{Float64,2}" in sig["evaluateDualTree3"] and "pos::BallTreeDensity" in sig["evaluateDualTree4"]
+    # each override keeps the reference reachable: non-Euclidean operators, FORCE_EVAL_DIRECT = false, sizes beyond the limits
+    for ref in ("reference_kde_auto", "reference_evaluateDualTree", "reference_evaluateDualTree_bd", "invoke_original"):
+        assert ref in enable, ref
+    assert "directEval" in enable and "isEuclidOps" in enable
+    # ... through the world age in which the reference's methods were defined
+    assert enable.count("Base.invoke_in_world") == 5
+    # the GPU entries the overrides land on
+    body = code[:code.index("function enable!()")]
+    for sym in (":kdehip_auto_bandwidth", ":kdehip_evaluate", ":kdehip_mul_device", ":kdehip_density_download"):
+        assert sym in body, sym
