@@ -375,6 +375,19 @@ def inproc_multi(args):
         mp.sample_philox_device(Np_total, Niter, seed, (args.warmup + i) * Np_total, True, Ps, Is, handles)
     sync_all()
     elapsed = time.perf_counter() - t0
+    # per device: the duration of its sampling launch and when its slice had arrived everywhere, relative to the first device
+    # to get there (a pass of its own: the timing events stay out of `value`) -- what the first run on N real GPUs needs to
+    # tell a slow kernel from a straggling device or link
+    kdehip._clib.kdehip_profile_sampler(1)
+    kms, dms = [], []
+    for i in range(min(args.steps, 20)):
+        mp.sample_philox_device(Np_total, Niter, seed, (args.warmup + args.steps + i) * Np_total, True, Ps, Is, handles)
+        k, d = mp.timing()
+        kms.append(k)
+        dms.append(d)
+    sync_all()
+    kdehip._clib.kdehip_profile_sampler(0)
+    kms, dms = np.array(kms), np.array(dms)
     # every device must hold the same complete result
     ref_p, ref_i = Ps[0].cpu(), Is[0].cpu()
     same = all(torch.equal(ref_p, P.cpu()) and torch.equal(ref_i, I.cpu()) for P, I in zip(Ps[1:], Is[1:]))
@@ -387,6 +400,12 @@ def inproc_multi(args):
                    "parallelism": f"ONE process, {G} device(s) through kdehip_product_multi_*; all-gather = kernel-epilogue peer stores",
                    "aliased_devices": alias, "copy_engine_transfers_per_device_per_product": mp.transfers_per_product},
         "all_devices_hold_the_same_result": bool(same),
+        "per_device": {"kernel_ms": [float(x) for x in kms.mean(axis=0)], "done_after_first_ms": [float(x) for x in dms.mean(axis=0)],
+                       "kernel_ms_skew": float((kms.max(axis=1) - kms.min(axis=1)).mean()),
+                       "done_skew_ms": float((dms.max(axis=1) - dms.min(axis=1)).mean()),
+                       "what": "mean over products of a repeat pass with timing events around every device's sampling launch "
+                               "(kdehip_product_multi_timing): kernel duration per device; host time at which a device's slice "
+                               "had arrived on every device, relative to the first"},
     }
     mp.close()
     print(json.dumps(out), flush=True)

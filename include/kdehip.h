@@ -183,7 +183,18 @@ const char *kdehip_product_kernel_name(const kdehip_product *plan, int64_t Np);
  * starts only after the work already queued on EVERY streams[h] is over (it overwrites their arrays: consumers of
  * the previous product on those streams are safe), and each stream continues only once the slices of all other
  * devices have arrived.  Topologies without peer access fall back to hipMemcpyPeerAsync, one copy per array and
- * destination (kdehip_product_multi_transfers_per_product tells: 0 = fused). */
+ * destination (kdehip_product_multi_transfers_per_product tells: 0 = fused).
+ * VISIBILITY of the peer-written slices: the stores are plain global stores of the producing kernel; they are complete
+ * and visible to device h when work on streams[h] that was enqueued AFTER this call starts (the call makes streams[h]
+ * wait for every device's `done` event, and a kernel that starts behind that wait begins with a system-scope acquire
+ * of its caches).  A consumer that is ALREADY RUNNING on device h while the product is sampled -- a persistent kernel
+ * polling the arrays -- has no such acquire and may read stale lines from its L2: consume the result from work
+ * enqueued behind the call.
+ * ALLOCATION of d_points[h] / d_indices[h]: plain hipMalloc memory is peer-mapped by hipDeviceEnablePeerAccess (done at
+ * create).  Arrays from a stream-ordered pool (hipMallocAsync) or from virtual-memory mappings are reachable from a
+ * peer only if the pool / mapping grants that device access (hipMemPoolSetAccess / hipMemSetAccess); the call looks at
+ * every destination once per product and takes the copy path for anything it cannot show reachable
+ * (KDEHIP_PEER_STORES=0 forces the copy path, =1 skips the look-up). */
 typedef struct kdehip_product_multi kdehip_product_multi;
 int kdehip_product_multi_create(kdehip_product_multi **out, int Ndens, const kdehip_density *trees, int ndims,
                                 const uint8_t *partialDimMask, int precision, int first_device, int ngpus);

@@ -106,6 +106,7 @@ SIGNATURES = {
     "kdehip_density_set_bandwidth": (C.c_int, [C.c_int64, C.c_int64, f64p, C.c_int64, f64p, i64p, i64p, f64p, f64p, f64p, f64p]),
     "kdehip_profile_sampler": (None, [C.c_int]),
     "kdehip_profile_sampler_read": (C.c_int, [C.c_int, C.c_void_p, f64p, i64p]),
+    "kdehip_product_multi_timing": (C.c_int, [C.c_void_p, f64p, f64p]),
     "kdehip_density_from_device_points": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_int64, C.c_int64, C.c_int,
                                                     C.c_void_p, f64p, i32p]),
     "kdehip_mul_device": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p), C.c_uint64, C.c_int, f64p, i32p]),

@@ -1035,8 +1035,17 @@ __device__ __forceinline__ void stage_tile(const unsigned char *__restrict__ src
   const __amdgpu_buffer_rsrc_t rsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(src), 0, bytes, 0x00020000);
   const int pieces = bytes >> 10;
+  // (the piece offset goes through readfirstlane: strength reduction otherwise keeps it in a vector register, and the
+  // scalar-offset operand of the load is then fed by a waterfall loop -- 18 instructions per 1-KiB piece instead of 6)
+#ifdef KDEHIP_X_OLDSTAGE  // (A/B only: the round-3 form)
   for (int c = wave; c < pieces; c += WAVES)
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LdsVoidPtr)(dst + (c << 10)), 16, lane << 4, c << 10, 0, 0);
+#else
+  for (int c = wave; c < pieces; c += WAVES) {
+    const int off = __builtin_amdgcn_readfirstlane(c << 10);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LdsVoidPtr)(dst + off), 16, lane << 4, off, 0, 0);
+  }
+#endif
 }
 
 

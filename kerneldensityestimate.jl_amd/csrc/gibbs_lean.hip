@@ -663,6 +663,13 @@ int KDEHIP_CAT(launch_lean_batch_d, KDEHIP_DIM)(int M, const PlanDev &plan, cons
 }
 #endif
 
+#if defined(KDEHIP_LEAN_DEV) && !defined(KDEHIP_LEAN_HI) && !defined(KDEHIP_LEAN_F32)
+// (a development build replaces this translation unit with ONE instantiation: no batched kernels)
+int KDEHIP_CAT(launch_lean_batch_d, KDEHIP_DIM)(int, const PlanDev &, const RunArgs &, void *) {
+  return set_error(KDEHIP_ERR_UNSUPPORTED, "development library: no batched kernels");
+}
+#endif
+
 #if defined(KDEHIP_LEAN_HI)
 #define KDEHIP_LEAN_ENTRY launch_lean_hi_d
 #elif defined(KDEHIP_LEAN_F32)

@@ -1185,6 +1185,8 @@ struct kdehip_product_multi {
   std::vector<hipEvent_t> ready;  // per device: the work queued on its stream before this call is over (its arrays may be overwritten)
   bool peer_stores = true;        // every device can store into every other device's memory (else: peer copies)
   int last_transfers = -1;        // copy-engine transfers per device of the last product (-1: none yet)
+  std::vector<hipEvent_t> t_begin, t_end;  // kdehip_profile_sampler: around device g's sampling launch (created on demand)
+  bool timed = false;             // the last product was bracketed
 };
 
 namespace {
@@ -1273,6 +1275,8 @@ void kdehip_product_multi_destroy(kdehip_product_multi *mp) {
       (void)hipDeviceSynchronize();
       (void)hipEventDestroy(mp->done[g]);
       if (g < mp->ready.size()) (void)hipEventDestroy(mp->ready[g]);
+      if (g < mp->t_begin.size()) (void)hipEventDestroy(mp->t_begin[g]);
+      if (g < mp->t_end.size()) (void)hipEventDestroy(mp->t_end[g]);
     }
   for (kdehip_product *p : mp->plans) kdehip_product_destroy(p);
   delete mp;
@@ -1309,6 +1313,19 @@ int kdehip_product_multi_sample_philox(kdehip_product_multi *mp, int64_t Np, int
         peer_stores = false;
     }
   mp->last_transfers = (peer_stores || G == 1) ? 0 : 2 * (G - 1);
+  // kdehip_profile_sampler: every device's sampling launch between a pair of timing events of its own (kdehip_product_multi_timing)
+  const bool timed = g_profile_sampler.load(std::memory_order_relaxed) != 0;
+  if (timed && mp->t_begin.empty())
+    for (int g = 0; g < G; ++g) {
+      int rc = guard.enter(phys(mp->first_device + g));
+      if (rc != KDEHIP_OK) return rc;
+      hipEvent_t a = nullptr, b = nullptr;
+      KDEHIP_CHECK(hipEventCreate(&a));
+      mp->t_begin.push_back(a);
+      KDEHIP_CHECK(hipEventCreate(&b));
+      mp->t_end.push_back(b);
+    }
+  mp->timed = timed && static_cast<int>(mp->t_end.size()) == G;
   // (1) Device g is about to write into EVERY device's arrays: whatever is queued on the other devices' streams --
   // consumers of the previous product, typically -- must be over first (write after read).
   if (G > 1) {
@@ -1339,7 +1356,8 @@ int kdehip_product_multi_sample_philox(kdehip_product_multi *mp, int64_t Np, int
         }
       // global sample index = sample_offset + lo + s: the result does not depend on the number of devices
       rc = enqueue_philox(mp->plans[g], hi - lo, Niter, seed, sample_offset + lo, addEntropy, d_points[g] + lo * D,
-                          d_indices[g] + lo * M, nullptr, st, /*private_plan=*/false, &peers);
+                          d_indices[g] + lo * M, nullptr, st, /*private_plan=*/false, &peers, nullptr, nullptr,
+                          mp->timed ? mp->t_begin[g] : nullptr, mp->timed ? mp->t_end[g] : nullptr);
       if (rc != KDEHIP_OK) return rc;
       mp->plans[g]->async_pending.store(true);
       if (!peer_stores)
@@ -1360,6 +1378,45 @@ int kdehip_product_multi_sample_philox(kdehip_product_multi *mp, int64_t Np, int
     hipStream_t st = stream_of(h);
     for (int g = 0; g < G; ++g)
       if (g != h) KDEHIP_CHECK(hipStreamWaitEvent(st, mp->done[g], 0));
+  }
+  return KDEHIP_OK;
+}
+
+// Diagnostic (kdehip_profile_sampler on): of the LAST product, per device, the duration of its sampling launch and the
+// host time at which its slice had arrived everywhere (`done` event seen complete), relative to the first device to get
+// there -- what tells a straggling device or link from a slow kernel when the N > 1 path is first run on hardware.
+int kdehip_product_multi_timing(kdehip_product_multi *mp, double *kernel_ms, double *done_ms) {
+  if (!mp || !kernel_ms || !done_ms) return set_error(KDEHIP_ERR_ARG, "null argument");
+  if (!mp->timed) return set_error(KDEHIP_ERR_ARG, "kdehip_product_multi_timing: the last product was not timed (kdehip_profile_sampler(1) first)");
+  const int G = mp->ngpus;
+  DeviceGuard guard;
+  std::vector<char> seen(G, 0);
+  std::vector<double> at(G, 0.0);
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int left = G; left > 0;)
+    for (int g = 0; g < G; ++g) {
+      if (seen[g]) continue;
+      const int rc = guard.enter(phys(mp->first_device + g));
+      if (rc != KDEHIP_OK) return rc;
+      const hipError_t q = hipEventQuery(mp->done[g]);
+      if (q == hipSuccess) {
+        at[g] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        seen[g] = 1;
+        --left;
+      } else if (q != hipErrorNotReady) {
+        return set_error(KDEHIP_ERR_HIP, std::string("kdehip_product_multi_timing: ") + hipGetErrorString(q));
+      }
+    }
+  (void)hipGetLastError();
+  double first = at[0];
+  for (int g = 1; g < G; ++g) if (at[g] < first) first = at[g];
+  for (int g = 0; g < G; ++g) {
+    const int rc = guard.enter(phys(mp->first_device + g));
+    if (rc != KDEHIP_OK) return rc;
+    float ms = 0.0f;
+    KDEHIP_CHECK(hipEventElapsedTime(&ms, mp->t_begin[g], mp->t_end[g]));
+    kernel_ms[g] = ms;
+    done_ms[g] = at[g] - first;
   }
   return KDEHIP_OK;
 }

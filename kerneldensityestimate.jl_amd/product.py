@@ -185,6 +185,13 @@ class MultiProductPlan:
         (stores to the peer-mapped arrays of the other devices)"""
         return int(_lib.lib.kdehip_product_multi_transfers_per_product(self._h))
 
+    def timing(self):
+        """(kernel_ms[g], done_ms[g]) of the last product, with `kdehip_profile_sampler(1)` on: duration of every device's
+        sampling launch, and when its slice had arrived everywhere relative to the first device (kdehip_product_multi_timing)"""
+        k, d = np.zeros(self.ngpus), np.zeros(self.ngpus)
+        _lib.check(_lib.lib.kdehip_product_multi_timing(self._h, ptr(k, f64p), ptr(d, f64p)))
+        return k, d
+
     def sample_philox_device(self, Np, Niter, seed, sample_offset, addEntropy, d_points, d_indices, streams=None):
         """d_points / d_indices: one device array (torch tensor or address) per GPU, each holding the COMPLETE result
         afterwards (the all-gather is part of the run); enqueue only."""

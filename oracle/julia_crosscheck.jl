@@ -4,7 +4,7 @@
 # KernelDensityEstimate.jl installed runs, from the repo root:
 #
 #     python tests/golden/make_gibbs_kat.py --dump-text /tmp/kat      # inputs + the oracle's outputs, as text
-#     julia oracle/julia_crosscheck.jl /tmp/kat/c1 /tmp/kat/c2 /tmp/kat/d6
+#     julia oracle/julia_crosscheck.jl /tmp/kat/c1 /tmp/kat/c2 /tmp/kat/d6 /tmp/kat/c3      # c3 = the headline shape
 #
 # Each directory holds meta.txt (D M N Np Niter), points_j.txt (D x N), bw_j.txt (D), randU.txt, randN.txt and the
 # oracle's indices.txt (M x Np) and pGM.txt (D x Np).  The same random streams are handed to the reference through

@@ -68,15 +68,16 @@ with open(os.path.join(ROOT, "profiles", f"{tag}_valu_mix.md"), "w") as f:
     f.write(f"VALU issue cycles per chain: {cycles_per_chain:.0f}; with {chains_per_simd:g} chains per SIMD the vector pipe alone "
             f"needs {out['valu_floor_ms']:.3f} ms per launch at that clock.\n\n")
     f.write("other counters per chain: " + ", ".join(f"{k}={v:.0f}" for k, v in sorted(per.items())) + "\n")
-# bench.py reads ONE file: attach the floor to the committed profile of the same workload
-tl = os.path.join(ROOT, "profiles", "traffic_latest.json")
-try:
-    t = json.load(open(tl))
-    if t.get("workload") == line["config"]["workload"].split(":")[0]:
-        t["valu_floor"] = {"cycles_per_chain": cycles_per_chain, "clock_ghz": ghz, "simds": simds,
-                           "mix_per_chain": out["mix_per_chain"], "issue_cost_cycles": COST,
-                           "source": f"profiles/{tag}_valu_mix.json + profiles/r02_valu_rates.txt"}
-        json.dump(t, open(tl, "w"), indent=1)
-except (OSError, ValueError, KeyError):
-    pass
-print(json.dumps(out, indent=1))
+# bench.py reads the committed profile of its workload (profiles/traffic_<config>.json): attach the floor to it
+wl = line["config"]["workload"].split(":")[0]
+for name in [f"traffic_{wl}.json"] + (["traffic_latest.json"] if wl == "c3" else []):
+    tl = os.path.join(ROOT, "profiles", name)
+    try:
+        t = json.load(open(tl))
+        if t.get("workload") == wl:
+            t["valu_floor"] = {"cycles_per_chain": cycles_per_chain, "clock_ghz": ghz, "simds": simds,
+                               "mix_per_chain": out["mix_per_chain"], "issue_cost_cycles": COST,
+                               "source": f"profiles/{tag}_valu_mix.json + profiles/r02_valu_rates.txt"}
+            json.dump(t, open(tl, "w"), indent=1)
+    except (OSError, ValueError, KeyError):
+        pass

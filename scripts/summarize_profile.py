@@ -112,19 +112,29 @@ def main():
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     with open(os.path.join(ROOT, "profiles", f"{tag}_rocprof_summary.json"), "w") as f:
         json.dump(out, f, indent=1)
-    if "hbm_bytes_per_launch" in out and workload == "c3":  # bench.py's default workload is what the file describes
-        tl = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        keep = {}
-        try:  # the vector-pipe floor (scripts/summarize_mix.py) stays attached until it is re-measured
-            prev = json.load(open(tl))
-            if prev.get("workload") == workload and "valu_floor" in prev:
-                keep["valu_floor"] = prev["valu_floor"]
-        except (OSError, ValueError):
-            pass
-        with open(tl, "w") as f:
-            json.dump({"workload": workload, "tag": tag, "hbm_bytes_per_launch": out["hbm_bytes_per_launch"],
-                       "raw_bytes": out["hbm_bytes_per_launch_raw"], "fetch_calibration": calib,
-                       "issue": out.get("issue"), **keep}, f, indent=1)
+    if "hbm_bytes_per_launch" in out:  # what bench.py --config <workload> replays next to its live numbers
+        import datetime
+        import subprocess
+        try:
+            commit = subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
+        except OSError:
+            commit = ""
+        names = [f"traffic_{workload}.json"] + (["traffic_latest.json"] if workload == "c3" else [])
+        for name in names:
+            tl = os.path.join(ROOT, "profiles", name)
+            keep = {}
+            try:  # the vector-pipe floor (scripts/summarize_mix.py) stays attached until it is re-measured
+                prev = json.load(open(tl))
+                if prev.get("workload") == workload and "valu_floor" in prev:
+                    keep["valu_floor"] = prev["valu_floor"]
+            except (OSError, ValueError):
+                pass
+            with open(tl, "w") as f:
+                json.dump({"workload": workload, "tag": tag, "commit": commit, "date": datetime.date.today().isoformat(),
+                           "kernel": out["kernel"], "kernel_avg_ns_under_rocprof": out["avg_ns"],
+                           "hbm_bytes_per_launch": out["hbm_bytes_per_launch"],
+                           "raw_bytes": out["hbm_bytes_per_launch_raw"], "fetch_calibration": calib,
+                           "issue": out.get("issue"), **keep}, f, indent=1)
     lines = [f"# rocprofv3 summary `{tag}` ({workload})", "",
              "Command (on the MI355X box): `scripts/profile_gpu.sh " + tag + "` = `rocprofv3 --kernel-trace --stats -- python3 bench.py "
              "--steps 20 --warmup 3 --no-cpu-baseline` plus separate `--pmc` passes.", "",

@@ -68,6 +68,9 @@ if __name__ == "__main__":
         dump_text("c1", 1, 2, 100, 100, 5, os.path.join(sys.argv[2], "c1"))
         dump_text("c2", 2, 3, 200, 256, 5, os.path.join(sys.argv[2], "c2"))
         dump_text("d6", 6, 4, 300, 64, 3, os.path.join(sys.argv[2], "d6"))
+        # BASELINE config 3's full shape (6-D, 4 x 1000 points, Niter 10), 64 chains: the headline configuration is the
+        # first thing a maintainer with Julia checks (1.2 MB of text)
+        dump_text("c3", 6, 4, 1000, 64, 10, os.path.join(sys.argv[2], "c3"))
         sys.exit(0)
     make("c1", 1, 2, 100, 100, 5)   # BASELINE config 1
     make("c2", 2, 3, 200, 256, 5)   # BASELINE config 2

@@ -148,7 +148,64 @@ for G in (2, 3, 4, 8):
             assert np.array_equal(kept[k][1].cpu().numpy().reshape(Np, M).T, one[1]), (G, k, "consumer of product 1")
             assert np.array_equal(Ps[k].cpu().numpy().reshape(Np, D).T, other[0]), (G, k)
             assert np.array_equal(Is[k].cpu().numpy().reshape(Np, M).T, other[1]), (G, k)
+# diagnostics of a multi-device product: per-device launch duration and arrival skew (kdehip_product_multi_timing)
+with kdehip.MultiProductPlan(g, first_device=0, ngpus=4) as mp:
+    Ps = [torch.zeros(D * Np, dtype=torch.float64, device=dev) for _ in range(4)]
+    Is = [torch.zeros(M * Np, dtype=torch.int64, device=dev) for _ in range(4)]
+    torch.cuda.synchronize()
+    try:
+        mp.timing()
+        raise SystemExit("timing of an untimed product must be refused")
+    except kdehip.KdeHipError:
+        pass
+    kdehip._clib.kdehip_profile_sampler(1)
+    mp.sample_philox_device(Np, Niter, seed, 0, True, Ps, Is, None)
+    kms, dms = mp.timing()
+    kdehip._clib.kdehip_profile_sampler(0)
+    assert kms.shape == (4,) and (kms > 0).all() and (kms < 100).all(), kms
+    assert dms.min() == 0.0 and (dms >= 0).all() and (dms < 1000).all(), dms
+    torch.cuda.synchronize()
+    assert np.array_equal(Ps[3].cpu().numpy().reshape(Np, D).T, one[0])
 print("alias ok")
+'''
+
+_PEER_CHECK_SCRIPT = r'''
+import ctypes, numpy as np, torch, kdehip
+from tests.helpers import silverman_bw, synth_mixture
+rng = np.random.default_rng(12)
+D, M, N, Np, Niter, seed = 2, 3, 200, 300, 2, 5
+g = [kdehip.kde(p, silverman_bw(p)) for p in [synth_mixture(rng, D, N) for _ in range(M)]]
+one = kdehip.prodAppxMSGibbsS(None, g, None, None, Niter=Niter, Np=Np, seed=seed)
+dev = torch.device("cuda", 0)
+hip = ctypes.CDLL(None)   # the HIP runtime libkdehip.so is bound to
+with kdehip.MultiProductPlan(g, first_device=0, ngpus=2) as mp:
+    # (1) plain device memory (torch's allocator): the look-up passes, the gather stays fused
+    Ps = [torch.zeros(D * Np, dtype=torch.float64, device=dev) for _ in range(2)]
+    Is = [torch.zeros(M * Np, dtype=torch.int64, device=dev) for _ in range(2)]
+    torch.cuda.synchronize()
+    mp.sample_philox_device(Np, Niter, seed, 0, True, Ps, Is, None)
+    torch.cuda.synchronize()
+    assert mp.transfers_per_product == 0
+    assert np.array_equal(Ps[1].cpu().numpy().reshape(Np, D).T, one[0])
+    # (2) arrays from the stream-ordered pool (hipMallocAsync): looked at, reachable from the device itself -> still correct
+    h = hip
+    if hasattr(h, "hipMallocAsync"):
+        ptrs = []
+        for nbytes in (8 * D * Np, 8 * M * Np, 8 * D * Np, 8 * M * Np):
+            p = ctypes.c_void_p()
+            assert h.hipMallocAsync(ctypes.byref(p), ctypes.c_size_t(nbytes), None) == 0
+            ptrs.append(p.value)
+        h.hipDeviceSynchronize()
+        mp.sample_philox_device(Np, Niter, seed, 0, True, [ptrs[0], ptrs[2]], [ptrs[1], ptrs[3]], None)
+        h.hipDeviceSynchronize()
+        out = np.zeros(D * Np)
+        assert h.hipMemcpy(out.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(ptrs[2]), ctypes.c_size_t(8 * D * Np), 2) == 0
+        assert np.array_equal(out.reshape(Np, D).T, one[0]), "pool-allocated destination"
+        print("pool transfers:", mp.transfers_per_product)
+        for p in ptrs:
+            h.hipFreeAsync(ctypes.c_void_p(p), None)
+        h.hipDeviceSynchronize()
+print("peer check ok")
 '''
 
 
@@ -164,3 +221,17 @@ def test_multi_device_code_paths_with_aliased_devices():
     env = dict(os.environ, KDEHIP_ALIAS_DEVICES="1", PYTHONPATH=root)
     out = subprocess.run([sys.executable, "-c", _ALIAS_SCRIPT], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "alias ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+def test_peer_destination_lookup_on_aliased_devices():
+    """The fused gather stores into the caller's arrays on the other devices; which arrays a peer can reach is looked up
+    per product (plain device memory: yes; stream-ordered pools / virtual-memory mappings: what their access flags say;
+    csrc/product.hip peer_can_store).  KDEHIP_PEER_CHECK_ALIASED=1 runs that look-up on one GPU: results stay correct for
+    plain and for pool-allocated destinations, whichever path the product takes."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, KDEHIP_ALIAS_DEVICES="1", KDEHIP_PEER_CHECK_ALIASED="1", PYTHONPATH=root)
+    out = subprocess.run([sys.executable, "-c", _PEER_CHECK_SCRIPT], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "peer check ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
