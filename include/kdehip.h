@@ -299,6 +299,11 @@ int kdehip_prod_philox_batch(int nprod, const kdehip_batch_item *items, int prec
  * streams of their own do not mix. */
 void kdehip_profile_sampler(int enable);
 int kdehip_profile_sampler_read(int device, void *stream, double *total_ms, int64_t *launches);
+/* With the switch on, kdehip_product_multi_sample_philox brackets every device's sampling launch too; this returns, for
+ * the LAST product of `mp` (waiting for it), kernel_ms[g] = the duration of device g's launch and done_ms[g] = the host
+ * time at which g's slice had arrived on every device, relative to the first device to get there (both arrays: ngpus
+ * entries): a straggling device or link shows up as skew, a slow kernel as duration. */
+int kdehip_product_multi_timing(kdehip_product_multi *mp, double *kernel_ms, double *done_ms);
 
 /* ---- (3) host twin of the device RNG ----------------------------------------------------------
  * Fills the arrays a caller would pass as randU / randN so that a streams-run (or the Julia
