@@ -774,12 +774,11 @@ struct SegSums {
     ++k;
   }
 };
-// rows per segment / whether the segment form applies to a tile of B rows in chunks of rc rows
-__device__ __forceinline__ int seg_chunks(int rc) { return rc >= 64 ? 1 : 64 / rc; }
-__device__ __forceinline__ bool seg_applies(int B, int rc) {
-  const int sr = seg_chunks(rc) * rc;
-  return rc <= 64 && (B + sr - 1) / sr <= kMaxSeg;
-}
+// chunks per segment / segments per lane block of a chunked tile: from the descriptor (LevelDesc.seg, worked out by the
+// packer: no integer division on the step path); 0 chunks per segment = the segment form does not apply
+static_assert(kMaxSeg == kMaxSegDesc, "the packer's segment limit is the kernel's");
+__device__ __forceinline__ int seg_chunks(int seg) { return seg & 0xFFFF; }
+__device__ __forceinline__ int seg_count(int seg) { return seg >> 16; }
 
 template <typename T, typename P, typename Eval, typename DS>
 __device__ __forceinline__ int select_or_raise_seg(T S, const SegSums<T> &seg, int seg_rows, P rows, const DS &ds,
@@ -802,7 +801,7 @@ __device__ __forceinline__ int select_or_raise_seg(T S, const SegSums<T> &seg, i
   const T base = lane_read(incl - S, lstar);  // exclusive prefix of the winning lane's block
   int lenl = n - lstar * B;                   // entries of that block
   if (lenl > B) lenl = B;
-  const int nseg = (B + seg_rows - 1) / seg_rows;
+  const int nseg = seg_count(ds.seg);
   int sidx = nseg - 1;
   T before = T(0), run = T(0);
   bool found = false;
@@ -937,7 +936,7 @@ __device__ __forceinline__ int select_or_raise_seg_team(T S, const SegSums<T> &s
   const T base = lane_read(incl - S, lstar);
   int lenl = n - lstar * B;
   if (lenl > B) lenl = B;
-  const int nseg = (B + seg_rows - 1) / seg_rows;
+  const int nseg = seg_count(ds.seg);
   int sidx = nseg - 1;
   T before = T(0), run = T(0);
   bool found = false;
@@ -1047,6 +1046,63 @@ __device__ __forceinline__ void stage_tile(const unsigned char *__restrict__ src
   }
 #endif
 }
+
+// What a workgroup works on.  A plain launch: the kernel arguments, block = blockIdx.x.  A BATCHED launch
+// (kdehip_prod_philox_batch): workgroup b belongs to product batch_map[b]; its plan and run parameters come from that
+// product's BatchEntry -- three 64-byte scalar loads through the constant address space -- and its chains are numbered
+// from the product's first workgroup.
+template <bool BATCH>
+struct LaunchView {
+  const PlanDev &plan;
+  const RunArgs &a;
+  unsigned block;
+  __device__ __forceinline__ LaunchView(const PlanDev &p, const RunArgs &a_) : plan(p), a(a_), block(blockIdx.x) {}
+};
+// The run parameters of a batched workgroup: RunArgs' member names, scalars only (a copy of RunArgs itself -- with its
+// run-time-indexed peer arrays -- would have to live in scratch memory, and everything read from it would count as
+// divergent); no caller streams, no teams, no peers in a batched launch.
+struct BatchArgs {
+  int64_t Np;
+  int32_t Niter, addEntropy, variant, use_tables;
+  uint64_t seed;
+  int64_t sample_offset;
+  double *points;
+  int64_t *indices;
+  int32_t *labels;
+  static constexpr int32_t rng_philox = 1, team = 1, team_level = 0, team_min_rows = 0, npeers = 0, table_build = 0;
+  static constexpr const double *randU = nullptr, *randN = nullptr;
+  static constexpr int64_t K = 0, R = 0, nU = 0, nN = 0;
+  double *peer_points[1];
+  int64_t *peer_indices[1];
+};
+template <>
+struct LaunchView<true> {
+  PlanDev plan;
+  BatchArgs a;
+  unsigned block;
+  __device__ __forceinline__ LaunchView(const PlanDev &, const RunArgs &a_) {
+    const int e = ((const __attribute__((address_space(4))) int *)(a_.batch_map))[blockIdx.x];
+    const auto *src = (const __attribute__((address_space(4))) kdehip_v16i *)(a_.batch + e);
+    const kdehip_v16i r0 = src[0], r1 = src[1], r2 = src[2];  // three s_load_dwordx16
+    BatchPlanHead h;
+    BatchRun be;
+    BatchFlags fl;
+    __builtin_memcpy(&h, &r0, sizeof(h));
+    __builtin_memcpy(&be, &r1, sizeof(be));
+    __builtin_memcpy(&fl, &r2, sizeof(fl));
+    plan.data = h.data; plan.perm = h.perm; plan.levels = h.levels; plan.tables = h.tables; plan.tabdesc = h.tabdesc;
+    plan.tab_rows_total = h.tab_rows_total;
+    plan.M = h.M; plan.L = h.L; plan.D = h.D; plan.Lt = h.Lt;
+    plan.deep_level[0] = be.deep_level[0]; plan.deep_level[1] = be.deep_level[1];
+    plan.deep_share[0] = be.deep_share[0]; plan.deep_share[1] = be.deep_share[1];
+    a.Np = be.Np; a.Niter = fl.Niter; a.addEntropy = fl.addEntropy; a.use_tables = fl.use_tables;
+    a.variant = a_.variant;
+    a.seed = be.seed; a.sample_offset = be.sample_offset;
+    a.points = be.points; a.indices = be.indices; a.labels = be.labels;
+    a.peer_points[0] = nullptr; a.peer_indices[0] = nullptr;
+    block = blockIdx.x - static_cast<unsigned>(fl.first_block);
+  }
+};
 
 
 }  // namespace kdehip

@@ -75,6 +75,7 @@ LeanGeometry lean_geometry(int64_t Np, int variant, int precision, const PlanDev
   int launch_lean_d##d(int, int, const PlanDev &, const RunArgs &, void *);             \
   int launch_lean_hi_d##d(int, int, const PlanDev &, const RunArgs &, void *);          \
   int launch_lean_batch_d##d(int, const PlanDev &, const RunArgs &, void *);            \
+  int launch_tables_batch_d##d(const PlanDev &, const RunArgs &, void *);               \
   int launch_lean_f32_d##d(int, int, const PlanDev &, const RunArgs &, void *);
 KDEHIP_DECL(1) KDEHIP_DECL(2) KDEHIP_DECL(3) KDEHIP_DECL(4) KDEHIP_DECL(5) KDEHIP_DECL(6) KDEHIP_DECL(7) KDEHIP_DECL(8)
 #undef KDEHIP_DECL
@@ -140,6 +141,22 @@ int launch_gibbs_batch(int D, int M, const PlanDev &plan, const RunArgs &args, v
     case 6: return launch_lean_batch_d6(M, plan, args, stream);
     case 7: return launch_lean_batch_d7(M, plan, args, stream);
     case 8: return launch_lean_batch_d8(M, plan, args, stream);
+    default: return set_error(KDEHIP_ERR_UNSUPPORTED, "ndims outside 1..KDEHIP_MAX_DIMS");
+  }
+}
+
+// the conditional tables of such a group, one launch (args.batch / batch_map list the products that have tables; args.Np =
+// workgroups x 4)
+int launch_tables_batch(int D, const PlanDev &plan, const RunArgs &args, void *stream) {
+  switch (D) {
+    case 1: return launch_tables_batch_d1(plan, args, stream);
+    case 2: return launch_tables_batch_d2(plan, args, stream);
+    case 3: return launch_tables_batch_d3(plan, args, stream);
+    case 4: return launch_tables_batch_d4(plan, args, stream);
+    case 5: return launch_tables_batch_d5(plan, args, stream);
+    case 6: return launch_tables_batch_d6(plan, args, stream);
+    case 7: return launch_tables_batch_d7(plan, args, stream);
+    case 8: return launch_tables_batch_d8(plan, args, stream);
     default: return set_error(KDEHIP_ERR_UNSUPPORTED, "ndims outside 1..KDEHIP_MAX_DIMS");
   }
 }

@@ -53,8 +53,14 @@ namespace kdehip {
 // TBL: the instantiation that only fills the conditional tables (a.table_build) -- the same code, but without the
 // 120 KiB tile pool in its LDS footprint, so that a CU holds many more of its wavefronts (one wavefront per table row,
 // ~19,000 rows at config 3: 45 us with the sampler's one-workgroup-per-CU footprint, every one-shot call pays it).
-template <typename T, int D, int MODE, int WAVES, bool TBL = false>
-__global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan, RunArgs a) {
+// BATCH (with TBL only): the tables of MANY products in one launch (kdehip_prod_philox_batch) -- workgroup b fills rows of
+// product batch_map[b], whose plan it fetches through the scalar cache (LaunchView, gibbs_device.hpp).
+template <typename T, int D, int MODE, int WAVES, bool TBL = false, bool BATCH = false>
+__global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan_, RunArgs a_) {
+  static_assert(!BATCH || TBL, "batched launches of this kernel fill tables only");
+  const LaunchView<BATCH> view(plan_, a_);
+  const PlanDev &plan = view.plan;
+  const auto &a = view.a;
   constexpr bool FAST = (MODE != kModeGeneric);      // product/rsqrt + uniform-bandwidth forms
   constexpr bool MASKED = (MODE == kModeFastMasked);  // ... with inactive dimensions
   constexpr bool kAllDimsOn = (MODE == kModeFast);    // the plan checked it: no mask tests in this build
@@ -72,7 +78,7 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan,
   // readfirstlane makes the wave id (and everything derived from it: sample index, RNG counters,
   // descriptor addresses) provably wave-uniform, so it lives in SGPRs / runs on the scalar unit
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
-  int64_t s = static_cast<int64_t>(blockIdx.x) * WAVES + wave;
+  int64_t s = static_cast<int64_t>(view.block) * WAVES + wave;
   // surplus wavefronts of the last workgroup keep taking part in staging and barriers: they replay
   // the last chain and store nothing
   const bool live = s < a.Np;
@@ -235,8 +241,8 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan,
       const int RS = ds.F * 64 + 1, rc = chunk_rows(ds);
       LaneAcc<T> acc;  // the lane's sums over its rows, kept across the chunks (gibbs_device.hpp: one association everywhere)
       SegSums<T> seg;
-      const int cps = seg_chunks(rc);
-      const bool use_seg = seg_applies(ds.B, rc);
+      const int cps = seg_chunks(ds.seg);
+      const bool use_seg = cps != 0;
       int cin = 0;
       for (int r0 = 0; r0 < ds.B; r0 += rc, ++gchunk) {
         staging_barrier();  // this chunk has landed for every wavefront; the other half is free again
@@ -269,7 +275,7 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan,
   const TabTable tabs{(const __attribute__((address_space(4))) kdehip_v8i *)(plan.tabdesc)};
   T *tables = static_cast<T *>(const_cast<void *>(plan.tables));
   if (TBL || a.table_build) {
-    const int64_t g = static_cast<int64_t>(blockIdx.x) * WAVES + wave;
+    const int64_t g = static_cast<int64_t>(view.block) * WAVES + wave;
     if (g >= plan.tab_rows_total) return;
     int tl = 1, tj = 0;
     TabDesc td = tabs[1];
@@ -569,6 +575,17 @@ static int launch_one(const PlanDev &plan, const RunArgs &args, hipStream_t stre
 #endif
 #define KDEHIP_CAT2(a, b) a##b
 #define KDEHIP_CAT(a, b) KDEHIP_CAT2(a, b)
+
+// kdehip_prod_philox_batch: the conditional tables of a group of fp64 products in one launch; args.Np = workgroups x 4
+int KDEHIP_CAT(launch_tables_batch_d, KDEHIP_DIM)(const PlanDev &plan, const RunArgs &args, void *stream) {
+  constexpr int TW = 4;
+  if (args.Np <= 0) return KDEHIP_OK;
+  hipLaunchKernelGGL((gibbs_product_kernel<double, KDEHIP_DIM, kModeFast, TW, true, true>), dim3(static_cast<unsigned>(args.Np / TW)),
+                     dim3(TW * 64), 0, static_cast<hipStream_t>(stream), plan, args);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_error(KDEHIP_ERR_HIP, std::string("batched table build launch failed: ") + hipGetErrorString(e));
+  return KDEHIP_OK;
+}
 
 int KDEHIP_CAT(launch_gibbs_d, KDEHIP_DIM)(int precision, int mode, const PlanDev &plan, const RunArgs &args,
                                            void *stream) {

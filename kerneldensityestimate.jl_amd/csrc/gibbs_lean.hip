@@ -60,6 +60,7 @@ struct LeanTile {
   int lds_off;      // byte offset of the image in the LDS pool (resident mode)
   int stage_bytes;  // bytes of the image (streamed mode)
   int chunk_rows;   // rows per chunk (chunked mode)
+  int seg;          // segment geometry of a chunked tile (LevelDesc.seg)
   int hdr_lo, hdr_hi;  // element offset of the tile header in the plan's data
   // the members the draw functions of gibbs_device.hpp read
   int B, F, last_lane;
@@ -73,6 +74,7 @@ struct LeanTile {
     lds_off = scalar_copy(d.lds_off);
     stage_bytes = scalar_copy(d.stage_bytes);
     chunk_rows = scalar_copy(d.chunk_rows);
+    seg = scalar_copy(d.seg);
     hdr_lo = scalar_copy(static_cast<int>(d.hdr_off));
     hdr_hi = scalar_copy(static_cast<int>(d.hdr_off >> 32));
     B = (n + 63) >> 6;
@@ -85,63 +87,6 @@ struct LeanTile {
 // TEAMS: the instantiation whose wavefronts can form teams (RunArgs.team = 2 or 4; 16-wavefront fp64 builds).  A kernel
 // of its own: with the team paths compiled in, a 16-wavefront build is up to 25 % slower even when every chain has one
 // wavefront (config 4 with 16,384 chains: 31 -> 39 ms), and that is the build large batches run.
-// What a workgroup works on.  A plain launch: the kernel arguments, block = blockIdx.x.  A BATCHED launch
-// (kdehip_prod_philox_batch): workgroup b belongs to product batch_map[b]; its plan and run parameters come from that
-// product's BatchEntry -- three 64-byte scalar loads through the constant address space -- and its chains are numbered
-// from the product's first workgroup.
-template <bool BATCH>
-struct LaunchView {
-  const PlanDev &plan;
-  const RunArgs &a;
-  unsigned block;
-  __device__ __forceinline__ LaunchView(const PlanDev &p, const RunArgs &a_) : plan(p), a(a_), block(blockIdx.x) {}
-};
-// The run parameters of a batched workgroup: RunArgs' member names, scalars only (a copy of RunArgs itself -- with its
-// run-time-indexed peer arrays -- would have to live in scratch memory, and everything read from it would count as
-// divergent); no caller streams, no teams, no peers in a batched launch.
-struct BatchArgs {
-  int64_t Np;
-  int32_t Niter, addEntropy, variant, use_tables;
-  uint64_t seed;
-  int64_t sample_offset;
-  double *points;
-  int64_t *indices;
-  int32_t *labels;
-  static constexpr int32_t rng_philox = 1, team = 1, team_level = 0, team_min_rows = 0, npeers = 0;
-  static constexpr const double *randU = nullptr, *randN = nullptr;
-  static constexpr int64_t K = 0, R = 0, nU = 0, nN = 0;
-  double *peer_points[1];
-  int64_t *peer_indices[1];
-};
-template <>
-struct LaunchView<true> {
-  PlanDev plan;
-  BatchArgs a;
-  unsigned block;
-  __device__ __forceinline__ LaunchView(const PlanDev &, const RunArgs &a_) {
-    const int e = ((const __attribute__((address_space(4))) int *)(a_.batch_map))[blockIdx.x];
-    const auto *src = (const __attribute__((address_space(4))) kdehip_v16i *)(a_.batch + e);
-    const kdehip_v16i r0 = src[0], r1 = src[1], r2 = src[2];  // three s_load_dwordx16
-    BatchPlanHead h;
-    BatchRun be;
-    BatchFlags fl;
-    __builtin_memcpy(&h, &r0, sizeof(h));
-    __builtin_memcpy(&be, &r1, sizeof(be));
-    __builtin_memcpy(&fl, &r2, sizeof(fl));
-    plan.data = h.data; plan.perm = h.perm; plan.levels = h.levels; plan.tables = h.tables; plan.tabdesc = h.tabdesc;
-    plan.tab_rows_total = h.tab_rows_total;
-    plan.M = h.M; plan.L = h.L; plan.D = h.D; plan.Lt = h.Lt;
-    plan.deep_level[0] = be.deep_level[0]; plan.deep_level[1] = be.deep_level[1];
-    plan.deep_share[0] = be.deep_share[0]; plan.deep_share[1] = be.deep_share[1];
-    a.Np = be.Np; a.Niter = fl.Niter; a.addEntropy = fl.addEntropy; a.use_tables = fl.use_tables;
-    a.variant = a_.variant;
-    a.seed = be.seed; a.sample_offset = be.sample_offset;
-    a.points = be.points; a.indices = be.indices; a.labels = be.labels;
-    a.peer_points[0] = nullptr; a.peer_indices[0] = nullptr;
-    block = blockIdx.x - static_cast<unsigned>(fl.first_block);
-  }
-};
-
 template <typename T, int D, int M, int WAVES, bool TEAMS = false, bool BATCH = false>
 __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, RunArgs a_) {
   const LaunchView<BATCH> view(plan_, a_);
@@ -462,8 +407,8 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
             LaneAcc<T> acc;          // a wavefront that owns its chain
             T mx = T(0), my = T(0);  // a team member's share
             SegSums<T> seg;
-            const int cps = seg_chunks(rc);
-            const bool use_seg = seg_applies(ds.B, rc);
+            const int cps = seg_chunks(ds.seg);
+            const bool use_seg = cps != 0;
             // (a chunked level is always a shared one, and the team instantiation only runs with teams: lean_geometry)
             constexpr bool shared = kTeams;
             int cin = 0;

@@ -55,8 +55,19 @@ struct LevelDesc {
   int32_t stage_bytes;  // bytes to copy (header + rows, rounded up to 1 KiB)
   int32_t last_lane;    // (n - 1) / B: the lane that owns the last entry (kept here: no integer division per step)
   int32_t chunk_rows;   // rows per LDS chunk in chunked mode (multiple of 4: 16-byte aligned chunk starts)
-  int32_t pad_;
+  // chunked mode, the one-round second pass (gibbs_device.hpp "chunked tiles"): chunks per segment in bits 0..15 (0: the
+  // segment form does not apply to this tile), segments per lane block in bits 16..31 -- worked out by the packer so
+  // that no step of the kernel divides integers (four uniform divisions a step were 3 % of config 4's instructions)
+  int32_t seg;
 };
+// the segment geometry of a chunked tile of B rows per lane in chunks of rc rows: a segment = a whole number of chunks, at
+// most 64 rows, at most kMaxSegDesc segments (else 0)
+constexpr int kMaxSegDesc = 8;
+inline int32_t seg_geometry(int B, int rc) {
+  if (rc <= 0 || rc > 64) return 0;
+  const int cps = 64 / rc, sr = cps * rc, nseg = (B + sr - 1) / sr;
+  return nseg <= kMaxSegDesc ? (cps | (nseg << 16)) : 0;
+}
 static_assert(sizeof(LevelDesc) == 64, "LevelDesc is read with scalar loads; keep it 64 bytes");
 
 // Conditional table of density j on level l (see gibbs_kernel.hip "conditional tables"): rows of n+1
@@ -235,6 +246,7 @@ int device_cu_count();
 int launch_gibbs(int precision, int mode, const PlanDev &plan, const RunArgs &args, void *stream);
 // a group of fp64 products of M (2..4) densities in one launch (gibbs_dispatch.cpp; RunArgs.batch / batch_map)
 int launch_gibbs_batch(int D, int M, const PlanDev &plan, const RunArgs &args, void *stream);
+int launch_tables_batch(int D, const PlanDev &plan, const RunArgs &args, void *stream);
 
 // kde!(points)'s LOOCV bandwidth search (evaluate.hip) on `stream` of the current device, from the host's copy of the
 // D x N matrix and/or a copy that already lives in HBM (`d_points`: nothing is uploaded then).  Blocking.

@@ -279,6 +279,7 @@ int pack_layout_shapes(int M, int D, int L, const TileShape *shapes, const uint8
     for (int j = 0; j < M; ++j) {
       LevelDesc &ds = out.levels[static_cast<size_t>(j) * (L + 1) + l];
       ds.stage_mode = mode;
+      ds.seg = (mode == kStageChunked) ? seg_geometry(ds.B, ds.chunk_rows) : 0;
       ds.lds_off = (mode == kStageResident) ? static_cast<int32_t>(off) : 0;
       off += ds.stage_bytes;
     }

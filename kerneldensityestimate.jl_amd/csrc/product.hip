@@ -1007,7 +1007,18 @@ int kdehip_prod_philox_batch(int nprod, const kdehip_batch_item *items, int prec
   if (device < 0 || device >= kMaxDevices) return set_error(KDEHIP_ERR_UNSUPPORTED, "device ordinal beyond the library's bookkeeping (64)");
   pend.device = device;
   // groups of batchable products by (D, M); everything else runs one by one
-  struct Group { int D, M; std::vector<int> members; int64_t blocks = 0; size_t ent_at = 0, map_at = 0; };
+  struct Group {
+    int D, M;
+    std::vector<int> members;
+    int64_t blocks = 0;
+    size_t ent_at = 0, map_at = 0;
+    // the members whose conditional tables are worth building (gibbs_kernel.hip "conditional tables"), their table rows in
+    // workgroups of kTabWaves wavefronts (one wavefront per row)
+    std::vector<int> tabbed;
+    int64_t tab_blocks = 0;
+    size_t tent_at = 0, tmap_at = 0;
+  };
+  constexpr int kTabWaves = 4;
   std::vector<Group> groups;
   std::vector<int> singles;
   constexpr int kBatchWaves = 16;  // chains per workgroup of the batched instantiations
@@ -1017,18 +1028,31 @@ int kdehip_prod_philox_batch(int nprod, const kdehip_batch_item *items, int prec
     if (!batchable(p)) { singles.push_back(i); continue; }
     Group *g = nullptr;
     for (Group &c : groups) if (c.D == p->host.D && c.M == p->host.M) g = &c;
-    if (!g) { groups.push_back(Group{p->host.D, p->host.M, {}, 0, 0, 0}); g = &groups.back(); }
+    if (!g) { groups.emplace_back(); g = &groups.back(); g->D = p->host.D; g->M = p->host.M; }
     g->members.push_back(i);
     g->blocks += (items[i].Np + kBatchWaves - 1) / kBatchWaves;
   }
   for (size_t k = 0; k < groups.size();)  // a group of one gains nothing from the batched kernel
     if (groups[k].members.size() == 1) { singles.push_back(groups[k].members[0]); groups.erase(groups.begin() + k); } else ++k;
+  auto has_tables = [&](int i) {  // (the rule of maybe_build_tables)
+    const kdehip_product *p = pend.plans[i];
+    return p->mode != kModeGeneric && p->host.Lt > 0 && p->host.tab_rows > 0 && items[i].Np >= kTabMinChains;
+  };
+  for (Group &g : groups)
+    for (int i : g.members)
+      if (has_tables(i)) {
+        g.tabbed.push_back(i);
+        g.tab_blocks += (pend.plans[i]->host.tab_rows + kTabWaves - 1) / kTabWaves;
+      }
   const size_t off_jobs = head;
   size_t at = align256(off_jobs + njobs * sizeof(FillJob));
   for (Group &g : groups) {
     if (g.blocks > (int64_t(1) << 31) - 1) return set_error(KDEHIP_ERR_UNSUPPORTED, "kdehip_prod_philox_batch: too many chains for one launch");
+    if (g.tab_blocks > (int64_t(1) << 31) - 1) return set_error(KDEHIP_ERR_UNSUPPORTED, "kdehip_prod_philox_batch: too many table rows for one launch");
     g.ent_at = at; at = align256(at + g.members.size() * sizeof(BatchEntry));
     g.map_at = at; at = align256(at + static_cast<size_t>(g.blocks) * sizeof(int32_t));
+    g.tent_at = at; at = align256(at + g.tabbed.size() * sizeof(BatchEntry));
+    g.tmap_at = at; at = align256(at + static_cast<size_t>(g.tab_blocks) * sizeof(int32_t));
   }
   const size_t head_bytes = at, total = head_bytes + body;
   DeviceGuard guard;
@@ -1063,12 +1087,25 @@ int kdehip_prod_philox_batch(int nprod, const kdehip_batch_item *items, int prec
       be.run.deep_share[0] = pd.deep_share[0]; be.run.deep_share[1] = pd.deep_share[1];
       be.run.Np = it.Np; be.run.seed = it.seed; be.run.sample_offset = it.sample_offset;
       be.run.points = it.d_points; be.run.indices = it.d_indices; be.run.labels = it.d_labels;
-      be.flags.Niter = it.Niter; be.flags.addEntropy = it.addEntropy ? 1 : 0; be.flags.use_tables = 0;
+      be.flags.Niter = it.Niter; be.flags.addEntropy = it.addEntropy ? 1 : 0; be.flags.use_tables = has_tables(i) ? 1 : 0;
       be.flags.first_block = block;
       ent[k] = be;
       const int32_t nb = static_cast<int32_t>((it.Np + kBatchWaves - 1) / kBatchWaves);
       for (int32_t q = 0; q < nb; ++q) map[block + q] = static_cast<int32_t>(k);
       block += nb;
+    }
+    // the table launch of the group: the same entries, numbered from the product's first TABLE workgroup
+    BatchEntry *tent = reinterpret_cast<BatchEntry *>(hb + g.tent_at);
+    int32_t *tmap = reinterpret_cast<int32_t *>(hb + g.tmap_at);
+    int32_t tblock = 0, kt = 0;
+    for (size_t k = 0; k < g.members.size(); ++k) {
+      if (!ent[k].flags.use_tables) continue;
+      tent[kt] = ent[k];
+      tent[kt].flags.first_block = tblock;
+      const int32_t nb = static_cast<int32_t>((pend.plans[g.members[k]]->host.tab_rows + kTabWaves - 1) / kTabWaves);
+      for (int32_t q = 0; q < nb; ++q) tmap[tblock + q] = kt;
+      tblock += nb;
+      ++kt;
     }
   }
   auto fail = [&](int code) {  // work may have been enqueued: wait for it before the block goes back to the cache
@@ -1080,6 +1117,15 @@ int kdehip_prod_philox_batch(int nprod, const kdehip_batch_item *items, int prec
   rc = launch_fill_tiles(precision, reinterpret_cast<const FillJob *>(db + off_jobs), static_cast<int>(njobs), maxB, st);
   if (rc != KDEHIP_OK) return fail(rc);
   for (const Group &g : groups) {
+    if (g.tab_blocks > 0) {  // one launch fills the conditional tables of every member that has them
+      RunArgs t{};
+      t.table_build = 1;
+      t.batch = reinterpret_cast<const BatchEntry *>(db + g.tent_at);
+      t.batch_map = reinterpret_cast<const int32_t *>(db + g.tmap_at);
+      t.Np = g.tab_blocks * kTabWaves;
+      rc = launch_tables_batch(g.D, pend.plans[g.tabbed[0]]->dev, t, st);
+      if (rc != KDEHIP_OK) return fail(rc);
+    }
     RunArgs a{};
     a.rng_philox = 1;
     a.batch = reinterpret_cast<const BatchEntry *>(db + g.ent_at);

@@ -9,7 +9,7 @@ t1 = time.perf_counter()
 lib.kdehip_device_count.restype = ctypes.c_int
 n = lib.kdehip_device_count()          # hipGetDeviceCount: runtime initialisation
 t2 = time.perf_counter()
-hip = ctypes.CDLL(None)
+hip = ctypes.CDLL("libamdhip64.so")   # (already mapped: libkdehip.so links it)
 hip.hipSetDevice(0)
 hip.hipFree(None)                      # context creation
 t3 = time.perf_counter()

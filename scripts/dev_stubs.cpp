@@ -4,6 +4,7 @@
 namespace kdehip {
 #define STUB(d)                                                                                                       \
   int launch_gibbs_d##d(int, int, const PlanDev &, const RunArgs &, void *) { return set_error(KDEHIP_ERR_UNSUPPORTED, "mini development library: dimension count not built"); } \
+  int launch_tables_batch_d##d(const PlanDev &, const RunArgs &, void *) { return set_error(KDEHIP_ERR_UNSUPPORTED, "mini development library: dimension count not built"); } \
   int launch_lean_d##d(int, int, const PlanDev &, const RunArgs &, void *) { return kLeanNotCovered; }                 \
   int launch_lean_hi_d##d(int, int, const PlanDev &, const RunArgs &, void *) { return kLeanNotCovered; }              \
   int launch_lean_f32_d##d(int, int, const PlanDev &, const RunArgs &, void *) { return kLeanNotCovered; }

@@ -151,3 +151,40 @@ def test_kde_auto_builds_its_tree_under_the_search_and_equals_the_sequential_for
         _lib.check(_lib.lib.kdehip_make_density_auto(1, 1, _lib.ptr(one, P), _lib.ptr(z, P), None, 0, _lib.ptr(z, P), _lib.ptr(z, P),
                                                      _lib.ptr(z, P), _lib.ptr(zi, Q), _lib.ptr(zi, Q), _lib.ptr(zi, Q), _lib.ptr(zi, Q),
                                                      _lib.ptr(zi, Q), _lib.ptr(z, P), _lib.ptr(z, P), _lib.ptr(z, P), _lib.ptr(z, P)))
+
+
+_TWO_LAUNCH_SCRIPT = r'''
+import json, sys, numpy as np, kdehip
+from tests.helpers import synth_mixture
+out = {}
+for D, N in [(1, 65), (1, 128), (2, 129), (1, 191), (3, 192), (1, 257), (2, 320), (6, 500), (1, 1000), (6, 1000), (2, 1999),
+             (6, 2048), (1, 2049), (3, 3000), (1, 4032), (2, 4096)]:
+    rng = np.random.default_rng(1000 * D + N)
+    bw, ne = kdehip.auto_bandwidth(synth_mixture(rng, D, N), return_evals=True)
+    out[f"{D}x{N}"] = ([float(x) for x in bw], int(ne))
+print("RESULT " + json.dumps(out))
+'''
+
+
+def test_fused_loocv_rounds_equal_the_two_launch_rounds():
+    """The one-launch LOOCV round hands its slots between workgroups and XCDs inside the launch with device-scope relaxed
+    atomics (csrc/evaluate.hip slot_store / pairs_arrive: leaning on gfx950's write-through behaviour, see there).  The
+    two-launch rounds have no such hand-over (kernel boundaries order everything): both forms must select the same bandwidth
+    with the same number of likelihood evaluations -- tile counts 2 .. 64, odd and even circles, ragged last tiles."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = []
+    for two in ("0", "1"):
+        env = dict(os.environ, KDEHIP_LOOCV_TWO_LAUNCH=two, PYTHONPATH=root)
+        out = subprocess.run([sys.executable, "-c", _TWO_LAUNCH_SCRIPT], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stdout[-1000:] + out.stderr[-3000:]
+        line = [ln for ln in out.stdout.splitlines() if ln.startswith("RESULT ")][-1]
+        res.append(json.loads(line[7:]))
+    assert res[0].keys() == res[1].keys()
+    for k in res[0]:
+        (b0, n0), (b1, n1) = res[0][k], res[1][k]
+        assert n0 == n1, (k, n0, n1)
+        assert np.allclose(b0, b1, rtol=1e-9, atol=0.0), (k, b0, b1)
