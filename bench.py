@@ -530,39 +530,56 @@ def call_inclusive(kdehip, trees, plan, D, M, Nout, Niter, seed, prec):
 
 
 _COLD_CHILD = r"""
-import json, sys, time
+import ctypes, json, os, sys, time
+root, config = sys.argv[1], sys.argv[2]
 t0 = time.perf_counter()
-sys.path.insert(0, sys.argv[1])
+lib = ctypes.CDLL(os.path.join(root, "kerneldensityestimate.jl_amd", "libkdehip.so"))   # what a Julia `ccall` pays to bind
+t_dl = time.perf_counter()
+lib.kdehip_device_count.restype = ctypes.c_int
+lib.kdehip_device_count()          # hipGetDeviceCount: the HIP runtime initialises itself (not this library's time)
+t_init = time.perf_counter()
+sys.path.insert(0, root)
 import numpy as np
-import kdehip                      # dlopen of libkdehip.so (+ the HIP runtime)
-t_load = time.perf_counter()
+import kdehip
 import bench
-D, M, N, Nout, Niter, prec, cid = bench.CONFIGS[sys.argv[2]]
+t_py = time.perf_counter()
+D, M, N, Nout, Niter, prec, cid = bench.CONFIGS[config]
 pts, bws = bench.synth_inputs(kdehip, D, M, N, cid)
 trees = [kdehip.kde(p, b) for p, b in zip(pts, bws)]
 t1 = time.perf_counter()
-kdehip.prodAppxMSGibbsS(None, trees, None, None, Niter=Niter, Np=Nout, seed=1, precision=prec)   # device init, code objects, first launch
+kdehip.prodAppxMSGibbsS(None, trees, None, None, Niter=Niter, Np=Nout, seed=1, precision=prec)   # code objects of this shape, first launches
 t2 = time.perf_counter()
 kdehip.prodAppxMSGibbsS(None, trees, None, None, Niter=Niter, Np=Nout, seed=2, precision=prec)
 t3 = time.perf_counter()
-import os
 so = os.path.getsize(kdehip.LIB_PATH)
-print(json.dumps({"library_load_ms": (t_load - t0) * 1e3, "first_call_ms": (t2 - t1) * 1e3, "second_call_ms": (t3 - t2) * 1e3,
-                  "cold_start_ms": (t_load - t0 + t2 - t1) * 1e3, "libkdehip_bytes": so}))
+ms = lambda a, b: (b - a) * 1e3
+print(json.dumps({"dlopen_ms": ms(t0, t_dl), "hip_runtime_init_ms": ms(t_dl, t_init), "first_call_ms": ms(t1, t2),
+                  "second_call_ms": ms(t2, t3), "library_ms": ms(t0, t_dl) + ms(t1, t2),
+                  "cold_start_ms": ms(t0, t_init) + ms(t1, t2), "python_imports_ms": ms(t_init, t_py), "libkdehip_bytes": so}))
 """
 
 
 def cold_start(config):
-    """What a fresh process pays before its first product is back: load of libkdehip.so (ctypes dlopen,
-    no torch) + the first `prodAppxMSGibbsS` one-shot call (device initialisation, unpacking and loading the code objects,
-    first launch), against the second call of the same process.  Run in a child process; None if it fails."""
+    """What a fresh process pays before its first product is back, in a child process without torch: `dlopen` of
+    libkdehip.so; the HIP runtime's own initialisation (the first HIP call of any process: device enumeration -- 140-280 ms
+    on the pool's boxes with or without this library, scripts/cold_pieces.py); the first `prodAppxMSGibbsS` one-shot call
+    (unpacking and loading the code objects of this shape's kernels, first launches) against the second.  `library_ms` =
+    dlopen + first call: the part that is this library's; `cold_start_ms` adds the runtime's initialisation.  For the
+    benched configuration and for config 2 (a small product).  None if the child fails."""
     import subprocess
-    try:
-        r = subprocess.run([sys.executable, "-c", _COLD_CHILD, ROOT, config], capture_output=True, text=True, timeout=300)
-        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-        return json.loads(line[-1]) if line else None
-    except Exception:  # noqa: BLE001  (diagnostic extra: never fails the bench)
-        return None
+    out = {}
+    for cfg in dict.fromkeys([config, "c2"]):
+        try:
+            r = subprocess.run([sys.executable, "-c", _COLD_CHILD, ROOT, cfg], capture_output=True, text=True, timeout=300)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            out[cfg] = json.loads(line[-1]) if line else None
+        except Exception:  # noqa: BLE001  (diagnostic extra: never fails the bench)
+            out[cfg] = None
+    first = out.get(config)
+    if first:   # (flat keys of the benched configuration, as in earlier rounds' lines)
+        out.update({k: first[k] for k in ("dlopen_ms", "hip_runtime_init_ms", "first_call_ms", "second_call_ms", "library_ms",
+                                          "cold_start_ms", "libkdehip_bytes")})
+    return out
 
 
 def cpu_baseline_and_parity(kdehip, plan, pts_all, bw_all, D, M, N, Nout, Niter, seed, warmup):

@@ -50,6 +50,10 @@ LeanGeometry lean_geometry(int64_t Np, int variant, int precision, const PlanDev
   const int vt = (variant / 1000) % 10;  // diagnostic builds combine a level cut-off (v = 100 + k) with a geometry: thousands digit
   if (vt == 6) g.waves = 16;
   if (vt == 8) g.waves = 8;
+#if !defined(KDEHIP_WITH_TEAMS) || !KDEHIP_WITH_TEAMS
+  // the team instantiations are not part of this build (make TEAMS=1): the team variants run as 16 one-wavefront chains
+  if (v == kVariantTeam2 || v == kVariantTeam4 || vt == 2 || vt == 4) { g.waves = 16; return g; }
+#endif
   if (v == kVariantTeam2 || vt == 2) team = 2;
   else if (v == kVariantTeam4 || vt == 4) team = 4;
   else if (v == 0 && vt == 0) {

@@ -16,6 +16,9 @@
 // Results: labels identical to gibbs_kernel.hip and to the oracle, points bit-identical to gibbs_kernel.hip
 // (same reciprocal / product forms) -- tested (tests/test_gpu_lean.py).
 #define KDEHIP_EXP256 1
+#ifndef KDEHIP_WITH_TEAMS
+#define KDEHIP_WITH_TEAMS 0
+#endif
 #include "gibbs_device.hpp"
 
 namespace kdehip {
@@ -532,6 +535,7 @@ template <typename T, int D, int M, int WAVES>
 static void launch_lean_waves(const PlanDev &plan, const RunArgs &args, hipStream_t stream) {
   const int chains = WAVES / (args.team > 1 ? args.team : 1);  // chains per workgroup
   const int64_t blocks = (args.Np + chains - 1) / chains;
+#if KDEHIP_WITH_TEAMS  // (make TEAMS=1; lean_geometry never reports a team otherwise)
   if constexpr (WAVES == 16 && sizeof(T) == 8) {
     if (args.team > 1) {
       hipLaunchKernelGGL((gibbs_lean_kernel<T, D, M, WAVES, true>), dim3(static_cast<unsigned>(blocks)), dim3(WAVES * 64), 0,
@@ -539,6 +543,7 @@ static void launch_lean_waves(const PlanDev &plan, const RunArgs &args, hipStrea
       return;
     }
   }
+#endif
   hipLaunchKernelGGL((gibbs_lean_kernel<T, D, M, WAVES>), dim3(static_cast<unsigned>(blocks)), dim3(WAVES * 64), 0,
                      stream, plan, args);
 }

@@ -1034,9 +1034,17 @@ int kdehip_prod_philox_batch(int nprod, const kdehip_batch_item *items, int prec
   }
   for (size_t k = 0; k < groups.size();)  // a group of one gains nothing from the batched kernel
     if (groups[k].members.size() == 1) { singles.push_back(groups[k].members[0]); groups.erase(groups.begin() + k); } else ++k;
-  auto has_tables = [&](int i) {  // (the rule of maybe_build_tables)
+  // Whether a member's conditional tables pay for themselves INSIDE the batch: a table row costs about as much as a full
+  // step of one chain, a tabulated sweep step saves ~60 % of one -- and the many small products a batch is made of have few
+  // chains per table row (config 2's shape: 4,092 rows for 256 chains).  Measured on MI355X (profiles/r04_batch.md):
+  // tables when chains x tabulated levels x sweeps x densities >= 6.5 x rows.  KDEHIP_BATCH_TABLES=0/1 forces never/always.
+  static const int force_tables = [] { const char *e = std::getenv("KDEHIP_BATCH_TABLES"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+  auto has_tables = [&](int i) {
     const kdehip_product *p = pend.plans[i];
-    return p->mode != kModeGeneric && p->host.Lt > 0 && p->host.tab_rows > 0 && items[i].Np >= kTabMinChains;
+    if (p->mode == kModeGeneric || p->host.Lt <= 0 || p->host.tab_rows <= 0 || items[i].Np < kTabMinChains) return false;
+    if (force_tables >= 0) return force_tables == 1;
+    const double saved = static_cast<double>(items[i].Np) * p->host.Lt * items[i].Niter * p->host.M;
+    return saved >= 6.5 * static_cast<double>(p->host.tab_rows);
   };
   for (Group &g : groups)
     for (int i : g.members)
