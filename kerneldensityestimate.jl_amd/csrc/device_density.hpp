@@ -14,6 +14,8 @@ struct Frontiers {
   std::vector<int32_t> ids;      // node ids (1-based), level l at [off[l], off[l+1])
   std::vector<int64_t> off;      // L + 2 entries
   std::vector<uint8_t> uniform;  // L + 1: every node of the frontier has the bandwidth vector of its first node
+  std::vector<double> uratio;    // L + 1, uniform frontiers: max over nodes and dimensions of |mean_d| / sqrt(2 bandwidth_d)
+                                 // (what the shared-bandwidth evaluator's rounding error grows with: pack_layout_shapes)
   bool bad = false;              // look = true: a mean beyond 1e100, a non-positive / non-finite variance or weight was seen
   double lo[KDEHIP_MAX_DIMS], hi[KDEHIP_MAX_DIMS];  // look = true: range of the variances per dimension
   int64_t nodes = 0;             // sum_{l >= 1} n_l
@@ -25,6 +27,7 @@ int expand_frontiers(const kdehip_density &t, int D, int L, bool look, Frontiers
 struct TileShape {
   int64_t n;
   bool uniform;
+  double uratio;  // Frontiers.uratio of a uniform frontier
 };
 // Phases 2-4 of pack_layout (tile geometry, staging modes, conditional tables) from the shapes [M][L+1] alone.
 int pack_layout_shapes(int M, int D, int L, const TileShape *shapes, const uint8_t *mask, int precision, bool fast,

@@ -178,9 +178,19 @@ __device__ __forceinline__ float load_single(P p) {
   return *(VP)(p);
 }
 
-// UNIFORM: the level has one bandwidth vector; ninv[d] = -1/(2 c_d), scale = rsqrt(prod_d c_d).
+// UNIFORM: the level has one bandwidth vector; scale = rsqrt(prod_d c_d).
+//   fp32: ninv[d] = -1/(2 c_d) (times log2 e), exponent = sum_d (m_d - center_d)^2 * ninv_d: three instructions per dimension.
+//   fp64 (round 4): ninv[d] = s_d = sqrt(1/(2 c_d)), center[d] = mu_d * s_d, exponent = -sum_d t_d^2 with
+//         t_d = fma(m_d, s_d, -mu_d s_d): TWO instructions per dimension.  t_d carries an absolute rounding error of
+//         ~1e-16 |m_d| s_d instead of the subtract-first form's 1e-16 |t_d|; the packer gives a frontier this compact tile
+//         only while |m_d| s_d <= |m_d| / sqrt(2 bandwidth_d) <= kMaxUniformRatio (pack_layout_shapes), so the exponent
+//         of any entry that can matter (|t| < 40) is good to 1e-9 at the very worst and to ~1e-14 for data within a few
+//         hundred bandwidths of the origin -- beyond what decides a label except in exact ties.
 // OFF (fp32 retries only): every exponent is raised by `xoff` (base-2 units) and clamped below the overflow
 // of exp2 -- see Num<float>::tiny_total.
+// (fp32 keeps the subtract-first form: measured at config 5, the two-instruction form buys 0.9 % there -- 19.01 ->
+// 18.84 ms, profiles/r04_experiments.md -- and would change the labels the fp32 gates were tuned on)
+template <typename T> constexpr bool kUniformTwoOp = std::is_same<T, double>::value;
 template <typename T, int D, bool OFF = false>
 struct EvalUniform {
   T center[D], ninv[D], scale;
@@ -192,6 +202,19 @@ struct EvalUniform {
     for (int d = 0; d < D; ++d) { e.center[d] = center[d]; e.ninv[d] = ninv[d]; }
     e.scale = scale; e.tab = tab; e.xoff = o;
     return e;
+  }
+  // what the dimension lanes hand to the evaluator (lanes = dimensions: `mean`, `c` = bandwidth + leave-one-out variance
+  // of this lane's dimension; on = the dimension takes part): the two per-dimension operands, before their broadcast
+  static __device__ __forceinline__ void operands(T mean, T c, bool on, T &cen, T &nin) {
+    if constexpr (kUniformTwoOp<T>) {
+      const T sl = Num<T>::rsqrt(c * T(2.0 / double(Num<T>::kExpArg)));  // sqrt(kExpArg / (2 c)): fp32 exponents are base 2
+      nin = on ? sl : T(0);
+      cen = on ? mean * sl : T(0);
+    } else {
+      const T ni = (T(-0.5) * T(Num<T>::kExpArg)) * fast_rcp(c);
+      nin = on ? ni : T(0);
+      cen = mean;
+    }
   }
   template <typename V> struct RowT { V m[D], w; };  // the fields of one entry (V = T) or of two (packed pair)
   using Row = RowT<T>;
@@ -206,13 +229,25 @@ struct EvalUniform {
   // value = front * exp(exponent)
   template <typename V>
   __device__ __forceinline__ V exponent(const RowT<V> &r, V &front) const {
-    V acc = OFF ? V(xoff) : V(0);
+    V acc;
+    if constexpr (kUniformTwoOp<T>) {
+      acc = V(0);
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
-      const V dl = r.m[d] - center[d];
-      acc = Num<V>::fma(dl * dl, V(ninv[d]), acc);
+      for (int d = 0; d < D; ++d) {
+        const V t = Num<V>::fma(r.m[d], V(ninv[d]), -V(center[d]));
+        acc = Num<V>::fma(t, t, acc);
+      }
+      if constexpr (OFF) acc = clamp_hi(V(xoff) - acc, V(T(126)));
+      else acc = -acc;
+    } else {
+      acc = OFF ? V(xoff) : V(0);
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        const V dl = r.m[d] - center[d];
+        acc = Num<V>::fma(dl * dl, V(ninv[d]), acc);
+      }
+      if constexpr (OFF) acc = clamp_hi(acc, V(T(126)));
     }
-    if constexpr (OFF) acc = clamp_hi(acc, V(T(126)));
     // (no per-entry NaN test: on the fast paths every tile value is finite and positive, so a NaN can
     // only come from the wave-uniform centre/cov and then hits every entry -- handled on the total)
     front = r.w * scale;

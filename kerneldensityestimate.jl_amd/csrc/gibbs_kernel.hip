@@ -165,17 +165,18 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan_
         EvalUniform<T, D> ev;
         ev.tab = sExpTab;
         T c = hdr[dl] + cov;
-        T ni = (T(-0.5) * T(Num<T>::kExpArg)) * fast_rcp(c);
+        bool on = true;
         if constexpr (MASKED) {  // an inactive dimension contributes nothing: c = 1, weight 0
-          const bool on = (act >> dl) & 1u;
+          on = (act >> dl) & 1u;
           c = on ? c : T(1);
-          ni = on ? ni : T(0);
         }
+        T cen, nin;
+        EvalUniform<T, D>::operands(mean, c, on, cen, nin);
         T Pr = T(1);
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-          ev.center[d] = lane_read(mean, d);
-          ev.ninv[d] = lane_read(ni, d);
+          ev.center[d] = lane_read(cen, d);
+          ev.ninv[d] = lane_read(nin, d);
           Pr *= lane_read(c, d);
         }
         ev.scale = Num<T>::rsqrt(Pr);

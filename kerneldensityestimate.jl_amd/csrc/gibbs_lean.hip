@@ -189,12 +189,13 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
       EvalUniform<T, D> ev;
       ev.tab = sExpTab;
       const T c = hdr[dl] + cov;
-      const T ni = (T(-0.5) * T(Num<T>::kExpArg)) * fast_rcp(c);
+      T cen, nin;
+      EvalUniform<T, D>::operands(mean, c, true, cen, nin);
       T Pr = T(1);
 #pragma unroll
       for (int d = 0; d < D; ++d) {
-        ev.center[d] = lane_read(mean, d);
-        ev.ninv[d] = lane_read(ni, d);
+        ev.center[d] = lane_read(cen, d);
+        ev.ninv[d] = lane_read(nin, d);
         Pr *= lane_read(c, d);
       }
       ev.scale = Num<T>::rsqrt(Pr);

@@ -33,6 +33,7 @@ const char *last_error_cstr();
 // Padding entries (z >= n) carry weight 0, variance 1, mean 0 and never win a draw.
 // The LDS image of a tile is a byte copy of [hdr_off, hdr_off + stage_bytes).
 constexpr int kTileHeader = 8;
+constexpr double kMaxUniformRatio = 1e5;  // see pack_layout_shapes: when a shared-bandwidth frontier gets the compact tile
 enum StageMode : int32_t {
   kStageGlobal = 0,    // tile too large for LDS: wavefronts read it from global memory (L1/L2)
   kStageResident = 1,  // all densities' tiles of the level fit the LDS pool at once

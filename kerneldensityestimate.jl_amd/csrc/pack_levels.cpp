@@ -51,6 +51,7 @@ int expand_frontiers(const kdehip_density &t, int D, int L, bool look, Frontiers
   out.ids.reserve(static_cast<size_t>(N) * (L + 1) / 2 + 64);
   out.off.assign(static_cast<size_t>(L) + 2, 0);
   out.uniform.assign(static_cast<size_t>(L) + 1, 1);
+  out.uratio.assign(static_cast<size_t>(L) + 1, 0.0);
   out.bad = false;
   out.nodes = 0;
   for (int d = 0; d < KDEHIP_MAX_DIMS; ++d) { out.lo[d] = INFINITY; out.hi[d] = 0.0; }
@@ -107,6 +108,17 @@ int expand_frontiers(const kdehip_density &t, int D, int L, bool look, Frontiers
         if (v[d] != bw0[d]) uni = false;
     }
     out.uniform[l] = uni ? 1 : 0;
+    if (uni) {  // (all-leaf frontiers: scanned in full above anyway)
+      double ratio = 0.0;
+      for (size_t z = begin; z < out.ids.size(); ++z) {
+        const double *mu = t.means + (static_cast<int64_t>(out.ids[z]) - 1) * D;
+        for (int d = 0; d < D; ++d) {
+          const double r = std::fabs(mu[d]) / std::sqrt(2.0 * bw0[d]);
+          ratio = r > ratio ? r : ratio;   // (a NaN mean or a non-positive bandwidth: caught by `look` / pack_fill)
+        }
+      }
+      out.uratio[l] = ratio;
+    }
   }
   out.off[static_cast<size_t>(L) + 1] = static_cast<int64_t>(out.ids.size());
   out.bad = bad;
@@ -177,6 +189,7 @@ int pack_layout(int Ndens, const kdehip_density *trees, int ndims, const uint8_t
       out.front_off[idx] = base + fr.off[l];
       shapes[idx].n = fr.off[l + 1] - fr.off[l];
       shapes[idx].uniform = fr.uniform[l] != 0;
+      shapes[idx].uratio = fr.uratio[l];
     }
     nodes += fr.nodes;
     if (fr.bad) finite_ok = false;
@@ -236,7 +249,12 @@ int pack_layout_shapes(int M, int D, int L, const TileShape *shapes, const uint8
       const size_t idx = static_cast<size_t>(j) * (L + 1) + l;
       const int64_t n = shapes[idx].n;
       const int64_t B = (n + 63) / 64;
-      const bool uni = out.fast && shapes[idx].uniform;  // compact tiles only on the fast path
+      // compact tiles only on the fast path.  fp64: the shared-bandwidth evaluator forms (m - mu) * s as fma(m, s, -mu*s)
+      // (two instructions per dimension instead of three, gibbs_device.hpp EvalUniform), whose rounding error grows
+      // with |m| * s <= |m| / sqrt(2 bandwidth): 1e-16 * kMaxUniformRatio = 1e-11 in the scaled difference at the very
+      // most; frontiers beyond that (data 10^5 bandwidths away from the origin) keep the per-node form, which subtracts first
+      // (fp32 keeps the subtract-first form: no limit)
+      const bool uni = out.fast && shapes[idx].uniform && (precision == 32 || shapes[idx].uratio <= kMaxUniformRatio);
       const int F = uni ? D + 1 : 2 * D + 1;
       const int64_t RS = static_cast<int64_t>(F) * 64 + 1;
       LevelDesc &ds = out.levels[idx];

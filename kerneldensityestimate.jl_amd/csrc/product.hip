@@ -828,7 +828,7 @@ int layout_resident(int Ndens, kdehip_device_density *const *trees, const uint8_
     const kdehip_device_density &t = *trees[j];
     for (int l = 0; l <= L; ++l) {
       const int lj = l < t.Lown ? l : t.Lown;
-      shapes[static_cast<size_t>(j) * (L + 1) + l] = {t.fr.off[lj + 1] - t.fr.off[lj], t.fr.uniform[lj] != 0};
+      shapes[static_cast<size_t>(j) * (L + 1) + l] = {t.fr.off[lj + 1] - t.fr.off[lj], t.fr.uniform[lj] != 0, t.fr.uratio[lj]};
     }
     if (t.fr.bad) finite_ok = false;
     for (int d = 0; d < D; ++d) {

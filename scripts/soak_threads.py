@@ -33,6 +33,8 @@ for c in range(24):   # a pool of prepared problems with their single-threaded a
                      a=kdehip.prodAppxMSGibbsS(None, trees, None, None, Niter=Niter, Np=Np, seed=c),
                      b=kdehip.prodAppxMSGibbsS(None, trees, None, None, Niter=Niter, Np=Np, randU=randU, randN=randN),
                      e=trees[0](pos), bw=kdehip.auto_bandwidth(x), kd=kdehip.kde_auto(x, overlap=False)))
+for j in jobs[:6]:   # (a few of them: the resident `*` and its host twin)
+    j["mul"] = kdehip.mul(j["trees"], seed=j["seed"]) if max(t.bt.num_points for t in j["trees"]) <= 1000 else None
 
 
 def worker(t):
@@ -40,7 +42,7 @@ def worker(t):
     bad = 0
     for _ in range(ncalls):
         j = jobs[int(r.integers(0, len(jobs)))]
-        kind = int(r.integers(0, 7))
+        kind = int(r.integers(0, 9))
         if kind == 0:
             got = kdehip.prodAppxMSGibbsS(None, j["trees"], None, None, Niter=j["Niter"], Np=j["Np"], seed=j["seed"])
             ok = np.array_equal(got[0], j["a"][0]) and np.array_equal(got[1], j["a"][1])
@@ -65,6 +67,30 @@ def worker(t):
             st.synchronize()
             ok = all(np.array_equal(P.cpu().numpy().reshape(Np, D).T, j["a"][0]) and
                      np.array_equal(I.cpu().numpy().reshape(Np, M).T, j["a"][1]) for P, I in outs)
+        elif kind == 7:   # `*` on resident densities (kdehip_mul_device): product, bandwidth search, tree, upload -- per thread
+            if j.get("mul") is None:
+                continue
+            with kdehip.mul_device(j["dd"], seed=j["seed"]) as out:
+                got = out.download()
+            ok = all(np.array_equal(getattr(got, f), getattr(j["mul"], f)) for f in ("means", "bandwidth")) and \
+                all(np.array_equal(getattr(got.bt, f), getattr(j["mul"].bt, f)) for f in ("weights", "left_child", "permutation"))
+        elif kind == 8:   # several products in one batched call, on a stream of the thread's own
+            import torch
+            dev = torch.device("cuda", 0)
+            picks = [jobs[int(r.integers(0, len(jobs)))] for _ in range(int(r.integers(2, 6)))]
+            prods, want = [], []
+            for q in picks:
+                D, M, Np = q["trees"][0].bt.dims, len(q["trees"]), q["Np"]
+                P = torch.zeros(D * Np, dtype=torch.float64, device=dev)
+                I = torch.zeros(M * Np, dtype=torch.int64, device=dev)
+                prods.append(dict(trees=q["dd"], d_points=P, d_indices=I, Np=Np, Niter=q["Niter"], seed=q["seed"]))
+                want.append((q["a"], Np, D, M))
+            torch.cuda.synchronize()
+            st = torch.cuda.Stream(device=dev)
+            kdehip.prodAppxMSGibbsS_batch(prods, stream=st.cuda_stream)
+            st.synchronize()
+            ok = all(np.array_equal(pr["d_points"].cpu().numpy().reshape(Np, D).T, a[0]) and
+                     np.array_equal(pr["d_indices"].cpu().numpy().reshape(Np, M).T, a[1]) for pr, (a, Np, D, M) in zip(prods, want))
         elif kind == 5:   # kde!(points): the worker pool of the host tree builder is shared by every caller
             got = kdehip.kde_auto(j["x"], overlap=bool(r.integers(0, 2)))
             ok = all(np.array_equal(getattr(got, f), getattr(j["kd"], f)) for f in ("means", "bandwidth")) and \

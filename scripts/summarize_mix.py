@@ -14,7 +14,14 @@ kernel = sys.argv[2] if len(sys.argv) > 2 else "gibbs_lean_kernel"
 src = os.path.join(ROOT, "gpurun_out", f"mix_{tag}")
 
 counters, durs, waves = {}, [], None
-for path in glob.glob(os.path.join(src, "*", "*", "*counter_collection.csv")):
+# (rocprofv3 also traces bench.py's cold-start children, which run small products of their own: per counter pass keep the
+# largest csv, the bench process itself)
+paths = []
+for passdir in sorted(glob.glob(os.path.join(src, "*", ""))):
+    files = glob.glob(os.path.join(passdir, "*", "*counter_collection.csv"))
+    if files:
+        paths.append(max(files, key=os.path.getsize))
+for path in paths:
     acc = {}
     with open(path) as f:
         for row in csv.DictReader(f):

@@ -26,9 +26,16 @@ def modal_grid(rows, key):
     return max(c, key=c.get) if c else None
 
 
+def main_process(files):
+    """rocprofv3 also traces child processes (bench.py's cold-start children run small products of their own): one set of
+    csv files per process id -- keep the largest, the bench process itself."""
+    files = list(files)
+    return [max(files, key=os.path.getsize)] if files else []
+
+
 def counters(d, sub, match):
     acc = defaultdict(list)
-    for f in glob.glob(os.path.join(d, sub, "*", "*_counter_collection.csv")):
+    for f in main_process(glob.glob(os.path.join(d, sub, "*", "*_counter_collection.csv"))):
         rows = [r for r in csv.DictReader(open(f)) if match in r["Kernel_Name"]]
         grid = modal_grid(rows, "Grid_Size")
         for r in rows:
@@ -49,12 +56,12 @@ def main():
     calib = float(sys.argv[4]) if len(sys.argv) > 4 else 2.0
     d = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     stats = []
-    for f in glob.glob(os.path.join(d, "stats", "*", "*_kernel_stats.csv")):
+    for f in main_process(glob.glob(os.path.join(d, "stats", "*", "*_kernel_stats.csv"))):
         stats += list(csv.DictReader(open(f)))
     krow = next(r for r in stats if match in r["Name"])
     # per-dispatch durations from the kernel trace, sampling launches only (see modal_grid)
     trace = []
-    for f in glob.glob(os.path.join(d, "stats", "*", "*_kernel_trace.csv")):
+    for f in main_process(glob.glob(os.path.join(d, "stats", "*", "*_kernel_trace.csv"))):
         trace += [r for r in csv.DictReader(open(f)) if match in r["Kernel_Name"]]
     gkey = "Grid_Size" if trace and "Grid_Size" in trace[0] else ("Grid_Size_X" if trace and "Grid_Size_X" in trace[0] else None)
     durs = []

@@ -237,3 +237,34 @@ def test_malformed_tree_is_refused_with_its_message(N):
     with kdehip.ProductPlan(good) as plan:   # (and the pool is none the worse for it)
         p, i = plan.sample(64, Niter=1, seed=2)
         assert np.isfinite(p).all()
+
+
+@pytest.mark.parametrize("offset,expect_compact", [(0.0, True), (3.0e3, True), (4.0e7, False)])
+def test_shared_bandwidth_evaluator_far_from_the_origin(offset, expect_compact):
+    """The fp64 shared-bandwidth evaluator forms (m - mu) s as fma(m, s, -mu s): two instructions per dimension, and a
+    rounding error that grows with |m| s (csrc/gibbs_device.hpp EvalUniform).  The packer therefore gives a leaf frontier
+    the compact shared-bandwidth tile only while |m| / sqrt(2 bandwidth) <= 1e5 (csrc/pack_levels.cpp) and keeps the
+    per-node form, which subtracts first, beyond: data thousands of bandwidths away from the origin still give the
+    oracle's labels either way."""
+    rng = np.random.default_rng(17)
+    D, M, N, Np, Niter = 3, 3, 700, 200, 3
+    g, o = [], []
+    for j in range(M):
+        pts = rng.standard_normal((D, N)) * 0.8 + rng.uniform(-1, 1, size=(D, 1)) + offset
+        ks = np.full(D, 0.25)
+        a, b = _pair(pts, ks)
+        g.append(a)
+        o.append(b)
+    with kdehip.ProductPlan(g) as plan:
+        # (compact leaf tiles carry D + 1 fields per node instead of 2 D + 1: the plan's size tells which it got)
+        size = plan.packed_bytes
+        K, R = plan.randu_per_sample(Niter), plan.randn_per_sample()
+        randU, randN = kdehip.philox_streams(5, 0, Np, K, R)
+        got = plan.sample(Np, Niter=Niter, seed=5)
+    g0 = [kdehip.kde(t_pts, [0.25]) for t_pts in [kdehip.getPoints(t) - offset for t in g]]
+    with kdehip.ProductPlan(g0) as plan0:
+        size0 = plan0.packed_bytes
+    assert (size == size0) == expect_compact, (size, size0)
+    ref = oracle.gibbs1(o, Np, Niter, randU, randN)
+    assert np.array_equal(got[1], ref[1])
+    assert np.allclose(got[0], ref[0], rtol=1e-9, atol=1e-6)
