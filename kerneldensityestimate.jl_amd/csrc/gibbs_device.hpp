@@ -424,6 +424,19 @@ struct EvalGeneric {
   static constexpr bool kPairs = false;
 };
 
+// Issue priority of this wavefront on its SIMD (s_setprio): the latency-bound phases of a step (set-up, scan, selection,
+// adoption) run at high priority, the rows -- throughput work -- at low, so that a wavefront in a dependent chain is
+// served at once while its partner streams rows: oldest-first arbitration alone lets the OLDER wavefront's rows hold up the
+// younger one's chain.  Config 3, 2048 chains: 0.6047 -> 0.5840 ms (interleaved A/B, profiles/r04_experiments.md); config 5
+// -1 %; config 4 and 16-chain workgroups unchanged.  (-DKDEHIP_X_NO_SETPRIO: A/B builds without it.)
+#ifndef KDEHIP_X_NO_SETPRIO
+#define KDEHIP_PRIO_ROWS() __builtin_amdgcn_s_setprio(0)
+#define KDEHIP_PRIO_CHAIN() __builtin_amdgcn_s_setprio(3)
+#else
+#define KDEHIP_PRIO_ROWS() do {} while (0)
+#define KDEHIP_PRIO_CHAIN() do {} while (0)
+#endif
+
 // ---- one categorical label draw over a frontier -------------------------------------------------
 // Evaluates every node of the frontier with `ev`, and returns the tile position (row*64 + lane) of
 // the entry selected by the uniform draw `u`: the first z with u <= cdf[z], else the last
@@ -674,16 +687,18 @@ __device__ __forceinline__ int select_from_scan(T incl, T S, P rows, const DS &d
 // and no second wavefront scan -- every lane forms the running sums of its own block (the same sequential
 // sums the first pass accumulates), finds the first row that reaches the target, and the answer is read from
 // the winning lane.  (Rows beyond B are padding of weight 0 in the tile; they are not even evaluated.)
+// (`ra`: the lane's row 0, already requested by the caller -- a step's first row does not depend on the chain's state, so
+// gibbs_lean.hip asks for it before the leave-one-out product and the broadcasts)
 template <typename T, typename P, typename Eval, int BMAX, typename DS>
 __device__ __forceinline__ int draw_label_kept(P rows, const DS &ds, int lane, const Eval &ev, double u,
-                                               const void *fb) {
+                                               const void *fb, typename Eval::Row ra) {
   const int n = ds.n, B = ds.B, F = ds.F;
   const int RS = F * 64 + 1;
   T v[BMAX];
   P e = rows + lane;
   // first pass: the two-rows-per-trip schedule of lane_sum_rows (next row requested early, the two rows
   // interleaved around their exp table lookups), fully unrolled so that the values stay in registers
-  typename Eval::Row ra = ev.load(e);
+  KDEHIP_PRIO_ROWS();
 #pragma unroll
   for (int i = 0; i < BMAX; i += 2) {
     if (i + 2 <= B) {  // wave-uniform
@@ -704,6 +719,7 @@ __device__ __forceinline__ int draw_label_kept(P rows, const DS &ds, int lane, c
       v[i + 1] = T(0);
     }
   }
+  KDEHIP_PRIO_CHAIN();
   // the canonical lane sum (LaneAcc): a_k over the rows = k (mod 4); the rows beyond B add an exact +0
   T ak[4];
 #pragma unroll
@@ -753,6 +769,10 @@ __device__ __forceinline__ int draw_label_kept(P rows, const DS &ds, int lane, c
   int istar = __builtin_amdgcn_readlane(first, lstar);
   if (istar > len - 1) istar = len - 1;  // no row reached the target (rounding), or only padding rows did
   return istar * 64 + lstar;
+}
+template <typename T, typename P, typename Eval, int BMAX, typename DS>
+__device__ __forceinline__ int draw_label_kept(P rows, const DS &ds, int lane, const Eval &ev, double u, const void *fb) {
+  return draw_label_kept<T, P, Eval, BMAX>(rows, ds, lane, ev, u, fb, ev.load(rows + lane));
 }
 
 // fp32: the evaluation is repeated with every exponent raised by 110, 220, 330 binades while the sum stays below
@@ -877,7 +897,9 @@ __device__ __forceinline__ int draw_label(P rows, const DS &ds, int lane, const 
   }
 #endif
   KSTAMP(tp0);
+  KDEHIP_PRIO_ROWS();
   const T S = lane_sum_rows<T, P, Eval, PREFETCH>(rows, ds.B, ds.F * 64 + 1, lane, ev);
+  KDEHIP_PRIO_CHAIN();
   KSTAMP(tp1);
   KSTAMP_ADD(2, tp0, tp1);
   return select_or_raise<T, P>(S, rows, ds, lane, ev, u, fb KSTAMP_ARGS);

@@ -245,6 +245,7 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan_
       const int cps = seg_chunks(ds.seg);
       const bool use_seg = cps != 0;
       int cin = 0;
+      KDEHIP_PRIO_ROWS();
       for (int r0 = 0; r0 < ds.B; r0 += rc, ++gchunk) {
         staging_barrier();  // this chunk has landed for every wavefront; the other half is free again
         if (r0 + rc < ds.B) stage_chunk(ds, r0 + rc, (gchunk + 1) & 1);
@@ -254,6 +255,7 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan_
             (LdsPtr<T>)(pool + (gchunk & 1) * (kLdsPoolBytes / 2)), nrows, RS, lane, ev, acc);
         if (use_seg && ++cin == cps) { seg.note(acc.total()); cin = 0; }  // the lane's running sum at a segment boundary
       }
+      KDEHIP_PRIO_CHAIN();
       const T S = acc.total();
       // (a raised repeat of the evaluation reads the tile from global memory: no staging, no barriers)
       if (use_seg)

@@ -16,6 +16,9 @@
 // Results: labels identical to gibbs_kernel.hip and to the oracle, points bit-identical to gibbs_kernel.hip
 // (same reciprocal / product forms) -- tested (tests/test_gpu_lean.py).
 #define KDEHIP_EXP256 1
+#ifndef KDEHIP_PRELOAD_MAXB
+#define KDEHIP_PRELOAD_MAXB 8   // rows per lane up to which a resident step requests its first row ahead (see `step`)
+#endif
 #ifndef KDEHIP_WITH_TEAMS
 #define KDEHIP_WITH_TEAMS 0
 #endif
@@ -113,6 +116,7 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  KDEHIP_PRIO_CHAIN();
   // team geometry: chains of a workgroup = WAVES / team size; member 0 of a team owns the chain's outputs
   int tsize = 1;
   if constexpr (kTeams) tsize = a.team == 4 ? 4 : (a.team == 2 ? 2 : 1);
@@ -150,8 +154,21 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
   // ---- the chain's normal deviates, once (samplePoint! consumes D per level + D at the end, :440-463) ----
   double *sNorm = reinterpret_cast<double *>(smem + kNormOff) + chain * kLeanMaxNormals;
   const int R = D * (L + 1);
+#ifdef KDEHIP_X_OLDNORMALS
   for (int r = lane + 64 * tmember; r < R; r += 64 * tsize)
     sNorm[r] = a.rng_philox ? philox_normal(a.seed, gs, static_cast<uint32_t>(r)) : a.randN[s * a.R + r];
+#else
+  if (a.rng_philox) {  // a lane makes BOTH normals of a Philox block (one logarithm, one sine/cosine pair for two)
+    for (int b = lane + 64 * tmember; 2 * b < R; b += 64 * tsize) {
+      double n0, n1;
+      philox_normal_pair(a.seed, gs, static_cast<uint32_t>(b), n0, n1);
+      sNorm[2 * b] = n0;
+      if (2 * b + 1 < R) sNorm[2 * b + 1] = n1;
+    }
+  } else {
+    for (int r = lane + 64 * tmember; r < R; r += 64 * tsize) sNorm[r] = a.randN[s * a.R + r];
+  }
+#endif
   __syncthreads();  // (exp table; the strip is only read by its own chain's wavefronts)
 
   // ---- chain state: selected kernel of every density, lanes = dimensions ----
@@ -264,6 +281,43 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
   // one (pass, density) step on a tile readable through one pointer: leave-one-out product (sweeps) or the point
   // just drawn (sampleIndices! pass, :364-385), the draw, and the new kernel
   auto step = [&](auto jc, const auto &ds, auto hdr, bool first, T x) {
+#ifndef KDEHIP_X_NO_PRELOAD
+    // Frontiers with per-node bandwidths whose tile sits in LDS for the whole level, up to KEPT rows per lane (config 3:
+    // levels 5..8 and the first pass of 1..4): the fields of the lane's first row do not depend on the chain's state, so
+    // they are requested FIRST and land while the leave-one-out product and the broadcasts run -- a single-row step is
+    // one dependent chain, and this takes an LDS round trip out of it (0.5831 -> 0.5745 ms at config 3 with the
+    // single-row case alone, profiles/r04_experiments.md).
+    if constexpr (kIsLdsPtr<decltype(hdr + kTileHeader)> && sizeof(T) == 8 && !kTeams && kKeptRows && kPrefetchRows) {
+      if (!ds.uniform_bw && ds.B <= KDEHIP_PRELOAD_MAXB) {
+        auto rows1 = hdr + kTileHeader;
+        using P1 = decltype(rows1);
+        using Ev = EvalFast<T, D, false>;
+        Ev ev;
+        ev.tab = sExpTab;
+        ev.act = 0;
+        const typename Ev::Row row = ev.load(rows1 + lane);
+        T mean1 = x, cov1 = T(0);
+        if (!first) product(jc, mean1, cov1);
+        const double u1 = next_uniform();
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+          ev.center[d] = lane_read(mean1, d);
+          ev.cov[d] = lane_read(cov1, d);
+        }
+        int pos1;
+        if (ds.B == 1) {
+          const T S = ev(row);  // (= LaneAcc's total of a one-row lane: (v + 0) + (0 + 0))
+          pos1 = select_or_raise<T, P1>(S, rows1, ds, lane, ev, u1, fb);
+        } else if (ds.B <= 4) {
+          pos1 = draw_label_kept<T, P1, Ev, 4>(rows1, ds, lane, ev, u1, fb, row);
+        } else {
+          pos1 = draw_label_kept<T, P1, Ev, 8>(rows1, ds, lane, ev, u1, fb, row);
+        }
+        adopt(jc, ds, hdr, __builtin_amdgcn_readfirstlane(pos1));
+        return;
+      }
+    }
+#endif
     T mean = x, cov = T(0);
     if (!first) product(jc, mean, cov);
     const double u = next_uniform();
@@ -416,6 +470,7 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
             // (a chunked level is always a shared one, and the team instantiation only runs with teams: lean_geometry)
             constexpr bool shared = kTeams;
             int cin = 0;
+            KDEHIP_PRIO_ROWS();
             for (int r0 = 0; r0 < ds.B; r0 += rc, ++gchunk) {
               staging_barrier();  // this chunk has landed for every wavefront; the other half is free again
               if (r0 + rc < ds.B) stage_chunk(ds, r0 + rc, (gchunk + 1) & 1);
@@ -430,6 +485,7 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
               // the lane's running sum (a member: its share of it) at a segment boundary
               if (use_seg && ++cin == cps) { seg.note(shared ? mx + my : acc.total()); cin = 0; }
             }
+            KDEHIP_PRIO_CHAIN();
             if constexpr (kTeams) {
               if (shared) {
                 const T S = team_combine(mx + my, lane, team, /*pre_barrier=*/false);

@@ -72,4 +72,16 @@ KDEHIP_HD double philox_normal(uint64_t seed, uint64_t sample, uint32_t r) {
   return (r & 1u) ? rad * sin(ang) : rad * cos(ang);
 }
 
+// both normals of block `b` (normals 2b and 2b+1) from ONE Philox block, logarithm and sine/cosine pair: the same
+// numbers as philox_normal(.., 2b) and philox_normal(.., 2b+1)
+KDEHIP_HD void philox_normal_pair(uint64_t seed, uint64_t sample, uint32_t b, double &even, double &odd) {
+  const Philox4 blk = philox_block(seed, sample, b, 1u);
+  const double u1 = bits_to_unit(blk.v[0], blk.v[1]);
+  const double u2 = bits_to_unit(blk.v[2], blk.v[3]);
+  const double rad = sqrt(-2.0 * log(u1));
+  const double ang = 6.283185307179586476925286766559 * u2;
+  even = rad * cos(ang);
+  odd = rad * sin(ang);
+}
+
 }  // namespace kdehip

@@ -1,6 +1,6 @@
 # final evidence run of round 4 (GPU box): suite, soaks, bench lines, rocprofv3 summaries, per-level table
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r04f; mkdir -p $O
+TAG=${TAG:-r04f}; O=gpurun_out/$TAG; mkdir -p $O
 timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -6 > $O/tests.log; cat $O/tests.log
 python bench.py --steps 400 --warmup 20 > $O/bench_c3.json 2> $O/bench.err
 python bench.py --steps 20 --warmup 5 > $O/bench_c3_driver_form.json 2>> $O/bench.err
@@ -24,12 +24,12 @@ python scripts/loocv_timing.py 20 > $O/loocv.txt 2>&1
   timeout 600 python scripts/soak_determinism.py 1500 6 2>&1 | tail -1
   timeout 600 python scripts/soak_callers.py 1500 2>&1 | tail -1 ) > $O/soaks.txt 2>&1
 cat $O/soaks.txt
-bash scripts/profile_gpu.sh r04f3 > $O/prof_c3.log 2>&1
-bash scripts/profile_gpu.sh r04f4 --config c4 > $O/prof_c4.log 2>&1
-bash scripts/profile_gpu.sh r04f5 --config c5 --steps 6 > $O/prof_c5.log 2>&1
-bash scripts/valu_mix.sh r04f3 > $O/mix_c3.log 2>&1
-bash scripts/valu_mix.sh r04f4 --config c4 > $O/mix_c4.log 2>&1
-bash scripts/valu_mix.sh r04f5 --config c5 --steps 6 > $O/mix_c5.log 2>&1
+bash scripts/profile_gpu.sh ${TAG}3 > $O/prof_c3.log 2>&1
+bash scripts/profile_gpu.sh ${TAG}4 --config c4 > $O/prof_c4.log 2>&1
+bash scripts/profile_gpu.sh ${TAG}5 --config c5 --steps 6 > $O/prof_c5.log 2>&1
+bash scripts/valu_mix.sh ${TAG}3 > $O/mix_c3.log 2>&1
+bash scripts/valu_mix.sh ${TAG}4 --config c4 > $O/mix_c4.log 2>&1
+bash scripts/valu_mix.sh ${TAG}5 --config c5 --steps 6 > $O/mix_c5.log 2>&1
 if [ -f kerneldensityestimate.jl_amd/libkdehip_exp.so ]; then
   bash scripts/level_profile.sh kerneldensityestimate.jl_amd/libkdehip_exp.so > $O/level_insts.txt 2> $O/level_insts.err
   KDEHIP_LIB=$PWD/kerneldensityestimate.jl_amd/libkdehip_exp.so python scripts/level_timing2.py c3 0 > $O/level_timing.txt 2>&1
