@@ -894,6 +894,7 @@ __device__ __forceinline__ int draw_label(P rows, const DS &ds, int lane, const 
   if constexpr (PREFETCH && kIsLdsPtr<P> && sizeof(T) == 8 && kKeptRows) {
     if (ds.B > 1 && ds.B <= 4) return draw_label_kept<T, P, Eval, 4>(rows, ds, lane, ev, u, fb);
     if (ds.B > 4 && ds.B <= 8) return draw_label_kept<T, P, Eval, 8>(rows, ds, lane, ev, u, fb);
+
   }
 #endif
   KSTAMP(tp0);

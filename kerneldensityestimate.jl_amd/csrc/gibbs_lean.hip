@@ -90,6 +90,9 @@ struct LeanTile {
   }
 };
 
+// (see `step`: the builds with registers to spare and the kept-rows second pass, on tiles that sit in LDS)
+template <typename P, typename T, bool OK> constexpr bool kCanPreloadImpl = OK && kIsLdsPtr<P> && sizeof(T) == 8;
+
 // TEAMS: the instantiation whose wavefronts can form teams (RunArgs.team = 2 or 4; 16-wavefront fp64 builds).  A kernel
 // of its own: with the team paths compiled in, a 16-wavefront build is up to 25 % slower even when every chain has one
 // wavefront (config 4 with 16,384 chains: 31 -> 39 ms), and that is the build large batches run.
@@ -100,6 +103,7 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
   const auto &a = view.a;
   constexpr bool kPrefetchRows = (WAVES <= 12) || sizeof(T) == 4 || D <= 4;  // as in gibbs_kernel.hip
   constexpr bool kKeptRows = (WAVES <= 8);
+  constexpr bool kPreloadBuild = kKeptRows && kPrefetchRows && !(TEAMS && WAVES == 16);
   // wavefront teams (a chain on 2 or 4 wavefronts, RunArgs.team): the 16-wavefront fp64 builds
   constexpr bool kTeams = TEAMS && (WAVES == 16) && sizeof(T) == 8;
   // LDS: [exp table 2 KiB][normals: 1 KiB per chain; teams: the partial-sum strips in the upper half][uniforms:
@@ -278,42 +282,47 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
     return draw_label<T, P, kPrefetchRows, kKeptRows>(rows, ds, lane, ev, u, fb);
   };
 
+  // a step on an LDS tile with per-node bandwidths and at most 8 rows per lane whose first row `row` has been requested
+  // already: broadcasts, the kept-rows draw (or the single-row one), adoption
+  auto step_kept = [&](auto jc, const auto &ds, auto hdr, const auto &row, T mean, T cov, double u) {
+    auto rows1 = hdr + kTileHeader;
+    using P1 = decltype(rows1);
+    using Ev = EvalFast<T, D, false>;
+    Ev ev;
+    ev.tab = sExpTab;
+    ev.act = 0;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      ev.center[d] = lane_read(mean, d);
+      ev.cov[d] = lane_read(cov, d);
+    }
+    int pos1;
+    if (ds.B == 1) {
+      const T S = ev(row);  // (= LaneAcc's total of a one-row lane: (v + 0) + (0 + 0))
+      pos1 = select_or_raise<T, P1>(S, rows1, ds, lane, ev, u, fb);
+    } else if (ds.B <= 4) {
+      pos1 = draw_label_kept<T, P1, Ev, 4>(rows1, ds, lane, ev, u, fb, row);
+    } else {
+      pos1 = draw_label_kept<T, P1, Ev, 8>(rows1, ds, lane, ev, u, fb, row);
+    }
+    adopt(jc, ds, hdr, __builtin_amdgcn_readfirstlane(pos1));
+  };
+
   // one (pass, density) step on a tile readable through one pointer: leave-one-out product (sweeps) or the point
   // just drawn (sampleIndices! pass, :364-385), the draw, and the new kernel
   auto step = [&](auto jc, const auto &ds, auto hdr, bool first, T x) {
 #ifndef KDEHIP_X_NO_PRELOAD
-    // Frontiers with per-node bandwidths whose tile sits in LDS for the whole level, up to KEPT rows per lane (config 3:
-    // levels 5..8 and the first pass of 1..4): the fields of the lane's first row do not depend on the chain's state, so
-    // they are requested FIRST and land while the leave-one-out product and the broadcasts run -- a single-row step is
-    // one dependent chain, and this takes an LDS round trip out of it (0.5831 -> 0.5745 ms at config 3 with the
-    // single-row case alone, profiles/r04_experiments.md).
-    if constexpr (kIsLdsPtr<decltype(hdr + kTileHeader)> && sizeof(T) == 8 && !kTeams && kKeptRows && kPrefetchRows) {
+    // Frontiers with per-node bandwidths whose tile sits in LDS for the whole level, up to KDEHIP_PRELOAD_MAXB rows per
+    // lane (config 3: levels 5..8 and the first pass of 1..4): the fields of the lane's first row do not depend on the
+    // chain's state, so they are requested FIRST and land while the leave-one-out product and the broadcasts run -- a
+    // single-row step is one dependent chain, and this takes an LDS round trip out of it (profiles/r04_experiments.md).
+    if constexpr (kCanPreloadImpl<decltype(hdr + kTileHeader), T, kPreloadBuild>) {
       if (!ds.uniform_bw && ds.B <= KDEHIP_PRELOAD_MAXB) {
-        auto rows1 = hdr + kTileHeader;
-        using P1 = decltype(rows1);
-        using Ev = EvalFast<T, D, false>;
-        Ev ev;
-        ev.tab = sExpTab;
-        ev.act = 0;
-        const typename Ev::Row row = ev.load(rows1 + lane);
+        const auto row = EvalFast<T, D, false>().load(hdr + kTileHeader + lane);
         T mean1 = x, cov1 = T(0);
         if (!first) product(jc, mean1, cov1);
         const double u1 = next_uniform();
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-          ev.center[d] = lane_read(mean1, d);
-          ev.cov[d] = lane_read(cov1, d);
-        }
-        int pos1;
-        if (ds.B == 1) {
-          const T S = ev(row);  // (= LaneAcc's total of a one-row lane: (v + 0) + (0 + 0))
-          pos1 = select_or_raise<T, P1>(S, rows1, ds, lane, ev, u1, fb);
-        } else if (ds.B <= 4) {
-          pos1 = draw_label_kept<T, P1, Ev, 4>(rows1, ds, lane, ev, u1, fb, row);
-        } else {
-          pos1 = draw_label_kept<T, P1, Ev, 8>(rows1, ds, lane, ev, u1, fb, row);
-        }
-        adopt(jc, ds, hdr, __builtin_amdgcn_readfirstlane(pos1));
+        step_kept(jc, ds, hdr, row, mean1, cov1, u1);
         return;
       }
     }
@@ -434,6 +443,8 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
           if (active) {
             auto hdr = (LdsPtr<T>)(pool + (t & 1) * (kLdsPoolBytes / 2));
             auto rows = hdr + kTileHeader;
+            // (requesting the first row ahead of the broadcasts here, as the resident steps do, was measured: no gain --
+            // 0.5825 vs 0.5811 ms)
             const int pos = __builtin_amdgcn_readfirstlane(draw(ds, hdr, mean, cov, [&](const auto &ev) {
               return draw_rows(ds, rows, ev, u, /*pre_barrier=*/false);  // (the step's staging barrier separates the exchanges)
             }));
