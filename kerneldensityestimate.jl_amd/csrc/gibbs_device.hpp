@@ -282,6 +282,22 @@ struct EvalUniform {
   }
 };
 
+// sum over dimensions [LO, HI) of d2[d] / c[d] as one fraction n / e (EvalFast)
+template <typename V, int LO, int HI>
+__device__ __forceinline__ void fraction_sum(const V *d2, const V *c, V &n, V &e) {
+  if constexpr (HI - LO == 1) {
+    n = d2[LO];
+    e = c[LO];
+  } else {
+    constexpr int MID = LO + (HI - LO + 1) / 2;
+    V na, ea, nb, eb;
+    fraction_sum<V, LO, MID>(d2, c, na, ea);
+    fraction_sum<V, MID, HI>(d2, c, nb, eb);
+    n = Num<V>::fma(na, eb, nb * ea);
+    e = ea * eb;
+  }
+}
+
 // FAST: per-node bandwidths; one rsqrt instead of D divides and D logs.
 template <typename T, int D, bool MASKED, bool OFF = false>
 struct EvalFast {
@@ -321,7 +337,14 @@ struct EvalFast {
       }
     }
     const V w = row.w;
-    // pre[d]*suf[d] = prod_{k != d} c[k]; P = prod_k c[k]
+#ifndef KDEHIP_X_PREFIXPROD
+    // sum_d d2[d] / c[d] as ONE fraction num / prod, by pairwise addition of fractions n_a/e_a + n_b/e_b =
+    // (n_a e_b + n_b e_a) / (e_a e_b) over a balanced tree: 3 (D - 1) instructions (round 4; D = 6: 15, where the
+    // prefix/suffix products below take 19 -- c3 -1.5 %, c4 -1.3 %, c5 -1.4 %, profiles/r04_experiments.md)
+    V num, prod;
+    fraction_sum<V, 0, D>(d2, c, num, prod);
+#else
+    // (rounds 1-3) pre[d]*suf[d] = prod_{k != d} c[k]; P = prod_k c[k]
     V pre[D], suf[D];
     pre[0] = V(1);
 #pragma unroll
@@ -333,6 +356,7 @@ struct EvalFast {
     V num = V(0);
 #pragma unroll
     for (int d = 0; d < D; ++d) num = Num<V>::fma(d2[d], pre[d] * suf[d], num);
+#endif
     const V r = Num<V>::rsqrt(prod);
     const V q = num * r * r;  // = sum_d delta_d^2 / c_d
     front = w * r;

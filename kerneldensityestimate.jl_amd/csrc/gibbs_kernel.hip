@@ -36,8 +36,8 @@
 //   UNIFORM  levels whose nodes share one bandwidth vector (every leaf level): the D reciprocals and
 //            the normalisation are wave-uniform and hoisted; per node D subtracts, D multiplies,
 //            D fused multiply-adds and one exp;
-//   FAST     p = w * rsqrt(prod_d c_d) * exp(-1/2 * sum_d delta_d^2 / c_d), the D reciprocals
-//            obtained from ONE rsqrt via prefix/suffix products -- no divide, no log;
+//   FAST     p = w * rsqrt(prod_d c_d) * exp(-1/2 * sum_d delta_d^2 / c_d), the sum formed as ONE fraction
+//            over prod_d c_d (pairwise addition of fractions) and ONE rsqrt -- no divide, no log;
 //   GENERIC  the reference's own per-dimension divide + log with its NaN rules (:287-303), used for
 //            inputs whose variance products could leave the range of T or are not finite/positive.
 // partialDimMask products (and one-density "products") run UNIFORM/FAST with the inactive dimensions
