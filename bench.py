@@ -102,6 +102,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-spin-up", action="store_true",
+                    help="skip the 40 ms of resident-plan launches that bring the device's clock up before the warm-up steps")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--nout", type=int, default=0, help="override chains per GPU (experiments; 0 = the config's)")
     ap.add_argument("--strong", action="store_true",
@@ -197,6 +199,22 @@ def main():
                 bufs["pending"] = None
         torch.cuda.synchronize()
 
+    # The device idled while the host built the inputs, and its power manager takes ~20 ms of continuous work to bring the
+    # clock back up (scripts/step_transient.py: 700 -> 590 us per config-3 call over the first 35 calls after 2 s of idle):
+    # a SHORT run (--steps 20 --warmup 5 = 15 ms) would sit on that ramp.  So the device is first kept busy for 40 ms with
+    # launches of ONE resident plan -- not warm-up steps of the measured call path, and reported as `spin_up`.
+    spin_up = {"launches": 0, "ms": 0.0}
+    if not args.no_spin_up and hi > lo:
+        ts = time.perf_counter()
+        while time.perf_counter() - ts < 0.040:
+            for _ in range(4):
+                plan.sample_philox_device(hi - lo, Niter, seed, lo, True, slots[0]["pts"], slots[0]["ind"], None, stream.cuda_stream)
+            torch.cuda.synchronize()
+            spin_up["launches"] += 4
+        spin_up["ms"] = (time.perf_counter() - ts) * 1e3
+    spin_up["what"] = ("untimed launches of one resident plan before the warm-up steps: the device's clock is back at its "
+                       "sustained value when the W warm-up steps start (--no-spin-up: without)")
+
     for i in range(args.warmup):
         one_call(i)
     drain()
@@ -279,6 +297,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "spin_up": spin_up,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "strong" if args.strong else "weak",
