@@ -165,16 +165,13 @@ template <typename P> constexpr bool kIsLdsPointer = false;
 template <typename T> constexpr bool kIsLdsPointer<const __attribute__((address_space(3))) T *> = true;
 
 // ---- kernel evaluation of one frontier entry -----------------------------------------------------
-// `e` points at (row, field 0, lane) of the entry (LDS or global pointer); field f is at e[f*64].
+// `e` points at (row, field 0, lane) of the entry (LDS or global pointer); field f is at e[f * TileAddr<T>::kField].
 
-// A load the compiler may not merge with its neighbours: the two halves of a packed fp32 pair come from two
-// rows; merged ds_read2 loads of two FIELDS of one row would land in the wrong register pairing and cost a
-// v_mov per value to untangle.
+// The two rows of a pair for one (field, lane), as ONE 8-byte load (fp32 tiles keep them adjacent: TileAddr): the
+// register pair the packed first pass works on, from one ds_read_b64 (2 LDS cycles; two ds_read_b32 take 4).
 template <typename P>
-__device__ __forceinline__ float load_single(P p) {
-  using E = std::remove_pointer_t<P>;
-  using VP = std::conditional_t<kIsLdsPointer<P>, volatile __attribute__((address_space(3))) const float *, volatile const float *>;
-  (void)sizeof(E);
+__device__ __forceinline__ kdehip_f2 load_pair(P p) {
+  using VP = std::conditional_t<kIsLdsPointer<P>, const __attribute__((address_space(3))) kdehip_f2 *, const kdehip_f2 *>;
   return *(VP)(p);
 }
 
@@ -222,8 +219,8 @@ struct EvalUniform {
   __device__ __forceinline__ Row load(P e) const {
     Row r;
 #pragma unroll
-    for (int d = 0; d < D; ++d) r.m[d] = e[d * 64];
-    r.w = e[D * 64];
+    for (int d = 0; d < D; ++d) r.m[d] = e[d * TileAddr<T>::kField];
+    r.w = e[D * TileAddr<T>::kField];
     return r;
   }
   // value = front * exp(exponent)
@@ -273,11 +270,11 @@ struct EvalUniform {
   __device__ __forceinline__ T operator()(P e) const { return (*this)(load(e)); }
   static constexpr bool kPairs = true;
   template <typename P>
-  __device__ __forceinline__ kdehip_f2 pair(P e, int RS) const {  // entries at e and e + RS
+  __device__ __forceinline__ kdehip_f2 pair(P e) const {  // the entries of rows 2p and 2p+1; e = row 2p's
     RowT<kdehip_f2> r;
 #pragma unroll
-    for (int d = 0; d < D; ++d) r.m[d] = kdehip_f2{load_single(e + d * 64), load_single(e + RS + d * 64)};
-    r.w = kdehip_f2{load_single(e + D * 64), load_single(e + RS + D * 64)};
+    for (int d = 0; d < D; ++d) r.m[d] = load_pair(e + d * TileAddr<T>::kField);
+    r.w = load_pair(e + D * TileAddr<T>::kField);
     return eval<kdehip_f2>(r);
   }
 };
@@ -318,8 +315,8 @@ struct EvalFast {
   __device__ __forceinline__ Row load(P e) const {
     Row r;
 #pragma unroll
-    for (int d = 0; d < D; ++d) { r.m[d] = e[d * 64]; r.v[d] = e[(D + d) * 64]; }
-    r.w = e[2 * D * 64];
+    for (int d = 0; d < D; ++d) { r.m[d] = e[d * TileAddr<T>::kField]; r.v[d] = e[(D + d) * TileAddr<T>::kField]; }
+    r.w = e[2 * D * TileAddr<T>::kField];
     return r;
   }
   template <typename V>
@@ -384,14 +381,14 @@ struct EvalFast {
   __device__ __forceinline__ T operator()(P e) const { return (*this)(load(e)); }
   static constexpr bool kPairs = true;
   template <typename P>
-  __device__ __forceinline__ kdehip_f2 pair(P e, int RS) const {  // entries at e and e + RS
+  __device__ __forceinline__ kdehip_f2 pair(P e) const {  // the entries of rows 2p and 2p+1; e = row 2p's
     RowT<kdehip_f2> r;
 #pragma unroll
     for (int d = 0; d < D; ++d) {
-      r.m[d] = kdehip_f2{load_single(e + d * 64), load_single(e + RS + d * 64)};
-      r.v[d] = kdehip_f2{load_single(e + (D + d) * 64), load_single(e + RS + (D + d) * 64)};
+      r.m[d] = load_pair(e + d * TileAddr<T>::kField);
+      r.v[d] = load_pair(e + (D + d) * TileAddr<T>::kField);
     }
-    r.w = kdehip_f2{load_single(e + 2 * D * 64), load_single(e + RS + 2 * D * 64)};
+    r.w = load_pair(e + 2 * D * TileAddr<T>::kField);
     return eval<kdehip_f2>(r);
   }
 };
@@ -414,8 +411,8 @@ struct EvalGeneric {
   __device__ __forceinline__ Row load(P e) const {
     Row r;
 #pragma unroll
-    for (int d = 0; d < D; ++d) { r.m[d] = e[d * 64]; r.v[d] = e[(D + d) * 64]; }
-    r.w = e[2 * D * 64];
+    for (int d = 0; d < D; ++d) { r.m[d] = e[d * TileAddr<T>::kField]; r.v[d] = e[(D + d) * TileAddr<T>::kField]; }
+    r.w = e[2 * D * TileAddr<T>::kField];
     return r;
   }
   __device__ __forceinline__ T operator()(const Row &row) const {
@@ -484,58 +481,60 @@ struct LaneAcc {
 };
 
 // every row of `rows` (row 0, field 0, lane 0; LDS or global), `nrows` of them, accumulated into acc
+// (RS = TileAddr<T>::stride(F): elements per row in fp64, per PAIR of rows in fp32; row 0 of `rows` is an even row)
 template <typename T, typename P, typename Eval, bool PREFETCH = true>
 __device__ __forceinline__ void lane_rows_all(P rows, int nrows, int RS, int lane, const Eval &ev, LaneAcc<T> &acc) {
+  using TA = TileAddr<T>;
   constexpr bool kUsePairs = sizeof(T) == 4 && Eval::kPairs;
   if constexpr (kUsePairs) {
-    // fp32: two rows per trip through the packed-math pipe (their 2F loads are in flight together)
+    // fp32: two rows per trip through the packed-math pipe, each (field, lane) of a row pair one 8-byte load
     kdehip_f2 Sa = {acc.a[0], acc.a[1]}, Sb = {acc.a[2], acc.a[3]};
-    P e2 = rows + lane;
+    P e2 = rows + lane * TA::kLane;
     int i2 = 0;
-    for (; i2 + 4 <= nrows; i2 += 4, e2 += 4 * RS) {
-      Sa += ev.pair(e2, RS);
-      Sb += ev.pair(e2 + 2 * RS, RS);
+    for (; i2 + 4 <= nrows; i2 += 4, e2 += 2 * RS) {
+      Sa += ev.pair(e2);
+      Sb += ev.pair(e2 + RS);
     }
     if (i2 + 2 <= nrows) {
-      Sa += ev.pair(e2, RS);
-      if (i2 + 2 < nrows) Sb.x += ev(e2 + 2 * RS);
+      Sa += ev.pair(e2);
+      if (i2 + 2 < nrows) Sb.x += ev(e2 + RS);
     } else if (i2 < nrows) {
       Sa.x += ev(e2);
     }
     acc.a[0] = Sa.x; acc.a[1] = Sa.y; acc.a[2] = Sb.x; acc.a[3] = Sb.y;
     return;
   } else if constexpr (!PREFETCH) {
-    P e0 = rows + lane;
+    P e0 = rows + lane * TA::kLane;
     int i = 0;
-    for (; i + 4 <= nrows; i += 4, e0 += 4 * RS) {
+    for (; i + 4 <= nrows; i += 4, e0 += TA::rel(4, RS)) {
       acc.a[0] += ev(e0);
-      acc.a[1] += ev(e0 + RS);
+      acc.a[1] += ev(e0 + TA::rel(1, RS));
       __builtin_amdgcn_sched_barrier(0);  // two rows in flight, as before: the 128-register builds have no room for four
-      acc.a[2] += ev(e0 + 2 * RS);
-      acc.a[3] += ev(e0 + 3 * RS);
+      acc.a[2] += ev(e0 + TA::rel(2, RS));
+      acc.a[3] += ev(e0 + TA::rel(3, RS));
       __builtin_amdgcn_sched_barrier(0);
     }
     if (i < nrows) acc.a[0] += ev(e0);
-    if (i + 1 < nrows) acc.a[1] += ev(e0 + RS);
-    if (i + 2 < nrows) acc.a[2] += ev(e0 + 2 * RS);
+    if (i + 1 < nrows) acc.a[1] += ev(e0 + TA::rel(1, RS));
+    if (i + 2 < nrows) acc.a[2] += ev(e0 + TA::rel(2, RS));
     return;
   } else {
     // software pipelined, two rows per trip with ping-pong register sets (no copies): the fields of the
     // next row are requested before the current row is evaluated, so the LDS (or L2) round trip overlaps
     // ~40-100 fp64 instructions instead of stalling in front of each of them.
-    P e = rows + lane;
+    P e = rows + lane * TA::kLane;  // (always an EVEN row's entry: trips advance by two rows)
     typename Eval::Row ra = ev.load(e);
     // LDS tiles: have row 0 landed before the loop, otherwise the compiler's wait-count bookkeeping merges
     // "row 0 pending" into the loop head and waits for every prefetch right after issuing it
     if constexpr (kIsLdsPtr<P>) __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) only
     int i = 0;
     auto trip = [&](T &x, T &y, int ii) {
-      const typename Eval::Row rb = ev.load(e + RS);  // row ii+1
+      const typename Eval::Row rb = ev.load(e + TA::rel(1, RS));  // row ii+1
       __builtin_amdgcn_sched_barrier(0);              // keep the requests above the arithmetic
       const typename Eval::Mid ma = ev.arg(ra);       // ... ends by issuing row ii's exp table lookup
       __builtin_amdgcn_sched_barrier(0);
       const typename Eval::Mid mb = ev.arg(rb);       // hides the latency of row ii's lookup
-      e += (ii + 2 < nrows) ? 2 * RS : RS;            // row ii+2, or row ii+1 again (never past the tile)
+      e += (ii + 2 < nrows) ? TA::rel(2, RS) : TA::rel(1, RS);  // row ii+2, or row ii+1 again (never past the tile; last use of e)
       ra = ev.load(e);
       __builtin_amdgcn_sched_barrier(0);
       x += ev.fin(ma);
@@ -557,9 +556,11 @@ __device__ __forceinline__ void lane_rows_all(P rows, int nrows, int RS, int lan
 // the rows of ONE member of a wavefront team: trips over rows (i, i + second) for i = first, first + stride, ...
 // (team of 2: first = 2t, second = 1, stride = 4, x = a_{2t}, y = a_{2t+1}; team of 4: first = t, second = 4,
 // stride = 8, both rows of a trip go to x = a_t in row order: `same`).  All arguments but `lane` are wave-uniform.
+// (fp64 builds only: the row offsets below are plain multiples of RS)
 template <typename T, typename P, typename Eval, bool PREFETCH = true>
 __device__ __forceinline__ void lane_rows_member(P rows, int nrows, int RS, int lane, const Eval &ev, int first,
                                                  int second, int stride, bool same, T &x, T &y) {
+  static_assert(!TileAddr<T>::kPaired, "wavefront teams are fp64 builds");
   int i = first;
   if (i >= nrows) return;
   P e = rows + lane + first * RS;
@@ -641,8 +642,9 @@ __device__ __forceinline__ int select_from_scan(T incl, T S, P rows, const DS &d
                                                 , unsigned long long *stamp_acc, bool stamp_on
 #endif
 ) {
+  using TA = TileAddr<T>;
   const int n = ds.n, B = ds.B, F = ds.F;
-  const int RS = F * 64 + 1;
+  const int RS = TA::stride(F);
   KSTAMP(tp1);
   const T total = lane_read(incl, 63);
 
@@ -652,7 +654,7 @@ __device__ __forceinline__ int select_from_scan(T incl, T S, P rows, const DS &d
     // "stick with selection of others": uniform over the frontier (:311-315); with a zero/NaN
     // last weight the reference's CDF is all-NaN and the last entry is taken.
     const int zl = n - 1;
-    const T wl = rows[(zl % B) * RS + (F - 1) * 64 + zl / B];
+    const T wl = rows[TA::row(zl % B, RS) + (F - 1) * TA::kField + (zl / B) * TA::kLane];
     int z = n - 1;
     if (wl > T(0)) {
       z = static_cast<int>(ceil(u * static_cast<double>(n))) - 1;
@@ -678,13 +680,13 @@ __device__ __forceinline__ int select_from_scan(T incl, T S, P rows, const DS &d
   int r0 = 0;
   int len = n - lstar * B;
   if (len > B) len = B;
-  P col = rows + lstar;
+  P col = rows + lstar * TA::kLane;
   while (len > 64) {  // only for frontiers beyond 4096 nodes
     const int b2 = (len + 63) / 64;
     T S2 = T(0);
     for (int i = 0; i < b2; ++i) {
       const int r = lane * b2 + i;
-      if (r < len) S2 += ev(col + (r0 + r) * RS);
+      if (r < len) S2 += ev(col + TA::row(r0 + r, RS));
     }
     const T inc2 = wave_inclusive_scan(S2);
     const unsigned long long h2 = __ballot(target <= base + inc2);
@@ -696,7 +698,7 @@ __device__ __forceinline__ int select_from_scan(T incl, T S, P rows, const DS &d
     len = (len - l2 * b2 < b2) ? (len - l2 * b2) : b2;
   }
   T p2 = T(0);
-  if (lane < len) p2 = ev(col + (r0 + lane) * RS);
+  if (lane < len) p2 = ev(col + TileAddr<T>::row(r0 + lane, RS));
   const T inc3 = wave_inclusive_scan(p2);
   const unsigned long long h3 = __ballot((target <= base + inc3) && (lane < len));
   const int istar = h3 ? (__ffsll(h3) - 1) : (len - 1);
@@ -716,20 +718,21 @@ __device__ __forceinline__ int select_from_scan(T incl, T S, P rows, const DS &d
 template <typename T, typename P, typename Eval, int BMAX, typename DS>
 __device__ __forceinline__ int draw_label_kept(P rows, const DS &ds, int lane, const Eval &ev, double u,
                                                const void *fb, typename Eval::Row ra) {
+  using TA = TileAddr<T>;
   const int n = ds.n, B = ds.B, F = ds.F;
-  const int RS = F * 64 + 1;
+  const int RS = TA::stride(F);
   T v[BMAX];
-  P e = rows + lane;
+  P e = rows + lane * TA::kLane;
   // first pass: the two-rows-per-trip schedule of lane_sum_rows (next row requested early, the two rows
   // interleaved around their exp table lookups), fully unrolled so that the values stay in registers
   KDEHIP_PRIO_ROWS();
 #pragma unroll
   for (int i = 0; i < BMAX; i += 2) {
     if (i + 2 <= B) {  // wave-uniform
-      const typename Eval::Row rb = ev.load(e + (i + 1) * RS);
+      const typename Eval::Row rb = ev.load(e + TA::rel(i + 1, RS));
       __builtin_amdgcn_sched_barrier(0);
       const typename Eval::Mid ma = ev.arg(ra);
-      if (i + 2 < B) ra = ev.load(e + (i + 2) * RS);
+      if (i + 2 < B) ra = ev.load(e + TA::rel(i + 2, RS));
       __builtin_amdgcn_sched_barrier(0);
       const typename Eval::Mid mb = ev.arg(rb);
       __builtin_amdgcn_sched_barrier(0);
@@ -758,7 +761,7 @@ __device__ __forceinline__ int draw_label_kept(P rows, const DS &ds, int lane, c
   if (!(total >= Num<T>::tiny_total())) {  // uniform fallback (:311-315), as in select_from_scan
     count_fallback(fb, lane);
     const int zl = n - 1;
-    const T wl = rows[(zl % B) * RS + (F - 1) * 64 + zl / B];
+    const T wl = rows[TA::row(zl % B, RS) + (F - 1) * TA::kField + (zl / B) * TA::kLane];
     int z = n - 1;
     if (wl > T(0)) {
       z = static_cast<int>(ceil(u * static_cast<double>(n))) - 1;
@@ -796,7 +799,7 @@ __device__ __forceinline__ int draw_label_kept(P rows, const DS &ds, int lane, c
 }
 template <typename T, typename P, typename Eval, int BMAX, typename DS>
 __device__ __forceinline__ int draw_label_kept(P rows, const DS &ds, int lane, const Eval &ev, double u, const void *fb) {
-  return draw_label_kept<T, P, Eval, BMAX>(rows, ds, lane, ev, u, fb, ev.load(rows + lane));
+  return draw_label_kept<T, P, Eval, BMAX>(rows, ds, lane, ev, u, fb, ev.load(rows + lane * TileAddr<T>::kLane));
 }
 
 // fp32: the evaluation is repeated with every exponent raised by 110, 220, 330 binades while the sum stays below
@@ -808,7 +811,7 @@ __device__ __forceinline__ int draw_label_raised(P rows, const DS &ds, int lane,
   int pos = -1;
   for (int k = 1; k <= Num<T>::kOffsetSteps && pos < 0; ++k) {
     const auto evo = ev.with_offset(T(Num<T>::kOffsetStep) * T(k));
-    const T S = lane_sum_rows<T, P, std::decay_t<decltype(evo)>, false>(rows, ds.B, ds.F * 64 + 1, lane, evo);
+    const T S = lane_sum_rows<T, P, std::decay_t<decltype(evo)>, false>(rows, ds.B, TileAddr<T>::stride(ds.F), lane, evo);
     const bool final = (k == Num<T>::kOffsetSteps);
     pos = select_from_scan<T, P>(wave_inclusive_scan(S), S, rows, ds, lane, evo, u,
                                  final ? Num<T>::final_total() : Num<T>::tiny_total(), final, fb
@@ -867,7 +870,7 @@ __device__ __forceinline__ int select_or_raise_seg(T S, const SegSums<T> &seg, i
 #endif
 ) {
   const int n = ds.n, B = ds.B;
-  const int RS = ds.F * 64 + 1;
+  const int RS = TileAddr<T>::stride(ds.F);
   const T incl = wave_inclusive_scan(S);
   const T total = lane_read(incl, 63);
   // underflow (uniform fallback, fp32 raised repeats): the general path
@@ -897,9 +900,9 @@ __device__ __forceinline__ int select_or_raise_seg(T S, const SegSums<T> &seg, i
   if (r0 >= lenl) return (lenl - 1) * 64 + lstar;  // (rounding pushed the target beyond the block's last entry)
   int len = lenl - r0;
   if (len > seg_rows) len = seg_rows;
-  P col = rows + lstar;
+  P col = rows + lstar * TileAddr<T>::kLane;
   T p2 = T(0);
-  if (lane < len) p2 = ev(col + (r0 + lane) * RS);
+  if (lane < len) p2 = ev(col + TileAddr<T>::row(r0 + lane, RS));
   const T inc3 = wave_inclusive_scan(p2);
   const unsigned long long h3 = __ballot((target <= (base + before) + inc3) && (lane < len));
   const int istar = h3 ? (__ffsll(h3) - 1) : (len - 1);
@@ -923,7 +926,7 @@ __device__ __forceinline__ int draw_label(P rows, const DS &ds, int lane, const 
 #endif
   KSTAMP(tp0);
   KDEHIP_PRIO_ROWS();
-  const T S = lane_sum_rows<T, P, Eval, PREFETCH>(rows, ds.B, ds.F * 64 + 1, lane, ev);
+  const T S = lane_sum_rows<T, P, Eval, PREFETCH>(rows, ds.B, TileAddr<T>::stride(ds.F), lane, ev);
   KDEHIP_PRIO_CHAIN();
   KSTAMP(tp1);
   KSTAMP_ADD(2, tp0, tp1);
@@ -977,7 +980,7 @@ template <typename T, typename P, bool PREFETCH, typename Eval, typename DS>
 __device__ __forceinline__ int draw_label_team(P rows, const DS &ds, int lane, const Eval &ev, double u,
                                                const void *fb, const Team<T> &tm, bool pre_barrier) {
   T x = T(0), y = T(0);
-  lane_rows_member<T, P, Eval, PREFETCH>(rows, ds.B, ds.F * 64 + 1, lane, ev, tm.first, tm.second, tm.stride, tm.same, x, y);
+  lane_rows_member<T, P, Eval, PREFETCH>(rows, ds.B, TileAddr<T>::stride(ds.F), lane, ev, tm.first, tm.second, tm.stride, tm.same, x, y);
   const T S = team_combine(x + y, lane, tm, pre_barrier);
   return select_or_raise<T, P>(S, rows, ds, lane, ev, u, fb
 #ifdef KDEHIP_STAMPS
@@ -993,7 +996,7 @@ __device__ __forceinline__ int select_or_raise_seg_team(T S, const SegSums<T> &s
                                                         int lane, const Eval &ev, double u, const void *fb,
                                                         const Team<T> &tm) {
   const int n = ds.n, B = ds.B;
-  const int RS = ds.F * 64 + 1;
+  const int RS = TileAddr<T>::stride(ds.F);
   const T incl = wave_inclusive_scan(S);
   const T total = lane_read(incl, 63);
   const T target = static_cast<T>(u) * total;
@@ -1036,9 +1039,9 @@ __device__ __forceinline__ int select_or_raise_seg_team(T S, const SegSums<T> &s
   if (r0 >= lenl) return (lenl - 1) * 64 + lstar;
   int len = lenl - r0;
   if (len > seg_rows) len = seg_rows;
-  P col = rows + lstar;
+  P col = rows + lstar * TileAddr<T>::kLane;
   T p2 = T(0);
-  if (lane < len) p2 = ev(col + (r0 + lane) * RS);
+  if (lane < len) p2 = ev(col + TileAddr<T>::row(r0 + lane, RS));
   const T inc3 = wave_inclusive_scan(p2);
   const unsigned long long h3 = __ballot((target <= (base + before) + inc3) && (lane < len));
   const int istar = h3 ? (__ffsll(h3) - 1) : (len - 1);

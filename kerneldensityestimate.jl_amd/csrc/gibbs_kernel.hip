@@ -114,9 +114,10 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan_
   // selected kernel of density j <- entry `pos` of the tile whose header is at `hdr` (LDS or global)
   // (updateGlbParticlesVariance!, :89-115; masked dimensions carry no information)
   auto set_particle = [&](int j, const LevelDesc &ds, auto hdr, int pos) {
-    auto e = hdr + kTileHeader + (pos >> 6) * (ds.F * 64 + 1) + (pos & 63);
-    const T mu = e[dl * 64];
-    const T var = ds.uniform_bw ? hdr[dl] : e[(D + dl) * 64];
+    using TA = TileAddr<T>;
+    auto e = hdr + kTileHeader + TA::row(pos >> 6, TA::stride(ds.F)) + (pos & 63) * TA::kLane;
+    const T mu = e[dl * TA::kField];
+    const T var = ds.uniform_bw ? hdr[dl] : e[(D + dl) * TA::kField];
     const bool on = kAllDimsOn || ((ds.mask_bits >> dl) & 1u);
     const T l = on ? (FAST ? fast_rcp(var) : T(1) / var) : T(0);
     if (lane < D) {
@@ -230,16 +231,17 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan_
   int gchunk = 0;
   auto chunk_rows = [&](const LevelDesc &ds) -> int { return ds.chunk_rows; };
   auto stage_chunk = [&](const LevelDesc &ds, int r0, int half) {
-    const int RS = ds.F * 64 + 1, rc = chunk_rows(ds);
+    using TA = TileAddr<T>;
+    const int RS = TA::stride(ds.F), rc = chunk_rows(ds);
     const int nrows = (ds.B - r0 < rc) ? (ds.B - r0) : rc;
-    const int bytes = (nrows * RS * int(sizeof(T)) + 1023) & ~1023;
-    stage_tile<WAVES>(reinterpret_cast<const unsigned char *>(data + ds.hdr_off + kTileHeader + static_cast<int64_t>(r0) * RS),
+    const int bytes = (static_cast<int>(TA::span(nrows, RS)) * int(sizeof(T)) + 1023) & ~1023;  // (r0: a multiple of 4 rows)
+    stage_tile<WAVES>(reinterpret_cast<const unsigned char *>(data + ds.hdr_off + kTileHeader + TA::row(r0, RS)),
                       pool + half * (kLdsPoolBytes / 2), bytes, wave, lane);
   };
   auto step_chunked = [&](int j, const LevelDesc &ds, const LevelDesc &dn, bool has_next, T mean, T cov, double u) {
     const T *hdr = data + ds.hdr_off;
     const int pos = draw(ds, hdr, mean, cov, [&](const auto &ev) {
-      const int RS = ds.F * 64 + 1, rc = chunk_rows(ds);
+      const int RS = TileAddr<T>::stride(ds.F), rc = chunk_rows(ds);
       LaneAcc<T> acc;  // the lane's sums over its rows, kept across the chunks (gibbs_device.hpp: one association everywhere)
       SegSums<T> seg;
       const int cps = seg_chunks(ds.seg);
@@ -305,7 +307,7 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan_
     T *row = tables + td.off + static_cast<int64_t>(cfg) * (td.n + 1);
     draw(ds, hdr, mean, cov, [&](const auto &ev) {
       T incl = wave_inclusive_scan(lane_sum_rows<T, const T *, std::decay_t<decltype(ev)>, false>(
-          hdr + kTileHeader, 1, ds.F * 64 + 1, lane, ev));
+          hdr + kTileHeader, 1, TileAddr<T>::stride(ds.F), lane, ev));
       // fp32: the scan of the first exponent offset at which the sum is large enough (see Num<float>::tiny_total);
       // an underflow in the reference's sense is stored as an all-zero row, which the sweep step takes as the
       // uniform fallback
@@ -314,7 +316,7 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan_
         for (int k = 1; k <= Num<T>::kOffsetSteps && !ok; ++k) {
           const auto evo = ev.with_offset(T(Num<T>::kOffsetStep) * T(k));
           incl = wave_inclusive_scan(lane_sum_rows<T, const T *, std::decay_t<decltype(evo)>, false>(
-              hdr + kTileHeader, 1, ds.F * 64 + 1, lane, evo));
+              hdr + kTileHeader, 1, TileAddr<T>::stride(ds.F), lane, evo));
           ok = lane_read(incl, 63) >= (k == Num<T>::kOffsetSteps ? Num<T>::final_total() : Num<T>::tiny_total());
         }
         if (!ok) incl = T(0);
@@ -472,7 +474,7 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan_
         if (!(total >= Num<T>::tiny_total())) {  // uniform fallback (:311-315), rare: fetch the descriptor here
           count_fallback(fb, lane);
           const LevelDesc dk = levels[jt * (L + 1) + l];
-          const T wl = ((LdsPtr<T>)(pool + dk.lds_off) + kTileHeader)[(dk.F - 1) * 64 + (n - 1)];
+          const T wl = ((LdsPtr<T>)(pool + dk.lds_off) + kTileHeader)[(dk.F - 1) * TileAddr<T>::kField + (n - 1) * TileAddr<T>::kLane];
           int z = n - 1;
           if (wl > T(0)) {
             z = static_cast<int>(ceil(u * static_cast<double>(n))) - 1;

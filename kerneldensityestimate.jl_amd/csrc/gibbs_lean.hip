@@ -182,9 +182,10 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
   // adopt entry `pos` of the tile whose header is at `hdr` (LDS or global) as density j's kernel
   auto adopt = [&](auto jc, const auto &ds, auto hdr, int pos) {
     constexpr int j = decltype(jc)::value;
-    auto e = hdr + kTileHeader + (pos >> 6) * (ds.F * 64 + 1) + (pos & 63);
-    const T mu = e[dl * 64];
-    const T var = ds.uniform_bw ? hdr[dl] : e[(D + dl) * 64];
+    using TA = TileAddr<T>;
+    auto e = hdr + kTileHeader + TA::row(pos >> 6, TA::stride(ds.F)) + (pos & 63) * TA::kLane;
+    const T mu = e[dl * TA::kField];
+    const T var = ds.uniform_bw ? hdr[dl] : e[(D + dl) * TA::kField];
     const T l = fast_rcp(var);
     lam[j] = l;
     lmu[j] = mu * l;
@@ -318,7 +319,7 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
     // single-row step is one dependent chain, and this takes an LDS round trip out of it (profiles/r04_experiments.md).
     if constexpr (kCanPreloadImpl<decltype(hdr + kTileHeader), T, kPreloadBuild>) {
       if (!ds.uniform_bw && ds.B <= KDEHIP_PRELOAD_MAXB) {
-        const auto row = EvalFast<T, D, false>().load(hdr + kTileHeader + lane);
+        const auto row = EvalFast<T, D, false>().load(hdr + kTileHeader + lane * TileAddr<T>::kLane);
         T mean1 = x, cov1 = T(0);
         if (!first) product(jc, mean1, cov1);
         const double u1 = next_uniform();
@@ -339,10 +340,11 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
 
   int gchunk = 0;  // workgroup-wide running chunk counter of the chunked mode (selects the pool half)
   auto stage_chunk = [&](const auto &ds, int r0, int half) {
-    const int RS = ds.F * 64 + 1, rc = ds.chunk_rows;
+    using TA = TileAddr<T>;
+    const int RS = TA::stride(ds.F), rc = ds.chunk_rows;
     const int nrows = (ds.B - r0 < rc) ? (ds.B - r0) : rc;
-    const int bytes = (nrows * RS * int(sizeof(T)) + 1023) & ~1023;
-    stage_tile<WAVES>(reinterpret_cast<const unsigned char *>(data + ds.hdr_off() + kTileHeader + static_cast<int64_t>(r0) * RS),
+    const int bytes = (static_cast<int>(TA::span(nrows, RS)) * int(sizeof(T)) + 1023) & ~1023;  // (r0: a multiple of 4 rows)
+    stage_tile<WAVES>(reinterpret_cast<const unsigned char *>(data + ds.hdr_off() + kTileHeader + TA::row(r0, RS)),
                       pool + half * (kLdsPoolBytes / 2), bytes, wave, lane);
   };
 
@@ -472,7 +474,7 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
           const T *hdr = data + ds.hdr_off();
           const int pos = draw(ds, hdr, mean, cov, [&](const auto &ev) {
             using Ev = std::decay_t<decltype(ev)>;
-            const int RS = ds.F * 64 + 1, rc = ds.chunk_rows;
+            const int RS = TileAddr<T>::stride(ds.F), rc = ds.chunk_rows;
             LaneAcc<T> acc;          // a wavefront that owns its chain
             T mx = T(0), my = T(0);  // a team member's share
             SegSums<T> seg;
@@ -488,7 +490,7 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
               else if (t + 1 < nsteps) stage_chunk(dn, 0, (gchunk + 1) & 1);
               const int nrows = (ds.B - r0 < rc) ? (ds.B - r0) : rc;
               const auto crows = (LdsPtr<T>)(pool + (gchunk & 1) * (kLdsPoolBytes / 2));
-              if (shared)
+              if constexpr (shared)
                 lane_rows_member<T, LdsPtr<T>, Ev, kPrefetchRows>(crows, nrows, RS, lane, ev, team.first, team.second,
                                                                   team.stride, team.same, mx, my);
               else
@@ -546,7 +548,7 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
           if (!(total >= Num<T>::tiny_total())) {  // uniform fallback (:311-315), rare
             count_fallback(fb, lane);
             const LeanTile<D> dk = tile(j);
-            const T wl = ((LdsPtr<T>)(pool + dk.lds_off) + kTileHeader)[(dk.F - 1) * 64 + (n - 1)];
+            const T wl = ((LdsPtr<T>)(pool + dk.lds_off) + kTileHeader)[(dk.F - 1) * TileAddr<T>::kField + (n - 1) * TileAddr<T>::kLane];
             int z = n - 1;
             if (wl > T(0)) {
               z = static_cast<int>(ceil(u * static_cast<double>(n))) - 1;

@@ -23,9 +23,15 @@ const char *last_error_cstr();
 // lane z / B, row z % B, i.e. lane `ln` of a wavefront owns the CONTIGUOUS entries
 // ln*B .. ln*B+B-1.  A tile is one contiguous block of T elements:
 //   header  kTileHeader (8) elements: the bandwidth vector of entry 0 (= of every entry if uniform_bw)
-//   row i   F fields of 64 lanes each + 1 pad element (row stride RS = F*64 + 1); the pad makes the
-//           column walk of the second selection pass bank-conflict free once the tile sits in LDS
-//   element (row i, field f, lane ln) at hdr_off + kTileHeader + i*RS + f*64 + ln
+//   fp64:   row i = F fields of 64 lanes each + 1 pad element (row stride RS = F*64 + 1); the pad makes the
+//           column walk of the second selection pass bank-conflict free once the tile sits in LDS;
+//           element (row i, field f, lane ln) at hdr_off + kTileHeader + i*RS + f*64 + ln
+//   fp32 (round 4): rows in PAIRS -- the values of rows 2p and 2p+1 for one (field, lane) are adjacent, so the packed
+//           first pass (two rows per v_pk_* instruction) fetches a register pair with ONE ds_read_b64 (2 LDS cycles
+//           for 512 bytes; two ds_read_b32 take 4: the LDS array was 55 % busy at config 5); pair stride
+//           RS = 2*F*64 + 2 (the 2 pad elements: the column walk stays conflict free);
+//           element (row i, field f, lane ln) at hdr_off + kTileHeader + (i/2)*RS + (f*64 + ln)*2 + i%2
+//   (TileAddr<T> below is the one place that knows this)
 //   fields: [0, D) mean per dimension; then, unless the level has ONE bandwidth vector shared by
 //   all its nodes (uniform_bw: always true for the leaf level of a reference-built density),
 //   [D, 2D) bandwidth (variance) per dimension; last field (F-1): weight.
@@ -33,6 +39,30 @@ const char *last_error_cstr();
 // Padding entries (z >= n) carry weight 0, variance 1, mean 0 and never win a draw.
 // The LDS image of a tile is a byte copy of [hdr_off, hdr_off + stage_bytes).
 constexpr int kTileHeader = 8;
+#if defined(__HIPCC__)
+#define KDEHIP_TILE_HD __host__ __device__ inline
+#else
+#define KDEHIP_TILE_HD inline
+#endif
+template <int ELEM_BYTES>
+struct TileAddrBytes {
+  static constexpr bool kPaired = ELEM_BYTES == 4;
+  static constexpr int kLane = kPaired ? 2 : 1;   // elements between the same field of adjacent lanes
+  static constexpr int kField = 64 * kLane;       // elements between adjacent fields of one entry
+  // RS: elements per row (fp64) / per PAIR of rows (fp32)
+  KDEHIP_TILE_HD static constexpr int stride(int F) { return kPaired ? 2 * F * 64 + 2 : F * 64 + 1; }
+  // element offset of (row r, field 0, lane 0) from the tile's first row
+  // (in the integer type of its arguments: 32-bit on the kernels' step paths)
+  template <typename I>
+  KDEHIP_TILE_HD static constexpr I row(I r, I RS) { return kPaired ? (r >> 1) * RS + (r & 1) : r * RS; }
+  // the same for row base + k where `base` is EVEN and k a small constant (relative to the base row's offset)
+  KDEHIP_TILE_HD static constexpr int rel(int k, int RS) { return kPaired ? (k >> 1) * RS + (k & 1) : k * RS; }
+  // elements of the rows of a tile with B rows per lane
+  KDEHIP_TILE_HD static constexpr int64_t body(int64_t B, int F) { return (kPaired ? (B + 1) / 2 : B) * stride(F); }
+  // elements covered by rows [r0, r0 + nrows), r0 even
+  KDEHIP_TILE_HD static constexpr int64_t span(int64_t nrows, int64_t RS) { return (kPaired ? (nrows + 1) / 2 : nrows) * RS; }
+};
+template <typename T> using TileAddr = TileAddrBytes<int(sizeof(T))>;
 constexpr double kMaxUniformRatio = 1e5;  // see pack_layout_shapes: when a shared-bandwidth frontier gets the compact tile
 enum StageMode : int32_t {
   kStageGlobal = 0,    // tile too large for LDS: wavefronts read it from global memory (L1/L2)
@@ -55,7 +85,7 @@ struct LevelDesc {
   int32_t lds_off;      // byte offset of the tile image in the LDS pool (resident mode)
   int32_t stage_bytes;  // bytes to copy (header + rows, rounded up to 1 KiB)
   int32_t last_lane;    // (n - 1) / B: the lane that owns the last entry (kept here: no integer division per step)
-  int32_t chunk_rows;   // rows per LDS chunk in chunked mode (multiple of 4: 16-byte aligned chunk starts)
+  int32_t chunk_rows;   // rows per LDS chunk in chunked mode (multiple of 4: 16-byte aligned chunk starts, whole row pairs)
   // chunked mode, the one-round second pass (gibbs_device.hpp "chunked tiles"): chunks per segment in bits 0..15 (0: the
   // segment form does not apply to this tile), segments per lane block in bits 16..31 -- worked out by the packer so
   // that no step of the kernel divides integers (four uniform divisions a step were 3 % of config 4's instructions)

@@ -36,7 +36,8 @@ using namespace kdehip;
 namespace kdehip {
 
 // One wavefront per (tile, row): lane ln writes entry z = ln*B + row of the frontier (kdehip_internal.hpp "packed
-// per-level layout"), field by field -- 64 contiguous elements per store -- from the density's arrays in HBM.
+// per-level layout"), field by field -- 64 contiguous elements per store (fp32: every other element of a row pair's
+// 128) -- from the density's arrays in HBM.
 template <typename T>
 __global__ __launch_bounds__(64) void fill_tiles_kernel(const FillJob *__restrict__ jobs) {
   const FillJob job = jobs[blockIdx.y];
@@ -44,7 +45,8 @@ __global__ __launch_bounds__(64) void fill_tiles_kernel(const FillJob *__restric
   if (row >= job.B) return;
   const int lane = threadIdx.x;
   const int D = job.D, F = job.F;
-  const int64_t RS = static_cast<int64_t>(F) * 64 + 1;
+  using TA = TileAddr<T>;
+  const int64_t RS = TA::stride(F);
   T *hdr = static_cast<T *>(job.hdr);
   const int32_t *front = job.front;
   const double *means = job.means, *bw = job.bandwidth;
@@ -54,12 +56,20 @@ __global__ __launch_bounds__(64) void fill_tiles_kernel(const FillJob *__restric
   }
   const int64_t z = static_cast<int64_t>(lane) * job.B + row;
   const int64_t src = z < job.n ? static_cast<int64_t>(front[z]) - 1 : -1;
-  T *r = hdr + kTileHeader + row * RS;
-  for (int d = 0; d < D; ++d) r[d * 64 + lane] = src >= 0 ? static_cast<T>(means[src * D + d]) : T(0);
+  T *r = hdr + kTileHeader + TA::row(static_cast<int64_t>(row), RS) + lane * TA::kLane;  // (row, field 0, this lane); field f at r[f * kField]
+  for (int d = 0; d < D; ++d) r[d * TA::kField] = src >= 0 ? static_cast<T>(means[src * D + d]) : T(0);
   if (!job.uniform)
-    for (int d = 0; d < D; ++d) r[(D + d) * 64 + lane] = src >= 0 ? static_cast<T>(bw[src * D + d]) : T(1);
-  r[(F - 1) * 64 + lane] = src >= 0 ? static_cast<T>(job.weights[src]) : T(0);
-  if (lane == 0) r[F * 64] = T(0);  // the pad element
+    for (int d = 0; d < D; ++d) r[(D + d) * TA::kField] = src >= 0 ? static_cast<T>(bw[src * D + d]) : T(1);
+  r[(F - 1) * TA::kField] = src >= 0 ? static_cast<T>(job.weights[src]) : T(0);
+  if (lane == 0) r[F * TA::kField] = T(0);  // the pad element
+  if (TA::kPaired && row == job.B - 1 && (job.B & 1)) {  // fp32: the missing second row of the last pair = padding entries
+    T *q = r + 1;
+    for (int d = 0; d < D; ++d) q[d * TA::kField] = T(0);
+    if (!job.uniform)
+      for (int d = 0; d < D; ++d) q[(D + d) * TA::kField] = T(1);
+    q[(F - 1) * TA::kField] = T(0);
+    if (lane == 0) q[F * TA::kField] = T(0);
+  }
   job.perm_out[static_cast<int64_t>(row) * 64 + lane] = src >= 0 ? static_cast<int32_t>(job.perm[src]) : 0;
 }
 

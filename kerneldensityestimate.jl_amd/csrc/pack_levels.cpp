@@ -256,7 +256,10 @@ int pack_layout_shapes(int M, int D, int L, const TileShape *shapes, const uint8
       // (fp32 keeps the subtract-first form: no limit)
       const bool uni = out.fast && shapes[idx].uniform && (precision == 32 || shapes[idx].uratio <= kMaxUniformRatio);
       const int F = uni ? D + 1 : 2 * D + 1;
-      const int64_t RS = static_cast<int64_t>(F) * 64 + 1;
+      // (TileAddr: fp64 rows of F*64+1 elements; fp32 row PAIRS of 2*F*64+2)
+      const bool paired = (precision == 32);
+      const int64_t RS = paired ? TileAddrBytes<4>::stride(F) : TileAddrBytes<8>::stride(F);
+      const int64_t body = paired ? TileAddrBytes<4>::body(B, F) : TileAddrBytes<8>::body(B, F);
       LevelDesc &ds = out.levels[idx];
       std::memset(&ds, 0, sizeof(ds));
       ds.n = static_cast<int32_t>(n);
@@ -267,14 +270,14 @@ int pack_layout_shapes(int M, int D, int L, const TileShape *shapes, const uint8
       ds.others_bits = others_bits[j];
       nelem = (nelem + 7) & ~int64_t(7);  // tiles start 64-byte (fp32: 32-byte) aligned
       ds.hdr_off = nelem;
-      nelem += kTileHeader + B * RS;
+      nelem += kTileHeader + body;
       ds.perm_off = nperm;
       nperm += B * 64;
-      const int64_t bytes = (kTileHeader + B * RS) * esz;
+      const int64_t bytes = (kTileHeader + body) * esz;
       if (bytes > (int64_t(1) << 30)) return set_error(KDEHIP_ERR_UNSUPPORTED, "level tile too large");
       ds.stage_bytes = static_cast<int32_t>((bytes + 1023) / 1024 * 1024);
       ds.last_lane = static_cast<int32_t>((n - 1) / B);
-      ds.chunk_rows = static_cast<int32_t>(((kLdsPoolBytes / 2 - 1024) / (RS * esz)) & ~int64_t(3));
+      ds.chunk_rows = static_cast<int32_t>(((paired ? 2 : 1) * ((kLdsPoolBytes / 2 - 1024) / (RS * esz))) & ~int64_t(3));
     }
   }
   out.data_elems = nelem + 1024 / 4;  // staged copies are rounded up to whole KiB: keep the tail readable
@@ -371,7 +374,8 @@ static void fill_density(const PackedProduct &pp, const kdehip_density &t, int j
     const int64_t n = ds.n, B = ds.B;
     const int F = ds.F;
     const bool uni = ds.uniform_bw != 0;
-    const int64_t RS = static_cast<int64_t>(F) * 64 + 1;
+    using TA = TileAddr<T>;
+    const int64_t RS = TA::stride(F);
     T *hdr = data + ds.hdr_off;
     for (int d = 0; d < kTileHeader; ++d)
       hdr[d] = d < D ? static_cast<T>(t.bandwidth[(static_cast<int64_t>(cur[0]) - 1) * D + d]) : T(0);
@@ -389,9 +393,12 @@ static void fill_density(const PackedProduct &pp, const kdehip_density &t, int j
         const int64_t z = static_cast<int64_t>(ln) * B + i;
         src[ln] = z < n ? static_cast<int64_t>(cur[z]) - 1 : -1;
       }
-      T *row = tile + i * RS;
+      T *row = tile + TA::row(i, RS);  // (row i, field 0, lane 0); field f of lane ln at row[f * kField + ln * kLane]
+      T dst[64];                        // one field of the row, checked here and then scattered into the tile
+      auto put = [&](int f) {
+        for (int ln = 0; ln < 64; ++ln) row[f * TA::kField + ln * TA::kLane] = dst[ln];
+      };
       for (int d = 0; d < D; ++d) {
-        T *dst = row + d * 64;
         for (int ln = 0; ln < 64; ++ln) dst[ln] = src[ln] >= 0 ? static_cast<T>(t.means[src[ln] * D + d]) : T(0);
         // (checked on the 64 contiguous values just written: vectorisable, unlike the gather above)
         T amax = T(0), nan_acc = T(0);
@@ -401,10 +408,10 @@ static void fill_density(const PackedProduct &pp, const kdehip_density &t, int j
           nan_acc += dst[ln] * T(0);  // 0 for a finite value, NaN otherwise
         }
         bad |= !(static_cast<double>(amax) < 1e100) | !(nan_acc == T(0));
+        put(d);
       }
       if (!uni)
         for (int d = 0; d < D; ++d) {
-          T *dst = row + (D + d) * 64;
           for (int ln = 0; ln < 64; ++ln) dst[ln] = src[ln] >= 0 ? static_cast<T>(t.bandwidth[src[ln] * D + d]) : T(1);
           T l = dst[0], h = dst[0], nan_acc = T(0);  // (padding entries carry variance 1: neutral for the range test)
           for (int ln = 0; ln < 64; ++ln) {
@@ -415,8 +422,9 @@ static void fill_density(const PackedProduct &pp, const kdehip_density &t, int j
           bad |= !(l > T(0)) | !(static_cast<double>(h) < INFINITY) | !(nan_acc == T(0));
           lo[d] = static_cast<double>(l) < lo[d] ? static_cast<double>(l) : lo[d];
           hi[d] = static_cast<double>(h) > hi[d] ? static_cast<double>(h) : hi[d];
+          put(D + d);
         }
-      T *wdst = row + (F - 1) * 64;
+      T *wdst = dst;
       for (int ln = 0; ln < 64; ++ln) wdst[ln] = src[ln] >= 0 ? static_cast<T>(t.weights[src[ln]]) : T(0);
       {
         T wl = wdst[0], wh = wdst[0], nan_acc = T(0);
@@ -427,12 +435,21 @@ static void fill_density(const PackedProduct &pp, const kdehip_density &t, int j
         }
         bad |= !(wl >= T(0)) | !(static_cast<double>(wh) < INFINITY) | !(nan_acc == T(0));
       }
-      row[F * 64] = T(0);  // the pad element
+      put(F - 1);
+      row[F * TA::kField] = T(0);  // the pad element (fp32: one of the pair's two)
       int32_t *pdst = prow + i * 64;
       for (int ln = 0; ln < 64; ++ln) pdst[ln] = src[ln] >= 0 ? static_cast<int32_t>(t.permutation[src[ln]]) : 0;
     }
+    if (TA::kPaired && (B & 1)) {  // the missing second row of the last pair: padding entries (weight 0, variance 1, mean 0)
+      T *row = tile + TA::row(B, RS);
+      for (int f = 0; f < F; ++f) {
+        const T v = (!uni && f >= D && f < 2 * D) ? T(1) : T(0);
+        for (int ln = 0; ln < 64; ++ln) row[f * TA::kField + ln * TA::kLane] = v;
+      }
+      row[F * TA::kField] = T(0);
+    }
     // gap up to the next tile's aligned start
-    const int64_t end = ds.hdr_off + kTileHeader + B * RS;
+    const int64_t end = ds.hdr_off + kTileHeader + TA::body(B, F);
     const int64_t next = (idx + 1 < pp.levels.size()) ? pp.levels[idx + 1].hdr_off : pp.data_elems;
     for (int64_t e = end; e < next; ++e) data[e] = T(0);
   }
