@@ -163,15 +163,18 @@ static __device__ unsigned long long g_stamp_acc[16];
 
 template <typename P> constexpr bool kIsLdsPointer = false;
 template <typename T> constexpr bool kIsLdsPointer<const __attribute__((address_space(3))) T *> = true;
+template <typename T> constexpr bool kIsLdsPointer<const volatile __attribute__((address_space(3))) T *> = true;
 
 // ---- kernel evaluation of one frontier entry -----------------------------------------------------
 // `e` points at (row, field 0, lane) of the entry (LDS or global pointer); field f is at e[f * TileAddr<T>::kField].
 
 // The two rows of a pair for one (field, lane), as ONE 8-byte load (fp32 tiles keep them adjacent: TileAddr): the
 // register pair the packed first pass works on, from one ds_read_b64 (2 LDS cycles; two ds_read_b32 take 4).
+// (a volatile load: the compiler would otherwise merge two of them into a ds_read2st64_b64, which takes 8 LDS-array cycles
+// where two ds_read_b64 take 2 + 2 -- config 5: 16.46 -> 15.94 ms, profiles/r04_experiments.md)
 template <typename P>
 __device__ __forceinline__ kdehip_f2 load_pair(P p) {
-  using VP = std::conditional_t<kIsLdsPointer<P>, const __attribute__((address_space(3))) kdehip_f2 *, const kdehip_f2 *>;
+  using VP = std::conditional_t<kIsLdsPointer<P>, const volatile __attribute__((address_space(3))) kdehip_f2 *, const kdehip_f2 *>;
   return *(VP)(p);
 }
 
@@ -466,6 +469,7 @@ struct EvalGeneric {
 // pass 1 over rows held at `rows` (LDS or global): the lane's private sum over its contiguous entries
 template <typename P> constexpr bool kIsLdsPtr = false;
 template <typename T> constexpr bool kIsLdsPtr<const __attribute__((address_space(3))) T *> = true;
+template <typename T> constexpr bool kIsLdsPtr<const volatile __attribute__((address_space(3))) T *> = true;
 
 // ---- the lane's sum over its rows: ONE association for every kernel, width, team size and staging mode ----------
 // S = (a0 + a1) + (a2 + a3), where a_k is the sum, in increasing row order, of the lane's rows r = k (mod 4).
@@ -1068,6 +1072,11 @@ struct TileGeom {
 };
 
 template <typename T> using LdsPtr = const __attribute__((address_space(3))) T *;
+// The same with every field read a load of its own: through a plain pointer the compiler merges two 8-byte field reads into
+// one ds_read2st64_b64 (8 LDS-array cycles for 1 KiB; two ds_read_b64: 2 + 2).  With four wavefronts per SIMD reading rows
+// (16-chain workgroups) the LDS array is busy enough for that to show -- config 3 with 16,384 chains 3.91 -> 3.81 ms --
+// with two per SIMD it is not (config 3: 0.5750 / 0.5749 ms, config 4: 4.37 -> 4.45 ms): gibbs_lean.hip picks by width.
+template <typename T> using LdsPtrSplit = const volatile __attribute__((address_space(3))) T *;
 // read-only, wave-uniform tables are read through the constant address space so that the compiler
 // uses scalar loads (s_load_*, lgkmcnt) and never drains the direct-to-LDS copies in flight (vmcnt)
 typedef int kdehip_v16i __attribute__((ext_vector_type(16)));

@@ -102,6 +102,8 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
   const PlanDev &plan = view.plan;
   const auto &a = view.a;
   constexpr bool kPrefetchRows = (WAVES <= 12) || sizeof(T) == 4 || D <= 4;  // as in gibbs_kernel.hip
+  // how the rows of an LDS tile are read: see LdsPtrSplit (fp32 reads its row pairs as single loads either way: load_pair)
+  using RowPtr = std::conditional_t<(WAVES == 16 && sizeof(T) == 8), LdsPtrSplit<T>, LdsPtr<T>>;
   constexpr bool kKeptRows = (WAVES <= 8);
   constexpr bool kPreloadBuild = kKeptRows && kPrefetchRows && !(TEAMS && WAVES == 16);
   // wavefront teams (a chain on 2 or 4 wavefronts, RunArgs.team): the 16-wavefront fp64 builds
@@ -414,7 +416,7 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
         for (int p = 0; p < npass; ++p)
           static_for<M>([&](auto jc) {
             const LeanTile<D> ds = tile(decltype(jc)::value);
-            step(jc, ds, (LdsPtr<T>)(pool + ds.lds_off), p == 0, x);
+            step(jc, ds, (RowPtr)(pool + ds.lds_off), p == 0, x);
           });
     } else if (mode == kStageStream) {
       staging_barrier();
@@ -443,7 +445,7 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
             stage_tile<WAVES>(reinterpret_cast<const unsigned char *>(data + dn.hdr_off()),
                               pool + ((t + 1) & 1) * (kLdsPoolBytes / 2), dn.stage_bytes, wave, lane);
           if (active) {
-            auto hdr = (LdsPtr<T>)(pool + (t & 1) * (kLdsPoolBytes / 2));
+            auto hdr = (RowPtr)(pool + (t & 1) * (kLdsPoolBytes / 2));
             auto rows = hdr + kTileHeader;
             // (requesting the first row ahead of the broadcasts here, as the resident steps do, was measured: no gain --
             // 0.5825 vs 0.5811 ms)
@@ -489,12 +491,12 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
               if (r0 + rc < ds.B) stage_chunk(ds, r0 + rc, (gchunk + 1) & 1);
               else if (t + 1 < nsteps) stage_chunk(dn, 0, (gchunk + 1) & 1);
               const int nrows = (ds.B - r0 < rc) ? (ds.B - r0) : rc;
-              const auto crows = (LdsPtr<T>)(pool + (gchunk & 1) * (kLdsPoolBytes / 2));
+              const auto crows = (RowPtr)(pool + (gchunk & 1) * (kLdsPoolBytes / 2));
               if constexpr (shared)
-                lane_rows_member<T, LdsPtr<T>, Ev, kPrefetchRows>(crows, nrows, RS, lane, ev, team.first, team.second,
+                lane_rows_member<T, RowPtr, Ev, kPrefetchRows>(crows, nrows, RS, lane, ev, team.first, team.second,
                                                                   team.stride, team.same, mx, my);
               else
-                lane_rows_all<T, LdsPtr<T>, Ev, kPrefetchRows>(crows, nrows, RS, lane, ev, acc);
+                lane_rows_all<T, RowPtr, Ev, kPrefetchRows>(crows, nrows, RS, lane, ev, acc);
               // the lane's running sum (a member: its share of it) at a segment boundary
               if (use_seg && ++cin == cps) { seg.note(shared ? mx + my : acc.total()); cin = 0; }
             }

@@ -1,6 +1,6 @@
-# round 4 (j): the fp32 row-pair tile layout -- GPU suite, fp32 soak, bench c5 / c3 / c4
+# round 4 (l): split LDS reads (fp32 pairs, 16-chain fp64 builds) -- GPU suite, fp32 soak, bench c5 / c3 / c4
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r04j; mkdir -p $O
+O=gpurun_out/r04l; mkdir -p $O
 timeout 1500 python -m pytest tests -q -m gpu -x > $O/gpu_tests.txt 2>&1; tail -n 6 $O/gpu_tests.txt
 timeout 600 python scripts/soak_fp32.py 800 2>&1 | tail -1 > $O/soak.txt
 timeout 600 python scripts/soak_chunked.py 400 2>&1 | tail -1 >> $O/soak.txt
@@ -12,4 +12,11 @@ python -c "
 import json
 for f in ['bench_c5','bench_c3','bench_c4']:
     d=json.load(open('$O/'+f+'.json')); print(f, round(d['ms_per_step'],4), d['roofline']['kernel_ms'], (d.get('parity') or {}).get('label_mismatches'))
+"
+python bench.py --nout 16384 --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_c3_16k.json 2>> $O/bench.err
+python bench.py --config c2 --batch 64 --steps 20 --warmup 3 > $O/bench_c2_batch64.json 2>> $O/bench.err
+python -c "
+import json
+for f in ['bench_c3_16k','bench_c2_batch64']:
+    d=json.load(open('$O/'+f+'.json')); print(f, round(d['ms_per_step'],4), d['roofline']['kernel_ms'])
 "
