@@ -159,3 +159,18 @@ def test_config5_total_chain_count_on_one_gpu():
         a, ia = p64.sample(Np // 8, Niter=Niter, seed=seed, sample_offset=lo)
     _gates(a, b[:, lo:lo + Np // 8], Np // 8)
     assert (ia != ib[:, lo:lo + Np // 8]).mean() < 0.15
+
+
+def test_fp32_row_pair_tiles_give_one_result_through_every_kernel():
+    """fp32 tiles keep the two rows of a pair adjacent (kdehip_internal.hpp TileAddr): the same fp32 product through
+    the register-resident sampler at 4 / 8 / 16 chains per workgroup, the general kernel at 4 / 8 / 16, a host-packed plan
+    and GPU-packed resident densities must be bit-identical -- odd and even rows per lane, resident / streamed / chunked
+    tiles, masks (scripts/soak_fp32_layout.py, 40 random shapes)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "soak_fp32_layout.py"), "40"], cwd=root,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert " 0 mismatches" in out.stdout
