@@ -103,8 +103,7 @@ int launch_gibbs(int precision, int mode, const PlanDev &plan, const RunArgs &ar
       default: break;
     }
     if (rc != kLeanNotCovered) return rc;
-  } else if (!generic_only && (plan.M <= 4 || (plan.M == 8 && precision == 32))) {
-    // products of 2..4 densities (fp32: and of 8), all dimensions active: the register-resident kernel
+  } else if (!generic_only && plan.M <= 4) {  // products of 2..4 densities, all dimensions active: the register-resident kernel  // products of 2..4 densities, all dimensions active: the register-resident kernel
     int rc = kLeanNotCovered;
     const bool f32 = (precision == 32);
     switch (plan.D) {

@@ -37,17 +37,14 @@ __device__ __forceinline__ void static_for(F &&f) {
 
 // Three translation units per dimension count (build time: the kernel is instantiated per density count, precision
 // and width, and the units compile in parallel): fp64 products of 2..4 densities at every workgroup width, the same
-// in fp32 plus fp32 products of 8 densities (-DKDEHIP_LEAN_F32), and fp64 products of 8 densities at 8 and 16 chains per
-// workgroup (-DKDEHIP_LEAN_HI).
+// in fp32 (-DKDEHIP_LEAN_F32), and fp64 products of 5..8 densities at 8 and 16 chains per workgroup (-DKDEHIP_LEAN_HI).
 // (Products of 5, 6 and 7 densities run the general kernel since round 3: their instantiations were a third of the
 // library's build time; a run-time density count inside a capacity-8 kernel was tried instead and made the register
 // allocator spill -- config 4, 2048 chains: 4.74 -> 6.28 ms -- so the density count stays a compile-time constant.)
 #if defined(KDEHIP_LEAN_HI) || (defined(KDEHIP_LEAN_DEV_M) && KDEHIP_LEAN_DEV_M > 4)
-constexpr bool lean_covers(int M) { return M == 8; }
-#elif defined(KDEHIP_LEAN_F32) && !defined(KDEHIP_LEAN_DEV)
-constexpr bool lean_covers(int M) { return (M >= 2 && M <= 4) || M == 8; }  // (fp32: 2..4 and 8 densities in one unit)
+constexpr int kLeanMinDens = 8, kLeanMaxDens = 8;
 #else
-constexpr bool lean_covers(int M) { return M >= 2 && M <= 4; }
+constexpr int kLeanMinDens = 2, kLeanMaxDens = 4;
 #endif
 constexpr int kLeanMaxNormals = 128;  // D*(L+1) normals of a chain kept in LDS (1 KiB per wavefront)
 
@@ -707,7 +704,8 @@ int KDEHIP_CAT(launch_lean_batch_d, KDEHIP_DIM)(int, const PlanDev &, const RunA
 int KDEHIP_CAT(KDEHIP_LEAN_ENTRY, KDEHIP_DIM)(int precision, int mode, const PlanDev &plan, const RunArgs &args,
                                               void *stream) {
   constexpr int D = KDEHIP_DIM;
-  if (mode != kModeFast || args.table_build || !lean_covers(plan.M) || D * (plan.L + 1) > kLeanMaxNormals)
+  if (mode != kModeFast || args.table_build || plan.M < kLeanMinDens || plan.M > kLeanMaxDens ||
+      D * (plan.L + 1) > kLeanMaxNormals)
     return kLeanNotCovered;
   if (args.Np <= 0) return KDEHIP_OK;
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -738,8 +736,7 @@ int KDEHIP_CAT(KDEHIP_LEAN_ENTRY, KDEHIP_DIM)(int precision, int mode, const Pla
   switch (plan.M) {
     case 2: return launch_lean_m<float, D, 2>(plan, args, st);
     case 3: return launch_lean_m<float, D, 3>(plan, args, st);
-    case 4: return launch_lean_m<float, D, 4>(plan, args, st);
-    default: return launch_lean_m_hi<float, D, 8>(plan, args, st);  // 8 densities: 8 and 16 chains per workgroup (round 4)
+    default: return launch_lean_m<float, D, 4>(plan, args, st);
   }
 #else
   if (!f64) return kLeanNotCovered;

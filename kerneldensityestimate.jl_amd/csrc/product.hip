@@ -442,7 +442,7 @@ int kdehip_product_launch_geometry(const kdehip_product *plan, int64_t Np, int32
   DeviceGuard guard;
   const int rc = guard.enter(plan->device);  // (the width heuristic asks the plan's device for its CU count)
   if (rc != KDEHIP_OK) return rc;
-  const bool lean = plan->mode == kModeFast && ((plan->host.M >= 2 && plan->host.M <= 4) || plan->host.M == 8);
+  const bool lean = plan->mode == kModeFast && ((plan->host.M >= 2 && plan->host.M <= 4) || (plan->host.M == 8 && plan->precision == 64));
   LeanGeometry g{chains_per_workgroup(Np, plan->variant), 1, 0, 0};
   const int v = plan->variant % 1000;
   if (lean && !(v >= kVariantGenericBase && v < kVariantGenericBase + 20))
@@ -458,7 +458,7 @@ const char *kdehip_product_kernel_name(const kdehip_product *plan, int64_t Np) {
   const bool forced_general = (v >= kVariantGenericBase && v < kVariantGenericBase + 20);
   const int M = plan->host.M, L = plan->host.L, D = plan->host.D;
   bool lean = !forced_general && plan->mode == kModeFast && D * (L + 1) <= 128 &&
-              ((M >= 2 && M <= 4) || M == 8);
+              ((M >= 2 && M <= 4) || (M == 8 && plan->precision == 64));
   if (lean && M == 8) {  // (the 8-density instantiations exist for 8 and 16 chains per workgroup)
     DeviceGuard guard;
     if (guard.enter(plan->device) != KDEHIP_OK) return "";

@@ -110,10 +110,10 @@ def test_lean_kernel_widths_and_caller_streams(width):
 
 
 def test_which_kernel_runs_is_pinned():
-    """The register-resident kernel exists for products of 2..4 densities and of 8 (BASELINE config 4's count; fp32 since
-    round 4) in both precisions, the 8-density ones at 8 and 16 chains per workgroup; everything else -- 5..7 densities,
-    more than 8, masked products, one-density "products" -- runs the general kernel (their instantiations were dropped in
-    round 3: a third of the build).  Pinned here so that a change of the dispatch shows up as a change of this test."""
+    """The register-resident kernel exists for products of 2..4 densities (both precisions) and for fp64 products of 8
+    (BASELINE config 4) at 8 and 16 chains per workgroup; everything else -- 5..7 densities, fp32 products of more than
+    4, masked products, one-density "products" -- runs the general kernel (their instantiations were dropped in round 3:
+    a third of the build).  Pinned here so that a change of the dispatch shows up as a change of this test."""
     rng = np.random.default_rng(0)
     def plan_of(M, prec=64, mask=None, D=2):
         trees = [kdehip.kde(rng.standard_normal((D, 40)), [0.3]) for _ in range(M)]
@@ -125,13 +125,12 @@ def test_which_kernel_runs_is_pinned():
     for M in (5, 6, 7, 9):
         with plan_of(M) as p:
             assert p.kernel_name(2048) == "gibbs_product_kernel"
-    for prec in (64, 32):
-        with plan_of(8, prec) as p:
-            assert p.kernel_name(2048) == "gibbs_lean_kernel" and p.kernel_name(16384) == "gibbs_lean_kernel"
-            assert p.kernel_name(512) == "gibbs_product_kernel"     # 4 chains per workgroup: not instantiated for 8 densities
-            p.set_variant(38)
-            assert p.kernel_name(2048) == "gibbs_product_kernel"    # plan variants 30+ force the general kernel
-    for M in (5, 7):
+    with plan_of(8) as p:
+        assert p.kernel_name(2048) == "gibbs_lean_kernel" and p.kernel_name(16384) == "gibbs_lean_kernel"
+        assert p.kernel_name(512) == "gibbs_product_kernel"     # 4 chains per workgroup: not instantiated for 8 densities
+        p.set_variant(38)
+        assert p.kernel_name(2048) == "gibbs_product_kernel"    # plan variants 30+ force the general kernel
+    for M in (5, 8):
         with plan_of(M, prec=32) as p:
             assert p.kernel_name(2048) == "gibbs_product_kernel"
     with plan_of(1) as p:
