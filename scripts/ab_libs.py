@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--nout", type=int, default=0)
     ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--prec", type=int, default=0, help="override the configuration's precision (32 / 64)")
     args = ap.parse_args()
     import torch
     import bench
@@ -45,6 +46,8 @@ def main():
         D, M, N, Nout, Niter, prec, cid = bench.CONFIGS[cname]
         if args.nout:
             Nout = args.nout
+        if args.prec:
+            prec = args.prec
         pts, bws = bench.synth_inputs(kdehip, D, M, N, cid)
         trees = [kdehip.kde(p, b) for p, b in zip(pts, bws)]
         arr = (_lib.CDensity * M)(*[t._cstruct() for t in trees])
