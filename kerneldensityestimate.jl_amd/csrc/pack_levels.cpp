@@ -166,7 +166,7 @@ int pack_layout(int Ndens, const kdehip_density *trees, int ndims, const uint8_t
   std::vector<int> rcs(static_cast<size_t>(M), KDEHIP_OK);
   int64_t points = 0;
   for (int j = 0; j < M; ++j) points += trees[j].npts;
-  HostPool *pool = (M > 1 && points >= 8192) ? &HostPool::get() : nullptr;
+  HostPool *pool = (M > 1 && points >= 2048) ? &HostPool::get() : nullptr;
   const bool look = pmode == kPackChecked;
   if (pool && pool->workers() > 0) {
     TaskGroup group(*pool);
@@ -361,13 +361,14 @@ struct FillFindings {
   FillFindings() { for (int d = 0; d < KDEHIP_MAX_DIMS; ++d) { lo[d] = INFINITY; hi[d] = 0.0; } }
 };
 
-// the tiles of density j: levels 0 .. L, contiguous in `data` (and in `perm`), no other density's elements touched
+// the tiles of density j, levels l0 .. l1 - 1: contiguous in `data` (and in `perm`), no other tile's elements touched
 template <typename T>
-static void fill_density(const PackedProduct &pp, const kdehip_density &t, int j, T *data, int32_t *perm, FillFindings &f) {
+static void fill_density(const PackedProduct &pp, const kdehip_density &t, int j, int l0, int l1, T *data, int32_t *perm,
+                         FillFindings &f) {
   const int D = pp.D, L = pp.L;
   bool bad = false;
   double *lo = f.lo, *hi = f.hi;
-  for (int l = 0; l <= L; ++l) {
+  for (int l = l0; l < l1; ++l) {
     const size_t idx = static_cast<size_t>(j) * (L + 1) + l;
     const LevelDesc &ds = pp.levels[idx];
     const int32_t *cur = pp.front.data() + pp.front_off[idx];
@@ -461,23 +462,27 @@ constexpr int64_t kParallelFillElems = 32 * 1024;  // smaller products are packe
 template <typename T>
 static bool fill_tiles(const PackedProduct &pp, const kdehip_density *trees, T *data, int32_t *perm) {
   const int D = pp.D, M = pp.M;
-  std::vector<FillFindings> part(static_cast<size_t>(M));
-  // the densities' tiles are independent: each is packed by a thread of the host pool (csrc/host_pool.hpp), the
-  // calling thread takes the first and whatever no worker has started by the time it is done
-  HostPool *pool = (M > 1 && pp.data_elems >= kParallelFillElems) ? &HostPool::get() : nullptr;
+  const int L = pp.L;
+  std::vector<FillFindings> part(static_cast<size_t>(2 * M));
+  // the tiles are independent: each density is packed by threads of the host pool (csrc/host_pool.hpp) in two tasks of
+  // about the same size -- its deepest level (half its frontier nodes) and all the levels above it; the calling thread
+  // takes the first task and whatever no worker has started by the time it is done
+  HostPool *pool = (pp.data_elems >= kParallelFillElems) ? &HostPool::get() : nullptr;
   if (pool && pool->workers() > 0) {
     TaskGroup group(*pool);
-    for (int j = 1; j < M; ++j)
-      group.run([&pp, trees, j, data, perm, &part] { fill_density<T>(pp, trees[j], j, data, perm, part[j]); });
-    fill_density<T>(pp, trees[0], 0, data, perm, part[0]);
+    for (int j = 0; j < M; ++j) {
+      if (j > 0) group.run([&pp, trees, j, L, data, perm, &part] { fill_density<T>(pp, trees[j], j, 0, L, data, perm, part[2 * j]); });
+      group.run([&pp, trees, j, L, data, perm, &part] { fill_density<T>(pp, trees[j], j, L, L + 1, data, perm, part[2 * j + 1]); });
+    }
+    fill_density<T>(pp, trees[0], 0, 0, L, data, perm, part[0]);
     group.wait();
   } else {
-    for (int j = 0; j < M; ++j) fill_density<T>(pp, trees[j], j, data, perm, part[j]);
+    for (int j = 0; j < M; ++j) fill_density<T>(pp, trees[j], j, 0, L + 1, data, perm, part[2 * j]);
   }
   bool bad = false;
   double lo[KDEHIP_MAX_DIMS], hi[KDEHIP_MAX_DIMS];
   for (int d = 0; d < KDEHIP_MAX_DIMS; ++d) { lo[d] = INFINITY; hi[d] = 0.0; }
-  for (int j = 0; j < M; ++j) {
+  for (int j = 0; j < 2 * M; ++j) {
     bad |= part[j].bad;
     for (int d = 0; d < D; ++d) {
       lo[d] = part[j].lo[d] < lo[d] ? part[j].lo[d] : lo[d];
