@@ -524,16 +524,32 @@ def call_inclusive(kdehip, trees, plan, D, M, Nout, Niter, seed, prec):
     K, R = plan.randu_per_sample(Niter), plan.randn_per_sample()
     randU, randN = kdehip.philox_streams(seed, 0, Nout, K, R)
 
-    def med(f, n=15):
+    def med(f, n=15, busy_s=0.040):
+        # (the calls are blocking, so the device idles between them and before the first: the same calls are first repeated
+        # for 40 ms, which brings the device's clock to what a caller that issues products back to back sees -- `spin_up`
+        # in main(); `from_idle_ms` below is the other end: the first calls after half a second of idle)
         f()
-        f()
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < busy_s:
+            f()
         ts = []
         for _ in range(n):
             t = time.perf_counter()
             f()
             ts.append(time.perf_counter() - t)
         return float(np.median(ts)) * 1e3
-    t_prod = med(lambda: kdehip.prodAppxMSGibbsS(None, trees, None, None, Niter=Niter, Np=Nout, seed=seed, precision=prec))
+
+    def from_idle(f, n=15):
+        time.sleep(0.5)
+        ts = []
+        for _ in range(n):
+            t = time.perf_counter()
+            f()
+            ts.append(time.perf_counter() - t)
+        return float(np.median(ts)) * 1e3
+    prod = lambda: kdehip.prodAppxMSGibbsS(None, trees, None, None, Niter=Niter, Np=Nout, seed=seed, precision=prec)  # noqa: E731
+    t_prod = med(prod)
+    t_prod_idle = from_idle(prod)
     t_g1 = med(lambda: kdehip.prodAppxMSGibbsS(None, trees, None, None, Niter=Niter, Np=Nout, randU=randU, randN=randN)) \
         if prec == 64 else None
     t_res = med(lambda: plan.sample(Nout, Niter=Niter, seed=seed))
@@ -542,7 +558,9 @@ def call_inclusive(kdehip, trees, plan, D, M, Nout, Niter, seed, prec):
     for d in dd:
         d.close()
     return {"ms": t_prod, "samples_per_sec": Nout / (t_prod * 1e-3),
-            "what": "prodAppxMSGibbsS, device Philox: pack + H2D + kernel + D2H, host buffers in and out (median of 15)",
+            "what": "prodAppxMSGibbsS, device Philox: pack + H2D + kernel + D2H, host buffers in and out (median of 15 "
+                    "blocking calls after 40 ms of the same calls)",
+            "from_idle_ms": t_prod_idle,   # median of the first 15 calls after 0.5 s of idle: the clock ramp included
             "gibbs1_caller_streams_ms": t_g1, "randU_MB_over_pcie": randU.nbytes / 1e6,
             "densities_resident_host_outputs_ms": t_dev,   # kdehip_prod_philox_resident: GPU re-layout, one copy back
             "resident_plan_run_plus_d2h_ms": t_res}
