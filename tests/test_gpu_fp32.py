@@ -163,7 +163,8 @@ def test_config5_total_chain_count_on_one_gpu():
 
 def test_fp32_row_pair_tiles_give_one_result_through_every_kernel():
     """fp32 tiles keep the two rows of a pair adjacent (kdehip_internal.hpp TileAddr): the same fp32 product through
-    the register-resident sampler at 4 / 8 / 16 chains per workgroup, the general kernel at 4 / 8 / 16, a host-packed plan
+    the register-resident sampler at 4 / 8 / 16 chains per workgroup (also with every tile read from global memory, and without
+    the conditional tables), the general kernel at 4 / 8 / 16, a host-packed plan
     and GPU-packed resident densities must be bit-identical -- odd and even rows per lane, resident / streamed / chunked
     tiles, masks (scripts/soak_fp32_layout.py, 40 random shapes)."""
     import os
