@@ -67,6 +67,11 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan_
   // pass 1 prefetches the next row's fields while it evaluates the current one; the 16-wavefront fp64
   // builds have 128 VGPRs and would spill from D = 6 on
   constexpr bool kPrefetchRows = (WAVES <= 12) || sizeof(T) == 4 || D <= 4;
+#ifdef KDEHIP_X_ALLCOPY  // (A/B only: rounds 1-3)
+  constexpr int kCopyWaves = WAVES;
+#else
+  constexpr int kCopyWaves = WAVES >= 8 ? WAVES / 2 : WAVES;  // who issues the copies of streamed tiles and chunks (gibbs_lean.hip)
+#endif
   using Lay = LdsLayout<T, D, WAVES>;
   __shared__ __attribute__((aligned(1024))) unsigned char smem[TBL ? Lay::kPoolOff : Lay::kBytes];
 
@@ -235,8 +240,10 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan_
     const int RS = TA::stride(ds.F), rc = chunk_rows(ds);
     const int nrows = (ds.B - r0 < rc) ? (ds.B - r0) : rc;
     const int bytes = (static_cast<int>(TA::span(nrows, RS)) * int(sizeof(T)) + 1023) & ~1023;  // (r0: a multiple of 4 rows)
-    stage_tile<WAVES>(reinterpret_cast<const unsigned char *>(data + ds.hdr_off + kTileHeader + TA::row(r0, RS)),
-                      pool + half * (kLdsPoolBytes / 2), bytes, wave, lane);
+    // (issued by the older wavefronts of every SIMD only, as in gibbs_lean.hip: kCopyWaves)
+    if (wave < kCopyWaves)
+      stage_tile<kCopyWaves>(reinterpret_cast<const unsigned char *>(data + ds.hdr_off + kTileHeader + TA::row(r0, RS)),
+                             pool + half * (kLdsPoolBytes / 2), bytes, wave, lane);
   };
   auto step_chunked = [&](int j, const LevelDesc &ds, const LevelDesc &dn, bool has_next, T mean, T cov, double u) {
     const T *hdr = data + ds.hdr_off;
@@ -440,10 +447,16 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan_
           staging_barrier();
           KSTAMP(tb1);
           KSTAMP_ADD(6, tb0, tb1);
-          if (t + 1 < nsteps)
+          // (the next tile's copy: at the end of the step by the older wavefronts, gibbs_lean.hip "kLateCopy"; with one
+          // wavefront per SIMD at its start by everyone)
+          constexpr bool kLateCopy = kCopyWaves < WAVES;
+          if (!kLateCopy && t + 1 < nsteps)
             stage_tile<WAVES>(reinterpret_cast<const unsigned char *>(data + ds_next.hdr_off),
                        pool + ((t + 1) & 1) * (kLdsPoolBytes / 2), ds_next.stage_bytes, wave, lane);
           step(j, ds, (LdsPtr<T>)(pool + (t & 1) * (kLdsPoolBytes / 2)), mean, cov, u);
+          if (kLateCopy && t + 1 < nsteps && wave < kCopyWaves)
+            stage_tile<kCopyWaves>(reinterpret_cast<const unsigned char *>(data + ds_next.hdr_off),
+                                   pool + ((t + 1) & 1) * (kLdsPoolBytes / 2), ds_next.stage_bytes, wave, lane);
         }
         j = jn;
       }

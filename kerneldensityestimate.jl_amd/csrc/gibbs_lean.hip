@@ -104,6 +104,13 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
   constexpr bool kPrefetchRows = (WAVES <= 12) || sizeof(T) == 4 || D <= 4;  // as in gibbs_kernel.hip
   // how the rows of an LDS tile are read: see LdsPtrSplit (fp32 reads its row pairs as single loads either way: load_pair)
   using RowPtr = std::conditional_t<(WAVES == 16 && sizeof(T) == 8), LdsPtrSplit<T>, LdsPtr<T>>;
+  // the wavefronts that issue the copies of streamed tiles and chunks: the older half of the workgroup (wavefronts w and
+  // w + 4 share a SIMD, the lower one is the older: scripts/micro/simd_map.hip); everyone when each SIMD has one
+#ifdef KDEHIP_X_ALLCOPY  // (A/B only: rounds 1-3, every wavefront issues its share at the start of the step)
+  constexpr int kCopyWaves = WAVES;
+#else
+  constexpr int kCopyWaves = WAVES >= 8 ? WAVES / 2 : WAVES;
+#endif
   constexpr bool kKeptRows = (WAVES <= 8);
   constexpr bool kPreloadBuild = kKeptRows && kPrefetchRows && !(TEAMS && WAVES == 16);
   // wavefront teams (a chain on 2 or 4 wavefronts, RunArgs.team): the 16-wavefront fp64 builds
@@ -346,8 +353,11 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
     const int RS = TA::stride(ds.F), rc = ds.chunk_rows;
     const int nrows = (ds.B - r0 < rc) ? (ds.B - r0) : rc;
     const int bytes = (static_cast<int>(TA::span(nrows, RS)) * int(sizeof(T)) + 1023) & ~1023;  // (r0: a multiple of 4 rows)
-    stage_tile<WAVES>(reinterpret_cast<const unsigned char *>(data + ds.hdr_off() + kTileHeader + TA::row(r0, RS)),
-                      pool + half * (kLdsPoolBytes / 2), bytes, wave, lane);
+    const unsigned char *src = reinterpret_cast<const unsigned char *>(data + ds.hdr_off() + kTileHeader + TA::row(r0, RS));
+    // Issued by the OLDER wavefront(s) of every SIMD only (kCopyWaves): a `buffer_load ... lds` costs its issuer 60-180
+    // cycles, the hardware serves the older wavefront of a SIMD first, so the younger one is the step's critical path
+    // and the older one waits for it at the next barrier anyway (config 4: 4.36 -> 4.16 ms, profiles/r04_experiments.md)
+    if (wave < kCopyWaves) stage_tile<kCopyWaves>(src, pool + half * (kLdsPoolBytes / 2), bytes, wave, lane);
   };
 
 #ifdef KDEHIP_EXPERIMENTS  // diagnostic builds: variant 100+k stops after level k (scripts/level_profile.sh)
@@ -441,7 +451,11 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
           // tile t has been copied by all wavefronts once everyone passes this barrier; buffer (t+1)&1 was last
           // read in step t-1, which everyone has left -> start the next copy
           staging_barrier();
-          if (t + 1 < nsteps)
+          // The copy of the next tile: at the END of this step by the older wavefronts (kCopyWaves) -- they finish first and
+          // would idle at the next barrier -- instead of by everyone at its start, where it delayed every wavefront's rows
+          // (config 3: 0.5726 -> 0.5569 ms).  With one wavefront per SIMD: at the start, as before.
+          constexpr bool kLateCopy = kCopyWaves < WAVES;
+          if (!kLateCopy && t + 1 < nsteps)
             stage_tile<WAVES>(reinterpret_cast<const unsigned char *>(data + dn.hdr_off()),
                               pool + ((t + 1) & 1) * (kLdsPoolBytes / 2), dn.stage_bytes, wave, lane);
           if (active) {
@@ -454,6 +468,9 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
             }));
             adopt(jc, ds, hdr, pos);
           }
+          if (kLateCopy && t + 1 < nsteps && wave < kCopyWaves)
+            stage_tile<kCopyWaves>(reinterpret_cast<const unsigned char *>(data + dn.hdr_off()),
+                                   pool + ((t + 1) & 1) * (kLdsPoolBytes / 2), dn.stage_bytes, wave, lane);
           ++t;
         });
     } else if (mode == kStageChunked) {

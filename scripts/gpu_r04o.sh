@@ -1,6 +1,6 @@
-# round 4 (l): split LDS reads (fp32 pairs, 16-chain fp64 builds) -- GPU suite, fp32 soak, bench c5 / c3 / c4
+# round 4 (o): tile and chunk copies by the older wavefronts -- GPU suite, fp32 soak, bench c5 / c3 / c4
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r04l; mkdir -p $O
+O=gpurun_out/r04o; mkdir -p $O
 timeout 1500 python -m pytest tests -q -m gpu -x > $O/gpu_tests.txt 2>&1; tail -n 6 $O/gpu_tests.txt
 timeout 600 python scripts/soak_fp32.py 800 2>&1 | tail -1 > $O/soak.txt
 timeout 600 python scripts/soak_chunked.py 400 2>&1 | tail -1 >> $O/soak.txt
