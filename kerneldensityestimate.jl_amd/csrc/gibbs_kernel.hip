@@ -70,7 +70,7 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan_
 #ifdef KDEHIP_X_ALLCOPY  // (A/B only: rounds 1-3)
   constexpr int kCopyWaves = WAVES;
 #else
-  constexpr int kCopyWaves = WAVES >= 8 ? WAVES / 2 : WAVES;  // who issues the copies of streamed tiles and chunks (gibbs_lean.hip)
+  constexpr int kCopyWaves = WAVES > 4 ? 4 : WAVES;  // who issues the copies of streamed tiles and chunks (gibbs_lean.hip)
 #endif
   using Lay = LdsLayout<T, D, WAVES>;
   __shared__ __attribute__((aligned(1024))) unsigned char smem[TBL ? Lay::kPoolOff : Lay::kBytes];

@@ -104,12 +104,12 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
   constexpr bool kPrefetchRows = (WAVES <= 12) || sizeof(T) == 4 || D <= 4;  // as in gibbs_kernel.hip
   // how the rows of an LDS tile are read: see LdsPtrSplit (fp32 reads its row pairs as single loads either way: load_pair)
   using RowPtr = std::conditional_t<(WAVES == 16 && sizeof(T) == 8), LdsPtrSplit<T>, LdsPtr<T>>;
-  // the wavefronts that issue the copies of streamed tiles and chunks: the older half of the workgroup (wavefronts w and
-  // w + 4 share a SIMD, the lower one is the older: scripts/micro/simd_map.hip); everyone when each SIMD has one
+  // the wavefronts that issue the copies of streamed tiles and chunks: the OLDEST wavefront of every SIMD (wavefronts w,
+  // w + 4, w + 8, w + 12 share a SIMD, the lowest is the oldest: scripts/micro/simd_map.hip); everyone when each SIMD has one
 #ifdef KDEHIP_X_ALLCOPY  // (A/B only: rounds 1-3, every wavefront issues its share at the start of the step)
   constexpr int kCopyWaves = WAVES;
 #else
-  constexpr int kCopyWaves = WAVES >= 8 ? WAVES / 2 : WAVES;
+  constexpr int kCopyWaves = WAVES > 4 ? 4 : WAVES;  // (16 wavefronts: the oldest of the four on a SIMD; its half: c5 +0.8 %)
 #endif
   constexpr bool kKeptRows = (WAVES <= 8);
   constexpr bool kPreloadBuild = kKeptRows && kPrefetchRows && !(TEAMS && WAVES == 16);
