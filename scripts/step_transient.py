@@ -19,8 +19,21 @@ def main():
     st = torch.cuda.current_stream(dev)
     outp = [torch.empty(D * Nout, dtype=torch.float64, device=dev) for _ in range(2)]
     outi = [torch.empty(M * Nout, dtype=torch.int64, device=dev) for _ in range(2)]
+    spin = len(sys.argv) > 3
+    if spin:
+        plan = kdehip.ProductPlan(trees, precision=prec, device=0)
     for rep in range(2):
         torch.cuda.synchronize(); time.sleep(idle)
+        if spin:   # bench.py's order: 40 ms of resident-plan launches, 5 warm-up calls, a synchronize, then the timed calls
+            ts = time.perf_counter()
+            while time.perf_counter() - ts < 0.040:
+                for _ in range(4):
+                    plan.sample_philox_device(Nout, Niter, 1, 0, True, outp[0], outi[0], None, st.cuda_stream)
+                torch.cuda.synchronize()
+            for i in range(5):
+                kdehip.prodAppxMSGibbsS_device(dd, outp[i & 1], outi[i & 1], Np=Nout, Niter=Niter, seed=1, sample_offset=i * Nout,
+                                               precision=prec, stream=st.cuda_stream)
+            torch.cuda.synchronize()
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
         host = []
         ev[0].record(st)
