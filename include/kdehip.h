@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define KDEHIP_VERSION 400 /* 0.4.0 */
+#define KDEHIP_VERSION 500 /* 0.5.0 */
 
 enum {
   KDEHIP_OK = 0,
@@ -156,14 +156,21 @@ int kdehip_product_sample_philox_host(kdehip_product *plan, int64_t Np, int Nite
  * (`pT < 1e-99` -> uniform draw over the frontier, src/MSGibbs01.jl:311-315).  Waits for the device.
  * Negative = error code. */
 int64_t kdehip_product_fallback_count(kdehip_product *plan);
+/* Diagnostic: fp32 screening of the deep levels (fp64 plans of 2..4 or 8 densities with every dimension active): on a
+ * level whose fp64 tiles are streamed through LDS one at a time, the plan also holds the level's tiles in fp32, resident in
+ * LDS together; a draw step evaluates the frontier in packed fp32 with a rigorous bound on the error of its cumulative
+ * sums and keeps the fp32 decision only when the uniform draw is farther than that bound from every boundary it could
+ * cross -- otherwise the step is repeated in fp64.  Labels and points are those of the fp64 arithmetic bit for bit
+ * (csrc/screen_device.hpp).  levels: how many levels of the plan are screened; steps / repeats: label draws
+ * taken on screened levels so far, and how many of them were repeated in fp64.  Waits for the device.  Any pointer may be
+ * NULL. */
+int kdehip_product_screen_stats(kdehip_product *plan, int32_t *levels, int64_t *steps, int64_t *repeats);
 /* Scheduling knob for experiments/benchmarks; results never depend on it.  0 = library default,
- * 1 = read every tile from global memory (no LDS staging), 4 = no conditional tables,
- * 2 / 8 / 16 = 4 / 8 / 16 chains per workgroup, one wavefront per chain; 52 / 54 = workgroups of 16
- * wavefronts as 8 chains x 2 / 4 chains x 4 wavefronts (a TEAM of wavefronts shares the rows of a chain's deep
- * levels; fp64 products of 2..8 densities).  Default: chosen from the number of chains and the depth of the trees. */
+ * 1 = read every tile from global memory (no LDS staging), 4 = no conditional tables, 5 = no fp32 screening,
+ * 2 / 8 / 16 = 4 / 8 / 16 chains per workgroup (one wavefront per chain).  Default: chosen from the number of chains. */
 int kdehip_product_set_variant(kdehip_product *plan, int variant);
 /* Diagnostic: the launch geometry a run of Np chains of this plan gets under its current variant -- wavefronts per
- * workgroup and wavefronts per chain (1 = no team). */
+ * workgroup and wavefronts per chain (always 1 since round 5: a chain is one wavefront). */
 int kdehip_product_launch_geometry(const kdehip_product *plan, int64_t Np, int32_t *waves_per_workgroup,
                                    int32_t *waves_per_chain);
 /* Diagnostic: the sampling kernel a run of Np chains of this plan launches under its current variant --

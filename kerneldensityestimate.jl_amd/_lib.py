@@ -85,6 +85,7 @@ SIGNATURES = {
                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "kdehip_product_sample_philox_host": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_uint64, C.c_int64,
                                                     C.c_int, f64p, i64p, i32p]),
+    "kdehip_product_screen_stats": (C.c_int, [C.c_void_p, i32p, i64p, i64p]),
     "kdehip_product_set_variant": (C.c_int, [C.c_void_p, C.c_int]),
     "kdehip_product_launch_geometry": (C.c_int, [C.c_void_p, C.c_int64, i32p, i32p]),
     "kdehip_product_kernel_name": (C.c_char_p, [C.c_void_p, C.c_int64]),

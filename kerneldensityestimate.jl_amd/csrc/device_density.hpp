@@ -48,6 +48,9 @@ struct FillJob {
 };
 static_assert(sizeof(FillJob) == 80, "FillJob layout");
 int launch_fill_tiles(int precision, const FillJob *d_jobs, int ntiles, int maxB, void *stream);
+// The fp32 screen tiles of an fp64 plan (kdehip_internal.hpp "fp32 screening") from its fp64 tiles, one workgroup per
+// (density, level); enqueue only.
+int launch_screen_build(const PlanDev &plan, void *stream);
 
 }  // namespace kdehip
 

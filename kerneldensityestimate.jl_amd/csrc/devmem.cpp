@@ -125,11 +125,10 @@ void cached_host_free(void *p, size_t bytes) {
 
 }  // namespace kdehip
 
-extern "C" void kdehip_internal_drain_pending();  // product.hip: plans of enqueue-only device products still waiting for their work
 
 extern "C" void kdehip_clear_cache(void) {
   using namespace kdehip;
-  kdehip_internal_drain_pending();
+  kdehip::drain_pending();  // product.hip: plans of enqueue-only device products still waiting for their work
   int cur = 0;
   const bool have_cur = hipGetDevice(&cur) == hipSuccess;
   int n = 0;

@@ -471,13 +471,11 @@ template <typename P> constexpr bool kIsLdsPtr = false;
 template <typename T> constexpr bool kIsLdsPtr<const __attribute__((address_space(3))) T *> = true;
 template <typename T> constexpr bool kIsLdsPtr<const volatile __attribute__((address_space(3))) T *> = true;
 
-// ---- the lane's sum over its rows: ONE association for every kernel, width, team size and staging mode ----------
-// S = (a0 + a1) + (a2 + a3), where a_k is the sum, in increasing row order, of the lane's rows r = k (mod 4).
-// A wavefront that owns the whole chain keeps the four sums itself (lane_rows_all); when a chain is split over a
-// team of 2 (4) wavefronts, member t keeps a_{2t}, a_{2t+1} (a_t) of its rows only (lane_rows_member) and the
-// partial sums meet in LDS (team_combine): both forms add the very same numbers in the very same order, so which
-// label a uniform draw selects never depends on how many wavefronts worked on the chain.  Chunked tiles keep the
-// sums across chunks (chunk starts are multiples of 4 rows, so a row's class is its class inside the chunk).
+// ---- the lane's sum over its rows: ONE association for every kernel, width and staging mode ----------------------
+// S = (a0 + a1) + (a2 + a3), where a_k is the sum, in increasing row order, of the lane's rows r = k (mod 4): every
+// form of the first pass (two rows per trip, four, kept rows, chunks) adds the very same numbers in the very same order,
+// so which label a uniform draw selects never depends on a scheduling choice.  Chunked tiles keep the sums across chunks
+// (chunk starts are multiples of 4 rows, so a row's class is its class inside the chunk).
 template <typename T>
 struct LaneAcc {
   T a[4] = {T(0), T(0), T(0), T(0)};
@@ -557,46 +555,6 @@ __device__ __forceinline__ void lane_rows_all(P rows, int nrows, int RS, int lan
   }
 }
 
-// the rows of ONE member of a wavefront team: trips over rows (i, i + second) for i = first, first + stride, ...
-// (team of 2: first = 2t, second = 1, stride = 4, x = a_{2t}, y = a_{2t+1}; team of 4: first = t, second = 4,
-// stride = 8, both rows of a trip go to x = a_t in row order: `same`).  All arguments but `lane` are wave-uniform.
-// (fp64 builds only: the row offsets below are plain multiples of RS)
-template <typename T, typename P, typename Eval, bool PREFETCH = true>
-__device__ __forceinline__ void lane_rows_member(P rows, int nrows, int RS, int lane, const Eval &ev, int first,
-                                                 int second, int stride, bool same, T &x, T &y) {
-  static_assert(!TileAddr<T>::kPaired, "wavefront teams are fp64 builds");
-  int i = first;
-  if (i >= nrows) return;
-  P e = rows + lane + first * RS;
-  if constexpr (!PREFETCH) {
-    for (; i + second < nrows; i += stride, e += stride * RS) {
-      const T va = ev(e);
-      const T vb = ev(e + second * RS);
-      x += va;
-      if (same) x += vb; else y += vb;
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (i < nrows) x += ev(e);
-  } else {
-    typename Eval::Row ra = ev.load(e);
-    if constexpr (kIsLdsPtr<P>) __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) only
-    for (; i + second < nrows; i += stride) {
-      const typename Eval::Row rb = ev.load(e + second * RS);
-      __builtin_amdgcn_sched_barrier(0);
-      const typename Eval::Mid ma = ev.arg(ra);
-      __builtin_amdgcn_sched_barrier(0);
-      const typename Eval::Mid mb = ev.arg(rb);
-      e += (i + stride < nrows) ? stride * RS : second * RS;  // the next trip's first row, or stay inside the tile
-      ra = ev.load(e);
-      __builtin_amdgcn_sched_barrier(0);
-      x += ev.fin(ma);
-      const T vb = ev.fin(mb);
-      if (same) x += vb; else y += vb;
-    }
-    if (i < nrows) x += ev(ra);
-  }
-}
-
 // the canonical lane sum of a whole tile
 template <typename T, typename P, typename Eval, bool PREFETCH = true>
 __device__ __forceinline__ T lane_sum_rows(P rows, int nrows, int RS, int lane, const Eval &ev) {
@@ -609,8 +567,8 @@ __device__ __forceinline__ T lane_sum_rows(P rows, int nrows, int RS, int lane, 
 // in front of the plan's level table (a layout contract with product.hip: the table's address is live in scalar
 // registers anyway, so the counter costs the common path nothing): how tests compare the fp32 path's fallback
 // behaviour with fp64's and the oracle's.  `fb` = the level table's address.
-// Wavefronts whose draws must not be counted (the surplus wavefronts of the last workgroup, which replay the last chain,
-// and all but the first member of a wavefront team) pass fb = nullptr.
+// Wavefronts whose draws must not be counted (the surplus wavefronts of the last workgroup, which replay the last chain)
+// pass fb = nullptr.
 __device__ __forceinline__ void count_fallback(const void *fb, int lane) {
   if (fb != nullptr && lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(const_cast<void *>(fb)) - 1, 1ull);
 }
@@ -937,121 +895,6 @@ __device__ __forceinline__ int draw_label(P rows, const DS &ds, int lane, const 
   return select_or_raise<T, P>(S, rows, ds, lane, ev, u, fb KSTAMP_ARGS);
 }
 
-// ---- wavefront teams: one chain on 2 or 4 wavefronts ------------------------------------------------------------
-// With few chains per GPU (2048 per MI355X = two wavefronts per SIMD) the serial dependency chain of a step leaves the
-// vector pipes idle; on the deep levels (many rows per lane) the rows of a step are therefore shared by the wavefronts
-// of a TEAM: member t evaluates the rows whose class (row mod 4) it owns, the 64 partial lane sums of every member
-// meet in LDS (one workgroup barrier: all chains of a workgroup walk the schedule in lock step anyway), and from there
-// on every member repeats the identical selection -- same lane sums (LaneAcc's association), same scan, same second
-// pass -- so the members never diverge and need no further communication.  Every barrier below is executed by every
-// wavefront of the workgroup, whatever its chain's data look like.
-template <typename T>
-struct Team {
-  int size = 1;    // wavefronts per chain: 1, 2 or 4 (wave-uniform)
-  int member = 0;  // this wavefront's index in its team
-  int first = 0, second = 1, stride = 4;  // lane_rows_member's row walk of this member
-  bool same = false;
-  __attribute__((address_space(3))) T *xch = nullptr;    // the chain's strip [size][64]: partial lane sums
-  __attribute__((address_space(3))) T *notes = nullptr;  // the chain's strip [size][kMaxSeg]: segment sums of one lane
-  __device__ __forceinline__ void set(int size_, int member_) {
-    size = size_; member = member_;
-    same = (size_ == 4);
-    first = same ? member_ : 2 * member_;
-    second = same ? 4 : 1;
-    stride = same ? 8 : 4;
-  }
-};
-
-// LDS writes of this wavefront are complete, then the workgroup barrier (the direct-to-LDS copies that may be in
-// flight are NOT waited for: they belong to the staging protocol and its own barriers)
-__device__ __forceinline__ void team_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-// the lane sums of the whole chain from the members' partial sums, LaneAcc's association.  `pre_barrier`: the strip
-// may still be read by a slower member (no other workgroup barrier since the previous exchange: resident tiles).
-template <typename T>
-__device__ __forceinline__ T team_combine(T part, int lane, const Team<T> &tm, bool pre_barrier) {
-  if (pre_barrier) team_barrier();
-  tm.xch[tm.member * 64 + lane] = part;
-  team_barrier();
-  if (tm.size == 2) return tm.xch[lane] + tm.xch[64 + lane];
-  return (tm.xch[lane] + tm.xch[64 + lane]) + (tm.xch[128 + lane] + tm.xch[192 + lane]);
-}
-
-// draw_label for a tile readable through one pointer, rows shared by the team
-template <typename T, typename P, bool PREFETCH, typename Eval, typename DS>
-__device__ __forceinline__ int draw_label_team(P rows, const DS &ds, int lane, const Eval &ev, double u,
-                                               const void *fb, const Team<T> &tm, bool pre_barrier) {
-  T x = T(0), y = T(0);
-  lane_rows_member<T, P, Eval, PREFETCH>(rows, ds.B, TileAddr<T>::stride(ds.F), lane, ev, tm.first, tm.second, tm.stride, tm.same, x, y);
-  const T S = team_combine(x + y, lane, tm, pre_barrier);
-  return select_or_raise<T, P>(S, rows, ds, lane, ev, u, fb
-#ifdef KDEHIP_STAMPS
-                               , nullptr, false
-#endif
-  );
-}
-
-// select_or_raise_seg for a team: `seg` holds this member's share of the lane's running sums at the segment
-// boundaries; the shares of the winning lane meet in LDS (one more barrier) and are added in LaneAcc's association.
-template <typename T, typename P, typename Eval, typename DS>
-__device__ __forceinline__ int select_or_raise_seg_team(T S, const SegSums<T> &seg, int seg_rows, P rows, const DS &ds,
-                                                        int lane, const Eval &ev, double u, const void *fb,
-                                                        const Team<T> &tm) {
-  const int n = ds.n, B = ds.B;
-  const int RS = TileAddr<T>::stride(ds.F);
-  const T incl = wave_inclusive_scan(S);
-  const T total = lane_read(incl, 63);
-  const T target = static_cast<T>(u) * total;
-  const unsigned long long hit = __ballot(target <= incl);
-  const int last_lane = ds.last_lane;
-  int lstar = hit ? (__ffsll(hit) - 1) : last_lane;
-  if (lstar > last_lane) lstar = last_lane;
-  // (the exchange comes before the underflow test: every wavefront of the workgroup must pass the barrier)
-  T mine = T(0);
-#pragma unroll
-  for (int k = 0; k < kMaxSeg - 1; ++k) {
-    const T pk = lane_read(seg.v[k], lstar);
-    mine = (lane == k) ? pk : mine;
-  }
-  if (lane < kMaxSeg) tm.notes[tm.member * kMaxSeg + lane] = mine;
-  team_barrier();
-  if (!(total >= Num<T>::tiny_total())) return select_or_raise<T, P>(S, rows, ds, lane, ev, u, fb
-#ifdef KDEHIP_STAMPS
-                                                                     , nullptr, false
-#endif
-  );
-  const T base = lane_read(incl - S, lstar);
-  int lenl = n - lstar * B;
-  if (lenl > B) lenl = B;
-  const int nseg = seg_count(ds.seg);
-  int sidx = nseg - 1;
-  T before = T(0), run = T(0);
-  bool found = false;
-#pragma unroll
-  for (int k = 0; k < kMaxSeg - 1; ++k) {
-    if (k < nseg - 1) {  // wave-uniform
-      const T pk = (tm.size == 2) ? tm.notes[k] + tm.notes[kMaxSeg + k]
-                                  : (tm.notes[k] + tm.notes[kMaxSeg + k]) + (tm.notes[2 * kMaxSeg + k] + tm.notes[3 * kMaxSeg + k]);
-      if (!found && target <= base + pk) { found = true; sidx = k; before = run; }
-      run = pk;
-    }
-  }
-  if (!found) before = run;
-  int r0 = sidx * seg_rows;
-  if (r0 >= lenl) return (lenl - 1) * 64 + lstar;
-  int len = lenl - r0;
-  if (len > seg_rows) len = seg_rows;
-  P col = rows + lstar * TileAddr<T>::kLane;
-  T p2 = T(0);
-  if (lane < len) p2 = ev(col + TileAddr<T>::row(r0 + lane, RS));
-  const T inc3 = wave_inclusive_scan(p2);
-  const unsigned long long h3 = __ballot((target <= (base + before) + inc3) && (lane < len));
-  const int istar = h3 ? (__ffsll(h3) - 1) : (len - 1);
-  return (r0 + istar) * 64 + lstar;
-}
-
 // ---- the sampler ----------------------------------------------------------------------------------
 
 // LDS of one workgroup (ONE object, so the compiler keeps direct-to-LDS loads asynchronous):
@@ -1154,16 +997,17 @@ struct LaunchView {
 };
 // The run parameters of a batched workgroup: RunArgs' member names, scalars only (a copy of RunArgs itself -- with its
 // run-time-indexed peer arrays -- would have to live in scratch memory, and everything read from it would count as
-// divergent); no caller streams, no teams, no peers in a batched launch.
+// divergent); no caller streams, no peers in a batched launch.
 struct BatchArgs {
   int64_t Np;
   int32_t Niter, addEntropy, variant, use_tables;
+  static constexpr int32_t use_screen = 0;  // (batched launches run without the fp32 screen)
   uint64_t seed;
   int64_t sample_offset;
   double *points;
   int64_t *indices;
   int32_t *labels;
-  static constexpr int32_t rng_philox = 1, team = 1, team_level = 0, team_min_rows = 0, npeers = 0, table_build = 0;
+  static constexpr int32_t rng_philox = 1, npeers = 0, table_build = 0;
   static constexpr const double *randU = nullptr, *randN = nullptr;
   static constexpr int64_t K = 0, R = 0, nU = 0, nN = 0;
   double *peer_points[1];
@@ -1187,8 +1031,7 @@ struct LaunchView<true> {
     plan.data = h.data; plan.perm = h.perm; plan.levels = h.levels; plan.tables = h.tables; plan.tabdesc = h.tabdesc;
     plan.tab_rows_total = h.tab_rows_total;
     plan.M = h.M; plan.L = h.L; plan.D = h.D; plan.Lt = h.Lt;
-    plan.deep_level[0] = be.deep_level[0]; plan.deep_level[1] = be.deep_level[1];
-    plan.deep_share[0] = be.deep_share[0]; plan.deep_share[1] = be.deep_share[1];
+    plan.screened = 0;
     a.Np = be.Np; a.Niter = fl.Niter; a.addEntropy = fl.addEntropy; a.use_tables = fl.use_tables;
     a.variant = a_.variant;
     a.seed = be.seed; a.sample_offset = be.sample_offset;

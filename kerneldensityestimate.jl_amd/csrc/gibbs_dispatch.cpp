@@ -42,36 +42,11 @@ int chains_per_workgroup(int64_t Np, int variant) {
   return waves;
 }
 
-LeanGeometry lean_geometry(int64_t Np, int variant, int precision, const PlanDev &plan) {
-  const int v = variant % 1000;
-  LeanGeometry g{chains_per_workgroup(Np, variant), 1, 0, 0};
-  if (precision != 64) return g;  // (teams: the 16-wavefront fp64 builds of gibbs_lean.hip)
-  int team = 0;
-  const int vt = (variant / 1000) % 10;  // diagnostic builds combine a level cut-off (v = 100 + k) with a geometry: thousands digit
-  if (vt == 6) g.waves = 16;
-  if (vt == 8) g.waves = 8;
-#if !defined(KDEHIP_WITH_TEAMS) || !KDEHIP_WITH_TEAMS
-  // the team instantiations are not part of this build (make TEAMS=1): the team variants run as 16 one-wavefront chains
-  if (v == kVariantTeam2 || v == kVariantTeam4 || vt == 2 || vt == 4) { g.waves = 16; return g; }
-#endif
-  if (v == kVariantTeam2 || vt == 2) team = 2;
-  else if (v == kVariantTeam4 || vt == 4) team = 4;
-  else if (v == 0 && vt == 0) {
-    // Few chains and deep levels: a chain on 2 (4) wavefronts.  Workgroups of 16 wavefronts then hold 8 (4) chains;
-    // worth it while that still gives every CU at most one round and the shared levels carry most of the work.
-    // (kTeamMinShare currently switches this off: see its comment.)
-    const int64_t cus = device_cu_count();
-    if (Np <= 4 * cus && plan.deep_level[1] > 0 && plan.deep_share[1] >= kTeamMinShare) team = 4;
-    else if (Np <= 8 * cus && plan.deep_level[0] > 0 && plan.deep_share[0] >= kTeamMinShare) team = 2;
-  }
-  if (team) {
-    const int k = (team == 2) ? 0 : 1;
-    g.waves = 16;
-    g.team = team;
-    g.team_level = plan.deep_level[k] > 0 ? plan.deep_level[k] : plan.L + 1;  // (forced on a product without deep levels: member 0 works alone)
-    g.team_min_rows = kTeamMinRows[k];
-  }
-  return g;
+int lean_waves(int64_t Np, int variant) {
+  const int vt = (variant / 1000) % 10;
+  if (vt == 6) return 16;
+  if (vt == 8) return 8;
+  return chains_per_workgroup(Np, variant);
 }
 
 #define KDEHIP_DECL(d)                                                                  \

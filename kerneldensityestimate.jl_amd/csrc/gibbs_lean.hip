@@ -19,10 +19,8 @@
 #ifndef KDEHIP_PRELOAD_MAXB
 #define KDEHIP_PRELOAD_MAXB 8   // rows per lane up to which a resident step requests its first row ahead (see `step`)
 #endif
-#ifndef KDEHIP_WITH_TEAMS
-#define KDEHIP_WITH_TEAMS 0
-#endif
 #include "gibbs_device.hpp"
+#include "screen_device.hpp"
 
 namespace kdehip {
 
@@ -93,10 +91,7 @@ struct LeanTile {
 // (see `step`: the builds with registers to spare and the kept-rows second pass, on tiles that sit in LDS)
 template <typename P, typename T, bool OK> constexpr bool kCanPreloadImpl = OK && kIsLdsPtr<P> && sizeof(T) == 8;
 
-// TEAMS: the instantiation whose wavefronts can form teams (RunArgs.team = 2 or 4; 16-wavefront fp64 builds).  A kernel
-// of its own: with the team paths compiled in, a 16-wavefront build is up to 25 % slower even when every chain has one
-// wavefront (config 4 with 16,384 chains: 31 -> 39 ms), and that is the build large batches run.
-template <typename T, int D, int M, int WAVES, bool TEAMS = false, bool BATCH = false>
+template <typename T, int D, int M, int WAVES, bool BATCH = false>
 __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, RunArgs a_) {
   const LaunchView<BATCH> view(plan_, a_);
   const PlanDev &plan = view.plan;
@@ -112,15 +107,13 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
   constexpr int kCopyWaves = WAVES > 4 ? 4 : WAVES;  // (16 wavefronts: the oldest of the four on a SIMD; its half: c5 +0.8 %)
 #endif
   constexpr bool kKeptRows = (WAVES <= 8);
-  constexpr bool kPreloadBuild = kKeptRows && kPrefetchRows && !(TEAMS && WAVES == 16);
-  // wavefront teams (a chain on 2 or 4 wavefronts, RunArgs.team): the 16-wavefront fp64 builds
-  constexpr bool kTeams = TEAMS && (WAVES == 16) && sizeof(T) == 8;
-  // LDS: [exp table 2 KiB][normals: 1 KiB per chain; teams: the partial-sum strips in the upper half][uniforms:
-  // WAVES x 1 KiB][teams: 2 KiB of segment notes][tile pool]
+  // fp32 screening of the deep levels (screen_device.hpp): the fp64 instantiations of plain launches
+  constexpr bool kScreen = sizeof(T) == 8 && !BATCH;
+  constexpr bool kPreloadBuild = kKeptRows && kPrefetchRows;
+  // LDS: [exp table 2 KiB][normals: 1 KiB per chain][uniforms: WAVES x 1 KiB][tile pool]
   constexpr int kNormOff = 2048;
   constexpr int kUnifOff = kNormOff + WAVES * kLeanMaxNormals * 8;
-  constexpr int kNotesOff = kUnifOff + WAVES * 1024;
-  constexpr int kPoolOff = kNotesOff + (kTeams ? 2048 : 0);
+  constexpr int kPoolOff = kUnifOff + WAVES * 1024;
   static_assert(kPoolOff + kLdsPoolBytes <= 160 * 1024, "LDS budget of one CU exceeded");
   __shared__ __attribute__((aligned(1024))) unsigned char smem[kPoolOff + kLdsPoolBytes];
 
@@ -130,20 +123,10 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
   KDEHIP_PRIO_CHAIN();
-  // team geometry: chains of a workgroup = WAVES / team size; member 0 of a team owns the chain's outputs
-  int tsize = 1;
-  if constexpr (kTeams) tsize = a.team == 4 ? 4 : (a.team == 2 ? 2 : 1);
-  const int tshift = tsize >> 1;  // log2 of 1, 2, 4
-  // Members of a team are WAVES / team wavefronts apart: a workgroup's wavefronts go to the SIMDs in a cyclic order of
-  // four (scripts/micro/simd_map.hip), so the first members -- who walk the shallow levels alone -- are spread evenly
-  // over the four SIMDs (adjacent wavefronts as a team would park all first members on two of them).
-  const int chains_wg = WAVES >> tshift;
-  const int tmember = wave / chains_wg;
-  const int chain = wave - tmember * chains_wg;
-  int64_t s = static_cast<int64_t>(view.block) * (WAVES >> tshift) + chain;
-  const bool in_range = s < a.Np;  // surplus wavefronts of the last workgroup replay the last chain and store nothing
-  if (!in_range) s = a.Np - 1;
-  const bool live = in_range && tmember == 0;
+  const int chain = wave;  // one wavefront = one chain
+  int64_t s = static_cast<int64_t>(view.block) * WAVES + chain;
+  const bool live = s < a.Np;  // surplus wavefronts of the last workgroup replay the last chain and store nothing
+  if (!live) s = a.Np - 1;
   const uint64_t gs = static_cast<uint64_t>(a.sample_offset + s);
   const void *fb = live ? static_cast<const void *>(plan.levels) : nullptr;  // who counts uniform fallbacks
 
@@ -154,32 +137,22 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
   const int dl = lane < D ? lane : D - 1;  // this lane's dimension in the "lanes = dimensions" phases
   const int vlev = a.variant % 1000;
 
-  Team<T> team;
-  if constexpr (kTeams) {
-    team.set(tsize, tmember);
-    // (teams leave the upper half of the normals region free: at most 8 chains per workgroup)
-    team.xch = (__attribute__((address_space(3))) T *)(smem + kNormOff + 8192) + chain * (tsize * 64);
-    team.notes = (__attribute__((address_space(3))) T *)(smem + kNotesOff) + chain * (tsize * kMaxSeg);
-  }
-  const int team_level = (kTeams && tsize > 1) ? a.team_level : 0;
-  const int team_min_rows = a.team_min_rows;
-
   // ---- the chain's normal deviates, once (samplePoint! consumes D per level + D at the end, :440-463) ----
   double *sNorm = reinterpret_cast<double *>(smem + kNormOff) + chain * kLeanMaxNormals;
   const int R = D * (L + 1);
 #ifdef KDEHIP_X_OLDNORMALS
-  for (int r = lane + 64 * tmember; r < R; r += 64 * tsize)
+  for (int r = lane; r < R; r += 64)
     sNorm[r] = a.rng_philox ? philox_normal(a.seed, gs, static_cast<uint32_t>(r)) : a.randN[s * a.R + r];
 #else
   if (a.rng_philox) {  // a lane makes BOTH normals of a Philox block (one logarithm, one sine/cosine pair for two)
-    for (int b = lane + 64 * tmember; 2 * b < R; b += 64 * tsize) {
+    for (int b = lane; 2 * b < R; b += 64) {
       double n0, n1;
       philox_normal_pair(a.seed, gs, static_cast<uint32_t>(b), n0, n1);
       sNorm[2 * b] = n0;
       if (2 * b + 1 < R) sNorm[2 * b + 1] = n1;
     }
   } else {
-    for (int r = lane + 64 * tmember; r < R; r += 64 * tsize) sNorm[r] = a.randN[s * a.R + r];
+    for (int r = lane; r < R; r += 64) sNorm[r] = a.randN[s * a.R + r];
   }
 #endif
   __syncthreads();  // (exp table; the strip is only read by its own chain's wavefronts)
@@ -281,14 +254,9 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
   const T *tables = static_cast<const T *>(plan.tables);
   const int Lt = (vlev == 1 || vlev == 4 || !a.use_tables) ? 0 : plan.Lt;
 
-  bool shared_level = false;  // this level's steps are walked by all members of the team
-  // the draw on a tile readable through one pointer: by this wavefront alone, or its rows shared by the team
-  auto draw_rows = [&](const auto &ds, auto rows, const auto &ev, double u, bool pre_barrier) -> int {
+  // the draw on a tile readable through one pointer
+  auto draw_rows = [&](const auto &ds, auto rows, const auto &ev, double u) -> int {
     using P = decltype(rows);
-    if constexpr (kTeams) {
-      if (shared_level && ds.B >= team_min_rows)
-        return draw_label_team<T, P, kPrefetchRows>(rows, ds, lane, ev, u, fb, team, pre_barrier);
-    }
     return draw_label<T, P, kPrefetchRows, kKeptRows>(rows, ds, lane, ev, u, fb);
   };
 
@@ -342,9 +310,75 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
     const double u = next_uniform();
     auto rows = hdr + kTileHeader;
     const int pos = __builtin_amdgcn_readfirstlane(draw(ds, hdr, mean, cov, [&](const auto &ev) {
-      return draw_rows(ds, rows, ev, u, /*pre_barrier=*/true);
+      return draw_rows(ds, rows, ev, u);
     }));
     adopt(jc, ds, hdr, pos);
+  };
+
+  // ---- a step on a SCREENED level (screen_device.hpp): the draw in packed fp32 from the level's screen tile in LDS,
+  // certified against the fp64 decision -- or repeated in fp64 from the plan's fp64 tile in global memory; the new kernel
+  // always from the fp64 tile ----
+  uint32_t n_screened = 0, n_repeated = 0;  // (diagnostic counters: kdehip_product_screen_stats)
+  auto step_screen = [&](auto jc, const auto &ds, int sc_lds_off, bool first, T x) {
+    if constexpr (kScreen) {
+      T mean = x, cov = T(0);
+      if (!first) product(jc, mean, cov);
+      const double u = next_uniform();
+      const LdsPtr<float> h32 = (LdsPtr<float>)(pool + sc_lds_off);
+      const LdsPtr<double> h64 = (LdsPtr<double>)(pool + sc_lds_off);
+      // lanes = dimensions: centred operands and what the error bound needs
+      const double mu0 = h64[dl], cmin = h64[8 + dl];
+      const float mmax = h32[32 + dl], valid = h32[40];
+      const float cen = static_cast<float>(mean - mu0);
+      const float cf = static_cast<float>(cmin + cov), covf = static_cast<float>(cov);
+      const float acen = fabsf(cen);
+      const bool inr = (acen <= kScreenMaxAbsMean) && (covf <= static_cast<float>(kScreenMaxVar));  // (false for a NaN)
+      int pos = -1;
+      if (valid != 0.0f && __ballot(lane < D && !inr) == 0ull) {
+        const float t = mmax + acen;
+        float a2 = lane < D ? t * t * __builtin_amdgcn_rcpf(cf) : 0.0f;
+        a2 += dpp_fetch<0x111, 0xF>(a2);  // row_shr:1, 2, 4: lane 7 holds the sum over the (at most 8) dimension lanes
+        a2 += dpp_fetch<0x112, 0xF>(a2);
+        a2 += dpp_fetch<0x114, 0xF>(a2);
+        const float na = __builtin_sqrtf(lane_read(a2, 7)) * (kScreenU * kScreenSqrtC0 * 1.01f);
+        const float Bc = (kScreenLn2 * 1.01f) * (na + kScreenKx * kScreenU);
+        const float A = (kScreenLn2 * 1.01f) * na + static_cast<float>(ds.B + 40) * kScreenU;
+        const LdsPtr<float> rows32 = h32 + kScreenHeaderFloats;
+        if (ds.uniform_bw) {
+          ScreenEval<D, true> ev;
+          ev.A = A; ev.Bc = Bc;
+          const float ninv = -kScreenC0 * __builtin_amdgcn_rcpf(cf);
+          float pr = 1.0f;
+#pragma unroll
+          for (int d = 0; d < D; ++d) {
+            ev.cen[d] = lane_read(cen, d);
+            ev.b[d] = lane_read(ninv, d);
+            pr *= lane_read(cf, d);
+          }
+          ev.scale = __builtin_amdgcn_rsqf(pr);
+          pos = screen_draw<D, true>(rows32, ds.n, ds.B, ds.F, lane, ev, u);
+        } else {
+          ScreenEval<D, false> ev;
+          ev.A = A; ev.Bc = Bc; ev.scale = 1.0f;
+#pragma unroll
+          for (int d = 0; d < D; ++d) {
+            ev.cen[d] = lane_read(cen, d);
+            ev.b[d] = lane_read(covf, d);
+          }
+          pos = screen_draw<D, false>(rows32, ds.n, ds.B, ds.F, lane, ev, u);
+        }
+        pos = __builtin_amdgcn_readfirstlane(pos);
+      }
+      ++n_screened;
+      const T *hdrg = data + ds.hdr_off();
+      if (pos < 0) {  // not certified (or out of the screen's range): the fp64 draw on the fp64 tile
+        ++n_repeated;
+        pos = __builtin_amdgcn_readfirstlane(draw(ds, hdrg, mean, cov, [&](const auto &ev) {
+          return draw_rows(ds, hdrg + kTileHeader, ev, u);
+        }));
+      }
+      adopt(jc, ds, hdrg, pos);
+    }
   };
 
   int gchunk = 0;  // workgroup-wide running chunk counter of the chunked mode (selects the pool half)
@@ -366,35 +400,9 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
   const int Lrun = L;
 #endif
   for (int l = 1; l <= Lrun; ++l) {
-    // Teams: the levels below team_level belong to member 0; the other members only take part in the staging of
-    // the tiles and in the workgroup barriers, and receive the chain's state when the shared levels begin.
-    bool active = true;
-    if constexpr (kTeams) {
-      if (team_level > 0) {
-        shared_level = (l >= team_level);
-        active = shared_level || tmember == 0;
-        if (l == team_level) {
-          auto hand = team.xch;  // [2M][8]: lam, lmu of the lanes that hold dimensions
-          team_barrier();
-          if (tmember == 0 && lane < 8)
-            static_for<M>([&](auto jc) {
-              constexpr int j = decltype(jc)::value;
-              hand[(2 * j) * 8 + lane] = lam[j];
-              hand[(2 * j + 1) * 8 + lane] = lmu[j];
-            });
-          team_barrier();
-          if (tmember != 0)
-            static_for<M>([&](auto jc) {
-              constexpr int j = decltype(jc)::value;
-              lam[j] = hand[(2 * j) * 8 + dl];
-              lmu[j] = hand[(2 * j + 1) * 8 + dl];
-            });
-        }
-      }
-    }
     // samplePoint! (:440-463): x = mean + sqrt(cov) * randn, all densities included
-    T x = T(0);
-    if (active) {
+    T x;
+    {
       T mean, cov;
       product(IC<-1>{}, mean, cov);
       x = mean + Num<T>::sqrt(cov) * static_cast<T>(sNorm[(l - 1) * D + dl]);
@@ -413,21 +421,39 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
     const int mode = vlev == 1 ? int(kStageGlobal) : level_mode;
     const bool tabulated = (l <= Lt);
     const int npass = tabulated ? 1 : a.Niter + 1;  // tabulated levels: only the sampleIndices! pass runs here
-    if (!active) c += static_cast<uint32_t>(M * (a.Niter + 1));  // the draws member 0 makes on this level
 
-    if (mode == kStageResident) {
+    bool screened = false;
+    if constexpr (kScreen) {
+      if (a.use_screen && vlev != 1) screened = scalar_copy(levels[M * (L + 1) + l].stage_mode) == kStageScreen;
+    }
+    if (screened) {
+      // the level's M screen tiles are resident in LDS for the whole level: no barrier between steps
+      auto screen = [&](int j) -> LevelDesc { return levels[(M + j) * (L + 1) + l]; };  // (j: a compile-time constant)
+      staging_barrier();
+      static_for<M>([&](auto jc) {
+        const LevelDesc sc = screen(decltype(jc)::value);
+        stage_tile<WAVES>(reinterpret_cast<const unsigned char *>(reinterpret_cast<const float *>(plan.data) + sc.hdr_off),
+                          pool + sc.lds_off, sc.stage_bytes, wave, lane);
+      });
+      staging_barrier();
+      for (int p = 0; p < npass; ++p)
+        static_for<M>([&](auto jc) {
+          const LeanTile<D> ds = tile(decltype(jc)::value);
+          const int sc_off = scalar_copy(screen(decltype(jc)::value).lds_off);
+          step_screen(jc, ds, sc_off, p == 0, x);
+        });
+    } else if (mode == kStageResident) {
       staging_barrier();  // every wavefront is done reading the previous level's images
       static_for<M>([&](auto jc) {
         const LeanTile<D> ds = tile(decltype(jc)::value);
         stage_tile<WAVES>(reinterpret_cast<const unsigned char *>(data + ds.hdr_off()), pool + ds.lds_off, ds.stage_bytes, wave, lane);
       });
       staging_barrier();
-      if (active)
-        for (int p = 0; p < npass; ++p)
-          static_for<M>([&](auto jc) {
-            const LeanTile<D> ds = tile(decltype(jc)::value);
-            step(jc, ds, (RowPtr)(pool + ds.lds_off), p == 0, x);
-          });
+      for (int p = 0; p < npass; ++p)
+        static_for<M>([&](auto jc) {
+          const LeanTile<D> ds = tile(decltype(jc)::value);
+          step(jc, ds, (RowPtr)(pool + ds.lds_off), p == 0, x);
+        });
     } else if (mode == kStageStream) {
       staging_barrier();
       {
@@ -443,11 +469,8 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
           const LeanTile<D> ds = tile(j);
           const LeanTile<D> dn = tile(jn);  // the next step's tile (staged during this step)
           T mean = x, cov = T(0);
-          double u = 0.0;
-          if (active) {
-            if (p != 0) product(jc, mean, cov);
-            u = next_uniform();
-          }
+          if (p != 0) product(jc, mean, cov);
+          const double u = next_uniform();
           // tile t has been copied by all wavefronts once everyone passes this barrier; buffer (t+1)&1 was last
           // read in step t-1, which everyone has left -> start the next copy
           staging_barrier();
@@ -458,13 +481,13 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
           if (!kLateCopy && t + 1 < nsteps)
             stage_tile<WAVES>(reinterpret_cast<const unsigned char *>(data + dn.hdr_off()),
                               pool + ((t + 1) & 1) * (kLdsPoolBytes / 2), dn.stage_bytes, wave, lane);
-          if (active) {
+          {
             auto hdr = (RowPtr)(pool + (t & 1) * (kLdsPoolBytes / 2));
             auto rows = hdr + kTileHeader;
             // (requesting the first row ahead of the broadcasts here, as the resident steps do, was measured: no gain --
             // 0.5825 vs 0.5811 ms)
             const int pos = __builtin_amdgcn_readfirstlane(draw(ds, hdr, mean, cov, [&](const auto &ev) {
-              return draw_rows(ds, rows, ev, u, /*pre_barrier=*/false);  // (the step's staging barrier separates the exchanges)
+              return draw_rows(ds, rows, ev, u);
             }));
             adopt(jc, ds, hdr, pos);
           }
@@ -476,7 +499,7 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
     } else if (mode == kStageChunked) {
       // tiles larger than half the pool: pass 1 streams the rows through the two pool halves (one barrier per
       // chunk, the copy of chunk g+1 overlaps the evaluation of chunk g); the second pass and the new kernel are
-      // read from global memory.  (Chunked levels are always shared by a team: lean_geometry.)
+      // read from global memory.
       staging_barrier();
       stage_chunk(tile(0), 0, gchunk & 1);
       int t = 0;
@@ -494,13 +517,10 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
           const int pos = draw(ds, hdr, mean, cov, [&](const auto &ev) {
             using Ev = std::decay_t<decltype(ev)>;
             const int RS = TileAddr<T>::stride(ds.F), rc = ds.chunk_rows;
-            LaneAcc<T> acc;          // a wavefront that owns its chain
-            T mx = T(0), my = T(0);  // a team member's share
+            LaneAcc<T> acc;
             SegSums<T> seg;
             const int cps = seg_chunks(ds.seg);
             const bool use_seg = cps != 0;
-            // (a chunked level is always a shared one, and the team instantiation only runs with teams: lean_geometry)
-            constexpr bool shared = kTeams;
             int cin = 0;
             KDEHIP_PRIO_ROWS();
             for (int r0 = 0; r0 < ds.B; r0 += rc, ++gchunk) {
@@ -509,24 +529,11 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
               else if (t + 1 < nsteps) stage_chunk(dn, 0, (gchunk + 1) & 1);
               const int nrows = (ds.B - r0 < rc) ? (ds.B - r0) : rc;
               const auto crows = (RowPtr)(pool + (gchunk & 1) * (kLdsPoolBytes / 2));
-              if constexpr (shared)
-                lane_rows_member<T, RowPtr, Ev, kPrefetchRows>(crows, nrows, RS, lane, ev, team.first, team.second,
-                                                                  team.stride, team.same, mx, my);
-              else
-                lane_rows_all<T, RowPtr, Ev, kPrefetchRows>(crows, nrows, RS, lane, ev, acc);
-              // the lane's running sum (a member: its share of it) at a segment boundary
-              if (use_seg && ++cin == cps) { seg.note(shared ? mx + my : acc.total()); cin = 0; }
+              lane_rows_all<T, RowPtr, Ev, kPrefetchRows>(crows, nrows, RS, lane, ev, acc);
+              // the lane's running sum at a segment boundary
+              if (use_seg && ++cin == cps) { seg.note(acc.total()); cin = 0; }
             }
             KDEHIP_PRIO_CHAIN();
-            if constexpr (kTeams) {
-              if (shared) {
-                const T S = team_combine(mx + my, lane, team, /*pre_barrier=*/false);
-                if (use_seg)
-                  return __builtin_amdgcn_readfirstlane(select_or_raise_seg_team<T, const T *>(
-                      S, seg, cps * rc, hdr + kTileHeader, ds, lane, ev, u, fb, team));
-                return __builtin_amdgcn_readfirstlane(select_or_raise<T, const T *>(S, hdr + kTileHeader, ds, lane, ev, u, fb));
-              }
-            }
             const T S = acc.total();
             if (use_seg)
               return __builtin_amdgcn_readfirstlane(
@@ -537,15 +544,14 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
           ++t;
         });
     } else {  // kStageGlobal
-      if (active)
-        for (int p = 0; p < npass; ++p)
-          static_for<M>([&](auto jc) {
-            const LeanTile<D> ds = tile(decltype(jc)::value);
-            step(jc, ds, data + ds.hdr_off(), p == 0, x);
-          });
+      for (int p = 0; p < npass; ++p)
+        static_for<M>([&](auto jc) {
+          const LeanTile<D> ds = tile(decltype(jc)::value);
+          step(jc, ds, data + ds.hdr_off(), p == 0, x);
+        });
     }
 
-    if (tabulated && active) {
+    if (tabulated) {
       // ---- tabulated sweeps (see gibbs_kernel.hip "conditional tables"): the labels of all densities packed in
       // one scalar word, one table row load per step, the unchanged selection ----
       TabDesc td[M];
@@ -606,6 +612,13 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
     }
   }
 
+  if constexpr (kScreen) {  // diagnostic counters in front of the level table: [-3] screened steps, [-2] repeated in fp64
+    if (live && lane == 0 && n_screened != 0u) {
+      unsigned long long *cnt = reinterpret_cast<unsigned long long *>(const_cast<LevelDesc *>(plan.levels));
+      atomicAdd(cnt - 3, static_cast<unsigned long long>(n_screened));
+      if (n_repeated != 0u) atomicAdd(cnt - 2, static_cast<unsigned long long>(n_repeated));
+    }
+  }
   {  // final point (:625)
     T mean, cov;
     product(IC<-1>{}, mean, cov);
@@ -622,29 +635,13 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
 
 template <typename T, int D, int M, int WAVES>
 static void launch_lean_waves(const PlanDev &plan, const RunArgs &args, hipStream_t stream) {
-  const int chains = WAVES / (args.team > 1 ? args.team : 1);  // chains per workgroup
-  const int64_t blocks = (args.Np + chains - 1) / chains;
-#if KDEHIP_WITH_TEAMS  // (make TEAMS=1; lean_geometry never reports a team otherwise)
-  if constexpr (WAVES == 16 && sizeof(T) == 8) {
-    if (args.team > 1) {
-      hipLaunchKernelGGL((gibbs_lean_kernel<T, D, M, WAVES, true>), dim3(static_cast<unsigned>(blocks)), dim3(WAVES * 64), 0,
-                         stream, plan, args);
-      return;
-    }
-  }
-#endif
+  const int64_t blocks = (args.Np + WAVES - 1) / WAVES;
   hipLaunchKernelGGL((gibbs_lean_kernel<T, D, M, WAVES>), dim3(static_cast<unsigned>(blocks)), dim3(WAVES * 64), 0,
                      stream, plan, args);
 }
 
-// wavefronts per workgroup and per chain of this run (RunArgs carries the team part to the kernel)
-static int set_geometry(const PlanDev &plan, RunArgs &args, int precision) {
-  const LeanGeometry g = lean_geometry(args.Np, args.variant, precision, plan);
-  args.team = g.team;
-  args.team_level = g.team_level;
-  args.team_min_rows = g.team_min_rows;
-  return g.waves;
-}
+// wavefronts (= chains) per workgroup of this run
+static int set_geometry(const PlanDev &, RunArgs &args, int) { return lean_waves(args.Np, args.variant); }
 
 template <typename T, int D, int M>
 static int launch_lean_m(const PlanDev &plan, const RunArgs &args_in, hipStream_t stream) {
@@ -683,7 +680,7 @@ static int launch_lean_m_hi(const PlanDev &plan, const RunArgs &args_in, hipStre
 template <int D, int M>
 static void launch_lean_batch_m(const PlanDev &plan, const RunArgs &args, hipStream_t stream) {
   constexpr int W = 16;
-  hipLaunchKernelGGL((gibbs_lean_kernel<double, D, M, W, false, true>), dim3(static_cast<unsigned>(args.Np / W)), dim3(W * 64), 0,
+  hipLaunchKernelGGL((gibbs_lean_kernel<double, D, M, W, true>), dim3(static_cast<unsigned>(args.Np / W)), dim3(W * 64), 0,
                      stream, plan, args);
 }
 int KDEHIP_CAT(launch_lean_batch_d, KDEHIP_DIM)(int M, const PlanDev &plan, const RunArgs &args, void *stream) {

@@ -68,7 +68,8 @@ enum StageMode : int32_t {
   kStageGlobal = 0,    // tile too large for LDS: wavefronts read it from global memory (L1/L2)
   kStageResident = 1,  // all densities' tiles of the level fit the LDS pool at once
   kStageStream = 2,    // one tile per step, double-buffered in the LDS pool
-  kStageChunked = 3    // tile larger than half the pool: rows streamed through the two halves in chunks
+  kStageChunked = 3,   // tile larger than half the pool: rows streamed through the two halves in chunks
+  kStageScreen = 4     // (screen descriptors only) the level is SCREENED in fp32: see "fp32 screening" below
 };
 constexpr int kLdsPoolBytes = 120 * 1024;   // LDS bytes for staged tiles (of 160 KiB per CU; the rest: chain state)
 
@@ -101,6 +102,28 @@ inline int32_t seg_geometry(int B, int rc) {
 }
 static_assert(sizeof(LevelDesc) == 64, "LevelDesc is read with scalar loads; keep it 64 bytes");
 
+// ---- fp32 screening of the deep levels, fp64 certification (round 5; DESIGN.md "fp32 screening") --------------------
+// On a level whose fp64 tiles do not fit the LDS pool together (streamed / chunked levels) an fp64 plan ALSO carries
+// the level's tiles in fp32 -- means centred at the density's root mean (m' = m - mu0, subtracted in fp64, rounded once),
+// variances, weights, in the fp32 row-pair layout (TileAddr<float>) -- when all M of THOSE fit the pool at once.  A draw
+// step then evaluates the frontier in packed fp32 from LDS, together with a rigorous bound on the error of every
+// cumulative sum (each term carries the relative error A + Bc |x|, x its base-2 exponent; the wave-uniform A, Bc follow
+// from the header's bounds below), and accepts the fp32 decision only when the target u * total is farther than that bound
+// from every boundary it could cross; otherwise -- about 1 % of the steps at BASELINE config 3 -- the step is repeated in
+// fp64 from the plan's fp64 tile in global memory.  The drawn kernel's mean and variance are always adopted from the fp64
+// tile: labels and points are bit for bit those of the fp64 path.
+// A screen tile: [header kScreenHeaderFloats floats][row pairs as TileAddr<float>].  Header (written by the GPU,
+// pack_device.hip screen_build_kernel): mu0[8] (fp64), cmin[8] (fp64: per dimension the smallest variance of the tile =
+// THE variance of a shared-bandwidth tile), mmax[8] (fp32: max |m'_d|, rounded up), then flags[8] (fp32): [0] = 1 when
+// every value of the tile is inside the ranges the error analysis assumes (kScreen* below), else 0 = never screened.
+// Descriptors: a second [M][L+1] table of LevelDesc right behind the plan's level table; entry (j, l) has stage_mode ==
+// kStageScreen when LEVEL l is screened, n / B / F / uniform_bw / last_lane of the fp64 tile, hdr_off = offset of the
+// screen tile's header in FLOATS from the plan's data, lds_off / stage_bytes of its LDS image.
+constexpr int kScreenHeaderFloats = 48;
+constexpr int kScreenMaxRows = 64;           // rows per lane up to which a level is screened (one second-pass round)
+constexpr float kScreenMaxAbsMean = 65536.0f;  // |m'_d|, |centre'_d| <= 2^16
+constexpr double kScreenMinVar = 1.0 / 128.0, kScreenMaxVar = 256.0;  // variances (tile, leave-one-out) in [2^-7, 2^8]
+
 // Conditional table of density j on level l (see gibbs_kernel.hip "conditional tables"): rows of n+1
 // values (inclusive scan over the n frontier nodes, then the total).  Only levels whose frontier sizes
 // are powers of two (and <= 64) are tabulated: the labels of all densities are packed into one word,
@@ -127,8 +150,8 @@ struct PlanDev {
   const TabDesc *tabdesc;    // [M][L+1]
   int64_t tab_rows_total;
   int32_t M, L, D, Lt;       // Lt: levels 1..Lt are tabulated (0 = none)
-  int32_t deep_level[2];     // first level with a tile of >= kTeamMinRows[k] rows per lane (0 = none), see lean_geometry
-  float deep_share[2];       // share of a sweep's rows (plus a per-step overhead) that lies on those levels
+  int32_t screened;          // 1: the plan carries screen tiles (descriptors behind the level table) and they are built
+  int32_t reserved_[3];
 };
 
 constexpr int kMaxPeers = 7;  // other GPUs of one node
@@ -141,6 +164,7 @@ struct RunArgs {
   int32_t variant;
   int32_t table_build;  // 1: this launch fills the conditional tables instead of sampling
   int32_t use_tables;   // 1: the tables are built and may be used
+  int32_t use_screen;   // 1: the screen tiles are built and may be used (fp64 plans, gibbs_lean.hip)
   const double *randU;
   const double *randN;
   int64_t K, R;         // per-sample consumption
@@ -150,12 +174,6 @@ struct RunArgs {
   double *points;
   int64_t *indices;
   int32_t *labels;
-  // Wavefront teams (gibbs_lean.hip, 16-wavefront fp64 builds): `team` = wavefronts per chain (1, 2 or 4); levels
-  // below `team_level` are walked by the first member alone, from there on a step whose tile has at least
-  // `team_min_rows` rows per lane is shared by the members (gibbs_device.hpp "wavefront teams").
-  int32_t team;
-  int32_t team_level;
-  int32_t team_min_rows;
   // The all-gather of a multi-GPU product (kdehip_product_multi_*): the kernel stores every final point and label
   // not only into its own device's arrays but straight into the arrays of the `npeers` other devices as well
   // (peer-mapped pointers, stores travel over xGMI) -- no copy engines, no extra launches.
@@ -181,8 +199,7 @@ struct BatchPlanHead {   // = the first 64 bytes of PlanDev
   int32_t M, L, D, Lt;
 };
 struct BatchRun {
-  int32_t deep_level[2];   // (the tail of PlanDev)
-  float deep_share[2];
+  int32_t reserved_[4];    // (the tail of PlanDev)
   int64_t Np;
   uint64_t seed;
   int64_t sample_offset;
@@ -212,7 +229,8 @@ struct PackedProduct {
   std::vector<LevelDesc> levels;   // [M][L+1]
   std::vector<int32_t> front;      // every frontier's node ids (1-based), frontier (j, l) at front_off[j*(L+1)+l]
   std::vector<int64_t> front_off;  // [M*(L+1) + 1]
-  int64_t data_elems = 0;          // elements of the tile payload (incl. the readable tail)
+  int64_t data_elems = 0;          // elements of the tile payload (incl. the screen tiles and the readable tail)
+  int64_t tile_elems = 0;          // elements up to the end of the last tile proper (the packers write up to here)
   int64_t perm_elems = 0;          // int32 entries of the permutation rows
   std::vector<double> data;        // fp64 payload (pack_levels only)
   std::vector<int32_t> perm;
@@ -220,6 +238,8 @@ struct PackedProduct {
   bool fast = true;                // product/rsqrt arithmetic + compact uniform tiles in use
   bool all_active = true;          // every dimension of every density is informed by another density
   std::vector<TabDesc> tabdesc;    // [M][L+1]
+  std::vector<LevelDesc> screens;  // [M][L+1] screen descriptors ("fp32 screening"), empty = no level is screened
+  int nscreened = 0;               // screened levels
   int Lt = 0;                      // tabulated levels 1..Lt
   int64_t tab_entries = 0, tab_rows = 0;
   bool masked = false;
@@ -254,6 +274,7 @@ enum ArithMode : int {
 hipError_t cached_malloc(void **out, size_t bytes);
 void cached_free(void *p, size_t bytes);
 hipError_t cached_host_malloc(void **out, size_t bytes);
+void drain_pending();  // (product.hip) releases the plans of enqueue-only device products once their work is over
 void cached_host_free(void *p, size_t bytes);
 
 // Makes `device` the thread's current HIP device for the lifetime of the guard and restores the caller's
@@ -288,18 +309,12 @@ int auto_bandwidth_run(int D, int64_t N, const double *points, const double *d_p
 // the width with the smallest estimated time rounds(width) * cost(width) unless `variant` pins it
 // (kdehip_product_set_variant).  Shared by both sampler kernels.
 int chains_per_workgroup(int64_t Np, int variant);
-// The launch geometry of the register-resident sampler: wavefronts per workgroup and wavefronts per chain (team).
-// Teams exist in the 16-wavefront fp64 builds only; `deep_level[k]` (k = 0: teams of 2, k = 1: teams of 4) is the
-// first level with a tile of at least kTeamMinRows[k] rows per lane, 0 = the product has no such level.
-struct LeanGeometry { int waves; int team; int team_level; int team_min_rows; };
-constexpr int kTeamMinRows[2] = {8, 16};
-// Teams by default when the shared levels carry at least this share of a sweep.  2 = never: measured on MI355X
-// (round 3, DESIGN.md "wavefront teams") a team launch is SLOWER than one wavefront per chain at every BASELINE
-// shape -- 16 wavefronts per CU leave 128 registers per wavefront, and the register-resident kernel then spills in its
-// per-step code (config 4, 2048 chains: 8.3 ms against 4.7 ms) -- so teams stay a plan variant (52 / 54).
-constexpr float kTeamMinShare = 2.0f;
-constexpr int kVariantTeam2 = 52, kVariantTeam4 = 54;  // plan variants: 16 wavefronts per workgroup as 8 x 2 / 4 x 4
-LeanGeometry lean_geometry(int64_t Np, int variant, int precision, const PlanDev &plan);
+// The same for the register-resident sampler (gibbs_lean.hip): diagnostic builds combine a level cut-off (variant % 1000 =
+// 100 + k) with a width in the thousands digit (6: sixteen, 8: eight chains per workgroup).
+// (Rounds 3-4 also had "wavefront teams" -- one chain on 2 or 4 wavefronts of a 16-wavefront workgroup, plan variants
+// 52 / 54: bit-identical, measured slower than one wavefront per chain at every BASELINE shape in both rounds
+// (profiles/r03_experiments.md), never selected by a plan; removed in round 5.)
+int lean_waves(int64_t Np, int variant);
 
 // Variant codes 30..49 = "gibbs_kernel.hip even where gibbs_lean.hip applies" + (code - 30) as the plain variant.
 constexpr int kVariantGenericBase = 30;

@@ -86,6 +86,119 @@ int launch_fill_tiles(int precision, const FillJob *d_jobs, int ntiles, int maxB
   return KDEHIP_OK;
 }
 
+// ---- fp32 screen tiles (kdehip_internal.hpp "fp32 screening") ------------------------------------------------------
+// One workgroup per (density j, level l) of an fp64 plan; those whose level is screened re-write their fp64 tile as the
+// fp32 screen tile: means centred at the density's root mean (subtracted in fp64, rounded to nearest once), variances,
+// weights, in the fp32 row-pair layout; and the header the sampler's error bound is made of -- mu0, the smallest variance
+// per dimension, the largest |m'_d| (rounded up), and whether every value lies inside the ranges that bound assumes.
+__global__ __launch_bounds__(256) void screen_build_kernel(PlanDev plan) {
+  const int M = plan.M, L = plan.L, D = plan.D;
+  const int idx = blockIdx.x;  // j * (L + 1) + l
+  const LevelDesc sc = plan.levels[M * (L + 1) + idx];
+  if (sc.stage_mode != kStageScreen) return;
+  const LevelDesc ds = plan.levels[idx];
+  const int j = idx / (L + 1);
+  const LevelDesc root = plan.levels[j * (L + 1)];
+  const double *data = static_cast<const double *>(plan.data);
+  const double *src = data + ds.hdr_off;                   // fp64 tile: header, then rows
+  float *dst = reinterpret_cast<float *>(const_cast<double *>(data)) + sc.hdr_off;
+  using TA8 = TileAddrBytes<8>;
+  using TA4 = TileAddrBytes<4>;
+  const int F = ds.F, B = ds.B, n = ds.n;
+  const int RS8 = TA8::stride(F), RS4 = TA4::stride(F);
+  const bool uni = ds.uniform_bw != 0;
+  __shared__ double s_mu0[KDEHIP_MAX_DIMS];
+  __shared__ float s_mmax[4][KDEHIP_MAX_DIMS], s_vmin[4][KDEHIP_MAX_DIMS], s_vmax[4][KDEHIP_MAX_DIMS];
+  __shared__ int s_bad[4];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (t < KDEHIP_MAX_DIMS) s_mu0[t] = t < D ? (data + root.hdr_off + kTileHeader)[t * TA8::kField] : 0.0;  // root = entry 0 of the level-0 tile
+  __syncthreads();
+  float mmax[KDEHIP_MAX_DIMS], vmin[KDEHIP_MAX_DIMS], vmax[KDEHIP_MAX_DIMS];
+  for (int d = 0; d < KDEHIP_MAX_DIMS; ++d) { mmax[d] = 0.0f; vmin[d] = INFINITY; vmax[d] = 0.0f; }
+  int bad = 0;
+  float *rows = dst + kScreenHeaderFloats;
+  const int Bp = (B + 1) & ~1;  // rows of whole pairs: the missing second row of the last pair is padding
+  for (int i = wave; i < Bp; i += 4) {
+    const int z = lane * B + i;
+    const bool real = i < B && z < n;
+    const double *e8 = src + kTileHeader + TA8::row(i, RS8) + lane;
+    float *e4 = rows + TA4::row(i, RS4) + lane * TA4::kLane;
+    for (int d = 0; d < D; ++d) {
+      float m = 0.0f;
+      if (real) {
+        const double mc = e8[d * TA8::kField] - s_mu0[d];
+        m = static_cast<float>(mc);
+        const float am = fabsf(m);
+        bad |= !(am <= kScreenMaxAbsMean);
+        mmax[d] = am > mmax[d] ? am : mmax[d];
+      }
+      e4[d * TA4::kField] = m;
+    }
+    if (!uni)
+      for (int d = 0; d < D; ++d) {
+        float v = 1.0f;
+        if (real) {
+          const double vd = e8[(D + d) * TA8::kField];
+          v = static_cast<float>(vd);
+          bad |= !(vd >= kScreenMinVar && vd <= kScreenMaxVar);
+          vmin[d] = v < vmin[d] ? v : vmin[d];
+          vmax[d] = v > vmax[d] ? v : vmax[d];
+        }
+        e4[(D + d) * TA4::kField] = v;
+      }
+    float w = 0.0f;
+    if (real) {
+      const double wd = e8[(F - 1) * TA8::kField];
+      w = static_cast<float>(wd);
+      bad |= !(wd >= 0.0 && wd <= 2.0);
+    }
+    e4[(F - 1) * TA4::kField] = w;
+    if (lane == 0) e4[F * TA4::kField] = 0.0f;  // the pad element of this row's half of the pair
+  }
+  // reduce over the workgroup: lanes by DPP-free shuffles (this kernel runs once per plan)
+  for (int d = 0; d < D; ++d)
+    for (int o = 32; o > 0; o >>= 1) {
+      mmax[d] = fmaxf(mmax[d], __shfl_xor(mmax[d], o));
+      vmin[d] = fminf(vmin[d], __shfl_xor(vmin[d], o));
+      vmax[d] = fmaxf(vmax[d], __shfl_xor(vmax[d], o));
+    }
+  bad = __any(bad) ? 1 : 0;
+  if (lane == 0) {
+    for (int d = 0; d < KDEHIP_MAX_DIMS; ++d) { s_mmax[wave][d] = mmax[d]; s_vmin[wave][d] = vmin[d]; s_vmax[wave][d] = vmax[d]; }
+    s_bad[wave] = bad;
+  }
+  __syncthreads();
+  if (t < KDEHIP_MAX_DIMS) {
+    const int d = t;
+    float mm = 0.0f, lo = INFINITY;
+    for (int w = 0; w < 4; ++w) { mm = fmaxf(mm, s_mmax[w][d]); lo = fminf(lo, s_vmin[w][d]); }
+    double cmin = static_cast<double>(lo);
+    int b = s_bad[0] | s_bad[1] | s_bad[2] | s_bad[3];
+    if (uni && d < D) {  // the one bandwidth vector of a shared-bandwidth tile: its header
+      cmin = src[d];
+      b |= !(cmin >= kScreenMinVar && cmin <= kScreenMaxVar);
+    }
+    if (d >= D) { cmin = 1.0; mm = 0.0f; }
+    // (a variance that was rounded to fp32 may sit one ulp ABOVE the fp64 value: the bound's smallest variance steps down)
+    if (!uni && d < D) cmin = cmin * (1.0 - 1.2e-7);
+    double *h8 = reinterpret_cast<double *>(dst);
+    h8[d] = s_mu0[d];
+    h8[8 + d] = cmin;
+    dst[32 + d] = mm * (1.0f + 2.4e-7f);
+    // flags[0]: 1 = every value inside the ranges the error analysis assumes (the other flags: 0)
+    const unsigned long long anybad = __ballot(b != 0);
+    dst[40 + d] = (d == 0 && anybad == 0ull) ? 1.0f : 0.0f;
+  }
+}
+
+int launch_screen_build(const PlanDev &plan, void *stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  hipLaunchKernelGGL(screen_build_kernel, dim3(static_cast<unsigned>(plan.M * (plan.L + 1))), dim3(256), 0, stream, plan);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_error(KDEHIP_ERR_HIP, std::string("screen tile build launch failed: ") + hipGetErrorString(e));
+  return KDEHIP_OK;
+}
+
 }  // namespace kdehip
 
 // ---- densities in HBM ----------------------------------------------------------------------------------------------

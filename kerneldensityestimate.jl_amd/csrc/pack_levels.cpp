@@ -5,6 +5,7 @@
 // expanded once per product and stored level by level in the lane-blocked row/field layout
 // described in kdehip_internal.hpp; the kernels never touch the tree topology.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "device_density.hpp"
@@ -280,8 +281,8 @@ int pack_layout_shapes(int M, int D, int L, const TileShape *shapes, const uint8
       ds.chunk_rows = static_cast<int32_t>(((paired ? 2 : 1) * ((kLdsPoolBytes / 2 - 1024) / (RS * esz))) & ~int64_t(3));
     }
   }
-  out.data_elems = nelem + 1024 / 4;  // staged copies are rounded up to whole KiB: keep the tail readable
   out.perm_elems = nperm;
+  out.tile_elems = nelem;
 
   // ---- phase 3: where each level's tiles live while the kernel works on that level
   for (int l = 0; l <= L; ++l) {
@@ -305,6 +306,50 @@ int pack_layout_shapes(int M, int D, int L, const TileShape *shapes, const uint8
       off += ds.stage_bytes;
     }
   }
+
+  // ---- phase 3b: fp32 screening (kdehip_internal.hpp "fp32 screening"): fp64 plans of the register-resident sampler's
+  // domain; a level is screened when its fp64 tiles are streamed or chunked, every tile has 2..kScreenMaxRows rows per
+  // lane and the M fp32 images fit the pool together.  The screen tiles follow the fp64 tiles in the plan's data.
+  static const bool screen_on = [] { const char *e = std::getenv("KDEHIP_SCREEN"); return !(e && e[0] == '0'); }();
+  if (screen_on && precision == 64 && out.fast && out.all_active && !out.masked && ((M >= 2 && M <= 4) || M == 8) &&
+      D * (L + 1) <= 128) {
+    std::vector<LevelDesc> scr(static_cast<size_t>(M) * (L + 1));
+    std::memset(scr.data(), 0, scr.size() * sizeof(LevelDesc));
+    int64_t felem = 2 * nelem;  // in floats from the start of the plan's data
+    for (int l = 1; l <= L; ++l) {
+      const int mode = out.levels[l].stage_mode;
+      if (mode != kStageStream && mode != kStageChunked) continue;
+      bool ok = true;
+      int64_t sum = 0;
+      for (int j = 0; j < M && ok; ++j) {
+        const LevelDesc &ds = out.levels[static_cast<size_t>(j) * (L + 1) + l];
+        if (ds.B < 2 || ds.B > kScreenMaxRows) ok = false;
+        const int64_t bytes = (kScreenHeaderFloats + TileAddrBytes<4>::body(ds.B, ds.F)) * 4;
+        sum += (bytes + 1023) / 1024 * 1024;
+      }
+      if (!ok || sum > kLdsPoolBytes) continue;
+      int64_t off = 0;
+      for (int j = 0; j < M; ++j) {
+        const LevelDesc &ds = out.levels[static_cast<size_t>(j) * (L + 1) + l];
+        LevelDesc &sc = scr[static_cast<size_t>(j) * (L + 1) + l];
+        sc.n = ds.n; sc.B = ds.B; sc.F = ds.F; sc.uniform_bw = ds.uniform_bw; sc.last_lane = ds.last_lane;
+        sc.stage_mode = kStageScreen;
+        felem = (felem + 63) & ~int64_t(63);  // 256-byte aligned images
+        sc.hdr_off = felem;
+        const int64_t elems = kScreenHeaderFloats + TileAddrBytes<4>::body(ds.B, ds.F);
+        felem += elems;
+        sc.stage_bytes = static_cast<int32_t>((elems * 4 + 1023) / 1024 * 1024);
+        sc.lds_off = static_cast<int32_t>(off);
+        off += sc.stage_bytes;
+      }
+      ++out.nscreened;
+    }
+    if (out.nscreened > 0) {
+      out.screens.swap(scr);
+      nelem = (felem + 1) / 2;
+    }
+  }
+  out.data_elems = nelem + 1024 / 4;  // staged copies are rounded up to whole KiB: keep the tail readable
 
   // ---- phase 4: conditional tables (gibbs_kernel.hip): levels whose frontiers all fit one wavefront row
   // and have power-of-two sizes, as long as the rows of all densities stay within the entry budget
@@ -451,7 +496,9 @@ static void fill_density(const PackedProduct &pp, const kdehip_density &t, int j
     }
     // gap up to the next tile's aligned start
     const int64_t end = ds.hdr_off + kTileHeader + TA::body(B, F);
-    const int64_t next = (idx + 1 < pp.levels.size()) ? pp.levels[idx + 1].hdr_off : pp.data_elems;
+    // (the last tile: its readable tail; screen tiles, which follow, are written by the GPU)
+    const int64_t tail = pp.tile_elems + 1024 / 4 < pp.data_elems ? pp.tile_elems + 1024 / 4 : pp.data_elems;
+    const int64_t next = (idx + 1 < pp.levels.size()) ? pp.levels[idx + 1].hdr_off : tail;
     for (int64_t e = end; e < next; ++e) data[e] = T(0);
   }
   f.bad = bad;

@@ -37,7 +37,8 @@ struct kdehip_product {
   void *d_tables = nullptr;
   TabDesc *d_tabdesc = nullptr;
   bool tables_built = false;
-  std::mutex tables_mutex;  // concurrent first runs on one plan build the tables once
+  bool screens_built = false;  // the fp32 screen tiles (kdehip_internal.hpp "fp32 screening") are written
+  std::mutex tables_mutex;  // concurrent first runs on one plan build the tables (and the screen tiles) once
   unsigned long long *d_fallbacks = nullptr;  // device counter of uniform-fallback draws (:311-315), in the blob
   void *d_work = nullptr;   // scratch of the host-buffer entry points (outputs / uploaded streams), grown on demand
   size_t work_cap = 0;
@@ -93,6 +94,30 @@ int maybe_build_tables(kdehip_product *plan, int64_t Np, RunArgs &a, void *strea
   return KDEHIP_OK;
 }
 
+// The fp32 screen tiles of an fp64 plan are written by the GPU from the plan's own fp64 tiles (pack_device.hip
+// screen_build_kernel), on the stream that prepares the plan, before its first run.  Plan variant 5 runs without them.
+int maybe_build_screens(kdehip_product *plan, RunArgs &a, void *stream, bool private_plan = false) {
+  a.use_screen = 0;
+  if (!plan->dev.screened || plan->variant % 1000 == 5) return KDEHIP_OK;
+  std::lock_guard<std::mutex> lock(plan->tables_mutex);
+  if (!plan->screens_built) {
+    const int rc = launch_screen_build(plan->dev, stream);
+    if (rc != KDEHIP_OK) return rc;
+    if (!private_plan) KDEHIP_CHECK(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    plan->screens_built = true;
+  }
+  a.use_screen = 1;
+  return KDEHIP_OK;
+}
+
+// the plan's level table on the device: [M][L+1] level descriptors, then (screened plans) as many screen descriptors
+inline size_t level_table_bytes(const PackedProduct &pp) { return (pp.levels.size() + pp.screens.size()) * sizeof(LevelDesc); }
+inline void copy_level_table(const PackedProduct &pp, unsigned char *dst) {
+  std::memcpy(dst, pp.levels.data(), pp.levels.size() * sizeof(LevelDesc));
+  if (!pp.screens.empty())
+    std::memcpy(dst + pp.levels.size() * sizeof(LevelDesc), pp.screens.data(), pp.screens.size() * sizeof(LevelDesc));
+}
+
 // Scratch of the host-buffer entry points: one device buffer per plan, grown on demand (no per-call
 // hipMalloc / hipFree once it is large enough).  Callers hold plan->work_mutex.
 int reserve_work(kdehip_product *plan, size_t bytes) {
@@ -145,6 +170,8 @@ int enqueue_streams(kdehip_product *plan, int64_t Np, int Niter, const double *d
   a.randU = d_randU; a.randN = d_randN; a.K = K; a.R = R; a.nU = nU; a.nN = nN;
   a.seed = 0; a.sample_offset = 0;
   a.points = d_points; a.indices = d_indices; a.labels = d_labels;
+  rc = maybe_build_screens(plan, a, stream, private_plan);
+  if (rc != KDEHIP_OK) return rc;
   rc = maybe_build_tables(plan, Np, a, stream, private_plan);
   if (rc != KDEHIP_OK) return rc;
   return launch_gibbs(plan->precision, plan->mode, plan->dev, a, stream);
@@ -177,6 +204,8 @@ int enqueue_philox(kdehip_product *plan, int64_t Np, int Niter, uint64_t seed, i
   a.seed = seed; a.sample_offset = sample_offset;
   a.points = d_points; a.indices = d_indices; a.labels = d_labels;
   // (table_stream: a plan private to one call may fill its tables on another stream; the sampler waits for tables_done)
+  rc = maybe_build_screens(plan, a, table_stream ? table_stream : stream, private_plan);
+  if (rc != KDEHIP_OK) return rc;
   rc = maybe_build_tables(plan, Np, a, table_stream ? table_stream : stream, private_plan);
   if (rc != KDEHIP_OK) return rc;
   if (table_stream) {
@@ -224,11 +253,10 @@ int build_image(PlanImage &im, int Ndens, const kdehip_density *trees, int ndims
     const size_t nelem = static_cast<size_t>(im.host.data_elems);
     const size_t esz = (precision == 64) ? sizeof(double) : sizeof(float);
     const size_t nperm = static_cast<size_t>(im.host.perm_elems);
-    const size_t nlev = im.host.levels.size();
     const size_t ntab = im.host.tabdesc.size();
     im.off_lev = 256;                                        // the fallback counter sits in the 8 bytes before it
     im.off_count = im.off_lev - sizeof(unsigned long long);
-    im.off_tab = align256(im.off_lev + nlev * sizeof(LevelDesc));
+    im.off_tab = align256(im.off_lev + level_table_bytes(im.host));
     im.off_perm = align256(im.off_tab + ntab * sizeof(TabDesc));
     im.off_data = align256(im.off_perm + nperm * sizeof(int32_t));
     im.off_tables = align256(im.off_data + nelem * esz);
@@ -242,7 +270,7 @@ int build_image(PlanImage &im, int Ndens, const kdehip_density *trees, int ndims
     const double us_alloc = us();
     unsigned char *hb = static_cast<unsigned char *>(im.h_blob);
     std::memset(hb, 0, im.off_lev);
-    std::memcpy(hb + im.off_lev, im.host.levels.data(), nlev * sizeof(LevelDesc));
+    copy_level_table(im.host, hb + im.off_lev);
     std::memcpy(hb + im.off_tab, im.host.tabdesc.data(), ntab * sizeof(TabDesc));
     const bool ok = pack_fill(im.host, trees, hb + im.off_data, reinterpret_cast<int32_t *>(hb + im.off_perm));
     if (timing)
@@ -278,27 +306,7 @@ void bind_plan(kdehip_product *p, size_t off_lev, size_t off_count, size_t off_t
   p->dev.L = p->host.L;
   p->dev.D = p->host.D;
   p->dev.Lt = (p->mode == kModeGeneric) ? 0 : p->host.Lt;
-  // where a wavefront team would start sharing the rows of a step (lean_geometry): the first level with a tile of at
-  // least kTeamMinRows[k] rows per lane -- or a chunked level, whose staging every wavefront walks anyway -- and the
-  // share of a sweep's work (rows + ~4 rows' worth of per-step bookkeeping per tile) that lies from there on
-  for (int k = 0; k < 2; ++k) {
-    const int L = p->host.L, M = p->host.M;
-    int deep = 0;
-    for (int l = 1; l <= L && !deep; ++l)
-      for (int j = 0; j < M; ++j) {
-        const LevelDesc &ds = p->host.levels[static_cast<size_t>(j) * (L + 1) + l];
-        if (ds.B >= kTeamMinRows[k] || ds.stage_mode == kStageChunked) { deep = l; break; }
-      }
-    double all = 0.0, shared = 0.0;
-    for (int l = 1; l <= L; ++l)
-      for (int j = 0; j < M; ++j) {
-        const double w = p->host.levels[static_cast<size_t>(j) * (L + 1) + l].B + 4.0;
-        all += w;
-        if (deep && l >= deep) shared += w;
-      }
-    p->dev.deep_level[k] = deep;
-    p->dev.deep_share[k] = all > 0.0 ? static_cast<float>(shared / all) : 0.0f;
-  }
+  p->dev.screened = (p->mode == kModeFast && !p->host.screens.empty()) ? 1 : 0;
 }
 
 // A plan on `device` from an image: one device allocation, one DMA transfer (hipMalloc / hipFree cost tens of
@@ -430,6 +438,20 @@ int64_t kdehip_product_fallback_count(kdehip_product *plan) {
   return static_cast<int64_t>(v);
 }
 
+int kdehip_product_screen_stats(kdehip_product *plan, int32_t *levels, int64_t *steps, int64_t *repeats) {
+  if (!plan) return set_error(KDEHIP_ERR_ARG, "null plan");
+  DeviceGuard guard;
+  const int rc = guard.enter(plan->device);
+  if (rc != KDEHIP_OK) return rc;
+  unsigned long long v[2] = {0, 0};  // [screened steps, repeated in fp64]: the 16 bytes in front of the fallback counter
+  KDEHIP_CHECK(hipDeviceSynchronize());
+  KDEHIP_CHECK(hipMemcpy(v, plan->d_fallbacks - 2, sizeof(v), hipMemcpyDeviceToHost));
+  if (levels) *levels = plan->dev.screened ? plan->host.nscreened : 0;
+  if (steps) *steps = static_cast<int64_t>(v[0]);
+  if (repeats) *repeats = static_cast<int64_t>(v[1]);
+  return KDEHIP_OK;
+}
+
 int kdehip_product_set_variant(kdehip_product *plan, int variant) {
   if (!plan) return set_error(KDEHIP_ERR_ARG, "null plan");
   plan->variant = variant;
@@ -443,12 +465,10 @@ int kdehip_product_launch_geometry(const kdehip_product *plan, int64_t Np, int32
   const int rc = guard.enter(plan->device);  // (the width heuristic asks the plan's device for its CU count)
   if (rc != KDEHIP_OK) return rc;
   const bool lean = plan->mode == kModeFast && ((plan->host.M >= 2 && plan->host.M <= 4) || (plan->host.M == 8 && plan->precision == 64));
-  LeanGeometry g{chains_per_workgroup(Np, plan->variant), 1, 0, 0};
   const int v = plan->variant % 1000;
-  if (lean && !(v >= kVariantGenericBase && v < kVariantGenericBase + 20))
-    g = lean_geometry(Np, plan->variant, plan->precision, plan->dev);
-  *waves_per_workgroup = g.waves;
-  *waves_per_chain = g.team;
+  const bool as_lean = lean && !(v >= kVariantGenericBase && v < kVariantGenericBase + 20);
+  *waves_per_workgroup = as_lean ? lean_waves(Np, plan->variant) : chains_per_workgroup(Np, plan->variant);
+  *waves_per_chain = 1;
   return KDEHIP_OK;
 }
 
@@ -462,7 +482,7 @@ const char *kdehip_product_kernel_name(const kdehip_product *plan, int64_t Np) {
   if (lean && M == 8) {  // (the 8-density instantiations exist for 8 and 16 chains per workgroup)
     DeviceGuard guard;
     if (guard.enter(plan->device) != KDEHIP_OK) return "";
-    lean = lean_geometry(Np, plan->variant, plan->precision, plan->dev).waves != 4;
+    lean = lean_waves(Np, plan->variant) != 4;
   }
   return lean ? "gibbs_lean_kernel" : "gibbs_product_kernel";
 }
@@ -787,13 +807,16 @@ void reap_pending(int device, bool all, hipStream_t mine = nullptr) {
 
 }  // namespace
 
-void kdehip_internal_drain_pending() {  // kdehip_clear_cache: nothing may stay behind
+}  // extern "C"
+void kdehip::drain_pending() {  // kdehip_clear_cache: nothing may stay behind
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return;
   DeviceGuard guard;
   for (int d = 0; d < n && d < kMaxDevices; ++d)
     if (guard.enter(d) == KDEHIP_OK) reap_pending(d, true);
 }
+
+extern "C" {
 
 namespace {
 
@@ -843,11 +866,11 @@ int layout_resident(int Ndens, kdehip_device_density *const *trees, const uint8_
   p->precision = precision;
   p->fast = p->host.fast;
   p->mode = !p->host.fast ? kModeGeneric : (p->host.all_active ? kModeFast : kModeFastMasked);
-  const size_t nlev = p->host.levels.size(), ntab = p->host.tabdesc.size();
+  const size_t ntab = p->host.tabdesc.size();
   const size_t esz = (precision == 64) ? sizeof(double) : sizeof(float);
   lay.off_lev = 256;
   lay.off_count = lay.off_lev - sizeof(unsigned long long);
-  lay.off_tab = align256(lay.off_lev + nlev * sizeof(LevelDesc));
+  lay.off_tab = align256(lay.off_lev + level_table_bytes(p->host));
   lay.head_end = align256(lay.off_tab + ntab * sizeof(TabDesc));
   lay.off_perm = 0;
   lay.off_data = align256(static_cast<size_t>(p->host.perm_elems) * sizeof(int32_t));
@@ -861,10 +884,10 @@ int layout_resident(int Ndens, kdehip_device_density *const *trees, const uint8_
 int describe_resident(kdehip_product *p, kdehip_device_density *const *trees, const ResidentLayout &lay, void *d_blob,
                       unsigned char *hb, size_t head, size_t body, FillJob *jobs) {
   const int M = p->host.M, L = p->host.L, D = p->host.D;
-  const size_t nlev = p->host.levels.size(), ntab = p->host.tabdesc.size();
+  const size_t ntab = p->host.tabdesc.size();
   const size_t esz = (p->precision == 64) ? sizeof(double) : sizeof(float);
   std::memset(hb + head, 0, lay.off_lev);
-  std::memcpy(hb + head + lay.off_lev, p->host.levels.data(), nlev * sizeof(LevelDesc));
+  copy_level_table(p->host, hb + head + lay.off_lev);
   std::memcpy(hb + head + lay.off_tab, p->host.tabdesc.data(), ntab * sizeof(TabDesc));
   p->d_blob = d_blob;
   bind_plan(p, head + lay.off_lev, head + lay.off_count, head + lay.off_tab, body + lay.off_perm, body + lay.off_data,
@@ -981,7 +1004,14 @@ int kdehip_prod_philox_batch(int nprod, const kdehip_batch_item *items, int prec
   pend.stream = st;
   struct Abort {  // on an error before the hand-over to the queue: nothing has been enqueued that uses the block
     PendingPlan *pp; bool armed = true;
-    ~Abort() { if (armed) release_pending(*pp); }
+    // (the blocks go back to the cache of the CURRENT device, and the function's own DeviceGuard -- declared later, destroyed
+    // earlier -- has restored the caller's by now: enter the batch's device again for the release)
+    ~Abort() {
+      if (!armed) return;
+      DeviceGuard g;
+      (void)g.enter(pp->device);
+      release_pending(*pp);
+    }
   } abort_guard{&pend};
   std::vector<ResidentLayout> lays(nprod);
   std::vector<size_t> head_at(nprod), body_at(nprod), jobs_at(nprod);
@@ -1091,8 +1121,6 @@ int kdehip_prod_philox_batch(int nprod, const kdehip_batch_item *items, int prec
       BatchEntry be{};
       const PlanDev &pd = pend.plans[i]->dev;
       be.head = BatchPlanHead{pd.data, pd.perm, pd.levels, pd.tables, pd.tabdesc, pd.tab_rows_total, pd.M, pd.L, pd.D, pd.Lt};
-      be.run.deep_level[0] = pd.deep_level[0]; be.run.deep_level[1] = pd.deep_level[1];
-      be.run.deep_share[0] = pd.deep_share[0]; be.run.deep_share[1] = pd.deep_share[1];
       be.run.Np = it.Np; be.run.seed = it.seed; be.run.sample_offset = it.sample_offset;
       be.run.points = it.d_points; be.run.indices = it.d_indices; be.run.labels = it.d_labels;
       be.flags.Niter = it.Niter; be.flags.addEntropy = it.addEntropy ? 1 : 0; be.flags.use_tables = has_tables(i) ? 1 : 0;
@@ -1241,6 +1269,11 @@ struct kdehip_product_multi {
   int last_transfers = -1;        // copy-engine transfers per device of the last product (-1: none yet)
   std::vector<hipEvent_t> t_begin, t_end;  // kdehip_profile_sampler: around device g's sampling launch (created on demand)
   bool timed = false;             // the last product was bracketed
+  std::vector<char> timed_dev;    // ... and device g had chains in it (an empty slice records no events)
+  // verdicts of peer_can_store per (array, writing device): a caller passes the same arrays product after product, and
+  // a look-up is up to three driver queries (112 look-ups per product at 8 GPUs)
+  struct PeerVerdict { const void *p; int writer; bool ok; };
+  std::vector<PeerVerdict> peer_cache;
 };
 
 namespace {
@@ -1363,7 +1396,14 @@ int kdehip_product_multi_sample_philox(kdehip_product_multi *mp, int64_t Np, int
       // (KDEHIP_PEER_CHECK_ALIASED=1: tests on one GPU run the look-up on aliased devices too)
       static const bool check_aliased = [] { const char *e = std::getenv("KDEHIP_PEER_CHECK_ALIASED"); return e && e[0] == '1'; }();
       if (g == h || (phys(mp->first_device + g) == phys(mp->first_device + h) && !check_aliased)) continue;
-      if (!peer_can_store(d_points[h], phys(mp->first_device + g)) || !peer_can_store(d_indices[h], phys(mp->first_device + g)))
+      auto can = [&](const void *p, int writer) {
+        for (const auto &c : mp->peer_cache) if (c.p == p && c.writer == writer) return c.ok;
+        const bool ok = peer_can_store(p, writer);
+        if (mp->peer_cache.size() >= 256) mp->peer_cache.clear();  // (a caller that passes new arrays every time)
+        mp->peer_cache.push_back({p, writer, ok});
+        return ok;
+      };
+      if (!can(d_points[h], phys(mp->first_device + g)) || !can(d_indices[h], phys(mp->first_device + g)))
         peer_stores = false;
     }
   mp->last_transfers = (peer_stores || G == 1) ? 0 : 2 * (G - 1);
@@ -1380,6 +1420,7 @@ int kdehip_product_multi_sample_philox(kdehip_product_multi *mp, int64_t Np, int
       mp->t_end.push_back(b);
     }
   mp->timed = timed && static_cast<int>(mp->t_end.size()) == G;
+  mp->timed_dev.assign(static_cast<size_t>(G), 0);
   // (1) Device g is about to write into EVERY device's arrays: whatever is queued on the other devices' streams --
   // consumers of the previous product, typically -- must be over first (write after read).
   if (G > 1) {
@@ -1413,6 +1454,7 @@ int kdehip_product_multi_sample_philox(kdehip_product_multi *mp, int64_t Np, int
                           d_indices[g] + lo * M, nullptr, st, /*private_plan=*/false, &peers, nullptr, nullptr,
                           mp->timed ? mp->t_begin[g] : nullptr, mp->timed ? mp->t_end[g] : nullptr);
       if (rc != KDEHIP_OK) return rc;
+      if (mp->timed) mp->timed_dev[g] = 1;
       mp->plans[g]->async_pending.store(true);
       if (!peer_stores)
         for (int h = 0; h < G; ++h) {
@@ -1467,8 +1509,8 @@ int kdehip_product_multi_timing(kdehip_product_multi *mp, double *kernel_ms, dou
   for (int g = 0; g < G; ++g) {
     const int rc = guard.enter(phys(mp->first_device + g));
     if (rc != KDEHIP_OK) return rc;
-    float ms = 0.0f;
-    KDEHIP_CHECK(hipEventElapsedTime(&ms, mp->t_begin[g], mp->t_end[g]));
+    float ms = 0.0f;  // (a device whose slice was empty launched nothing and recorded no events: 0)
+    if (mp->timed_dev[g]) KDEHIP_CHECK(hipEventElapsedTime(&ms, mp->t_begin[g], mp->t_end[g]));
     kernel_ms[g] = ms;
     done_ms[g] = at[g] - first;
   }

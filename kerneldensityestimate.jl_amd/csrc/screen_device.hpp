@@ -1,0 +1,158 @@
+// screen_device.hpp -- fp32 SCREENING of a label draw with fp64 certification (gibbs_lean.hip, fp64 instantiations).
+//
+// makeFasterSampleIndex! + selectLabelOnLevel (reference src/MSGibbs01.jl:250-351) draw entry z of a frontier when the
+// uniform u satisfies b[z-1] < u * b[n-1] <= b[z], b = cumulative sums of the kernel values.  Which z that is depends on
+// the values only through those comparisons, so the values may be formed in ANY arithmetic as long as the comparisons are
+// known to come out as in fp64.  On the deep levels the frontier is therefore evaluated in packed fp32 (two rows per
+// v_pk_* instruction, hardware exp2 / rsq: ~2.5x fewer vector instructions per row than fp64) from an fp32 copy of the
+// tile that is RESIDENT in LDS (half the bytes: what is streamed in fp64 fits at once in fp32, so the per-step workgroup
+// barriers go too), together with a rigorous bound on the error of every cumulative sum; the fp32 decision is accepted
+// when the target is farther than that bound from the boundaries on both sides of it, and the step is repeated in fp64
+// (the unchanged path, tile read from global memory) otherwise.  Labels are then those of the fp64 path by construction;
+// the adopted kernel (mean, variance) is always read from the fp64 tile, so points are too.
+//
+// Error model (DESIGN.md "fp32 screening" has the derivation).  Entry i has the value v_i = front_i * 2^(x_i),
+// x_i = -c0 sum_d (m_id - centre_d)^2 / c_id <= 0, c0 = log2(e) / 2.  In fp32, on centred data (m' = m - mu0 and
+// centre' = centre - mu0 are formed in fp64 and rounded once, u = 2^-24):
+//   * the difference (m' - centre') carries |delta_d| <= u (|m'_d| + |centre'_d|) <= u (mmax_d + |centre'_d|) from the two
+//     roundings, which moves the exponent by at most 2 c0 sum_d |t_d| delta_d / sigma_d (t_d = the scaled difference,
+//     sigma_d^2 = c_id >= cmin_d) <= 2 sqrt(c0 |x_i|) |a'| by Cauchy-Schwarz, a'_d = u (mmax_d + |centre'_d|) / sqrt(cmin_d),
+//     and 2 sqrt(y) <= 1 + y gives the linear form  na (1 + |x_i|),  na = sqrt(c0) |a'|;
+//   * every other operation (the subtraction itself, squares, the sums of non-negative terms, products of variances,
+//     rsq, the rounded operands) is a relative perturbation of x_i by at most kx u, kx = 32 covering D <= 8;
+//   * front_i, exp2 and the final product add at most 24 u relative to v_i; fp32 sums of n non-negative numbers in any
+//     order are within (rows per lane + 16) u of the exact sum.
+// So |v~_i - v_i| <= v_i (A + Bc |x_i|) with the wave-uniform A = ln2 na + (B + 40) u, Bc = ln2 (na + kx u) (each with a
+// 1 % allowance for the second-order terms), every cumulative sum is within E = sum_i v~_i (A + Bc |x~_i|) of its fp64
+// value, and so is the target u * total.  A decision is certified when the boundaries on both sides of the target are
+// more than 2.5 E away (2 E would do).  Terms that fp32 flushes to zero or holds as denormals are below 2^-126 times a
+// front that the range checks bound by 2^28 each: with total >= 2^-40 required, their sum is below 2^-40 of the margin.
+// Range checks (else the step runs in fp64): tile values (screen_build_kernel: |m'| <= 2^16, variances in [2^-7, 2^8],
+// weights in [0, 2]) and per step |centre'_d| <= 2^16, leave-one-out variance <= 2^8.
+#pragma once
+#include "gibbs_device.hpp"
+
+namespace kdehip {
+
+constexpr float kScreenU = 5.9604645e-8f;       // 2^-24
+constexpr float kScreenC0 = 0.72134752f;        // log2(e) / 2
+constexpr float kScreenSqrtC0 = 0.84932180f;    // sqrt(c0)
+constexpr float kScreenLn2 = 0.69314718f;
+constexpr float kScreenKx = 32.0f;
+
+template <int D, bool UNI>
+struct ScreenEval {
+  float cen[D];  // centre'_d
+  float b[D];    // UNI: -c0 / c_d (the level's shared variance + leave-one-out variance); else: the leave-one-out variance
+  float scale;   // UNI: rsqrt(prod_d c_d)
+  float A, Bc;
+  using TA = TileAddr<float>;
+  template <typename V, typename LD>
+  __device__ __forceinline__ V value(LD &&ld, V &x) const {
+    V front;
+    if constexpr (UNI) {
+      V acc = V(0.0f);
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        const V dl = ld(d) - cen[d];
+        acc = Num<V>::fma(dl * dl, V(b[d]), acc);
+      }
+      front = ld(D) * scale;
+      x = acc;
+    } else {
+      V c[D], d2[D];
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        c[d] = ld(D + d) + b[d];
+        const V dl = ld(d) - cen[d];
+        d2[d] = dl * dl;
+      }
+      V num, prod;
+      fraction_sum<V, 0, D>(d2, c, num, prod);
+      const V r = Num<V>::rsqrt(prod);
+      const V q = num * r * r;
+      front = ld(2 * D) * r;
+      x = q * V(-kScreenC0);
+    }
+    return front * Num<V>::exp_fast(x, nullptr);
+  }
+  // one PAIR of rows; e = (row 2p, field 0, this lane).  The fields are requested first (one ds_read_b64 per field and
+  // lane: load_pair), the arithmetic follows a trip later: value sums S and error-bound sums E (both halves)
+  static constexpr int kFields = UNI ? D + 1 : 2 * D + 1;
+  struct Pair { kdehip_f2 f[kFields]; };
+  static __device__ __forceinline__ Pair load(LdsPtr<float> e) {
+    Pair r;
+#pragma unroll
+    for (int f = 0; f < kFields; ++f) r.f[f] = load_pair(e + f * TA::kField);
+    return r;
+  }
+  __device__ __forceinline__ void pair(const Pair &r, kdehip_f2 &S, kdehip_f2 &E) const {
+    kdehip_f2 x;
+    const kdehip_f2 v = value<kdehip_f2>([&](int f) { return r.f[f]; }, x);
+    S += v;
+    const kdehip_f2 g = Num<kdehip_f2>::fma(-x, kdehip_f2(Bc), kdehip_f2(A));
+    E = Num<kdehip_f2>::fma(v, g, E);
+  }
+  // one entry (second pass); e = (its row, field 0, its lane)
+  __device__ __forceinline__ float one(LdsPtr<float> e) const {
+    float x;
+    return value<float>([&](int f) { return e[f * TA::kField]; }, x);
+  }
+};
+
+// The draw on a screen tile (`rows` = row 0, field 0, lane 0 in LDS): the tile position of the entry u selects, or -1 when
+// the fp32 decision cannot be certified (the caller repeats the step in fp64).
+template <int D, bool UNI>
+__device__ __forceinline__ int screen_draw(LdsPtr<float> rows, int n, int B, int F, int lane, const ScreenEval<D, UNI> &ev,
+                                           double u) {
+  using TA = TileAddr<float>;
+  const int RS = TA::stride(F);
+  kdehip_f2 S = {0.0f, 0.0f}, E = {0.0f, 0.0f};
+  LdsPtr<float> e = rows + lane * TA::kLane;
+  const int npairs = (B + 1) >> 1;  // (the missing second row of the last pair is padding: weight 0)
+  using Ev = ScreenEval<D, UNI>;
+  KDEHIP_PRIO_ROWS();
+  {  // two pairs per trip, the next pair's fields requested before the current pair is evaluated (ping-pong registers)
+    typename Ev::Pair ra = Ev::load(e);
+    int p = 0;
+    for (; p + 2 <= npairs; p += 2) {
+      const typename Ev::Pair rb = Ev::load(e + RS);  // pair p + 1
+      __builtin_amdgcn_sched_barrier(0);
+      ev.pair(ra, S, E);
+      e += (p + 2 < npairs) ? 2 * RS : RS;  // pair p + 2, or pair p + 1 again (never past the tile)
+      ra = Ev::load(e);
+      __builtin_amdgcn_sched_barrier(0);
+      ev.pair(rb, S, E);
+    }
+    if (p < npairs) ev.pair(ra, S, E);
+  }
+  KDEHIP_PRIO_CHAIN();
+  const float s1 = S.x + S.y, e1 = E.x + E.y;
+  const float incl = wave_inclusive_scan(s1);
+  const float einc = wave_inclusive_scan(e1);
+  const float total = lane_read(incl, 63), etot = lane_read(einc, 63);
+  if (!(total >= 0x1p-40f && total < 0x1p100f)) return -1;  // (also a NaN)
+  const double td = u * static_cast<double>(total), md = 2.5 * static_cast<double>(etot);
+  // first lane that certainly reaches the target = first lane that possibly does
+  const double id = static_cast<double>(incl);
+  const unsigned long long hitA = __ballot(td + md <= id), hitB = __ballot(td - md <= id);
+  if (hitA == 0ull) return -1;
+  const int lstar = __ffsll(hitA) - 1;
+  if (__ffsll(hitB) - 1 != lstar) return -1;
+  // second pass: the winning lane's block, lanes = rows
+  const float base = lstar > 0 ? lane_read(incl, lstar - 1) : 0.0f;
+  int len = n - lstar * B;
+  if (len > B) len = B;
+  const bool in = lane < len;
+  float p2 = 0.0f;
+  if (in) p2 = ev.one(rows + lstar * TA::kLane + TA::row(lane, RS));
+  const float inc3 = wave_inclusive_scan(p2);
+  const double cum = static_cast<double>(base) + static_cast<double>(inc3);
+  const unsigned long long hitA2 = __ballot(in && td + md <= cum), hitB2 = __ballot(in && td - md <= cum);
+  if (hitA2 == 0ull) return -1;
+  const int istar = __ffsll(hitA2) - 1;
+  if (__ffsll(hitB2) - 1 != istar) return -1;
+  return istar * 64 + lstar;
+}
+
+}  // namespace kdehip

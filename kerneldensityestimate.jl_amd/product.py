@@ -94,6 +94,12 @@ class ProductPlan:
             _lib.check(n)
         return n
 
+    def screen_stats(self) -> dict:
+        """fp32 screening (kdehip_product_screen_stats): screened levels, label draws taken on them, draws repeated in fp64."""
+        lv, st, rp = C.c_int32(0), C.c_int64(0), C.c_int64(0)
+        _lib.check(_lib.lib.kdehip_product_screen_stats(self._h, C.byref(lv), C.byref(st), C.byref(rp)))
+        return {"levels": int(lv.value), "steps": int(st.value), "repeats": int(rp.value)}
+
     def set_variant(self, v: int):
         _lib.check(_lib.lib.kdehip_product_set_variant(self._h, int(v)))
 
@@ -102,7 +108,7 @@ class ProductPlan:
         return _lib.lib.kdehip_product_kernel_name(self._h, int(Np)).decode()
 
     def launch_geometry(self, Np: int) -> dict:
-        """Wavefronts per workgroup and per chain (`team`; 1 = none) a run of Np chains gets under the current variant."""
+        """Wavefronts per workgroup a run of Np chains gets under the current variant (`team`: always 1, kept for callers)."""
         w, t = C.c_int32(0), C.c_int32(0)
         _lib.check(_lib.lib.kdehip_product_launch_geometry(self._h, int(Np), C.byref(w), C.byref(t)))
         return {"waves": int(w.value), "team": int(t.value)}

@@ -1,6 +1,6 @@
 """(needs a -DKDEHIP_EXPERIMENTS development build of gibbs_lean.hip, scripts/dev_lean.sh) Cumulative kernel time when
 the anneal stops after level k (variant 100 + k), for a launch geometry given by the thousands digit of the variant
-(0 default, 2 / 4 teams of 2 / 4, 6 / 8 sixteen / eight one-wavefront chains per workgroup):
+(0 default, 6 / 8 sixteen / eight one-wavefront chains per workgroup):
     KDEHIP_LIB=.../libkdehip_x.so python scripts/level_timing2.py c3 [nout] geometry [geometry ...]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Soak of the chunked-tile paths (frontiers beyond half the LDS pool: rows streamed through LDS, segment second pass
-from global memory) against the oracle: random dimension, density count 2..8, sizes 1500..9000, every workgroup width and team size (plan variants 52, 54).
+from global memory) against the oracle: random dimension, density count 2..8, sizes 1500..9000, every workgroup width.
     python scripts/soak_chunked.py [cases]"""
 import os
 import sys
@@ -21,7 +21,7 @@ for c in range(cases):
     M = int(rng.integers(2, 9))
     Ns = [int(rng.integers(1500, 9000)) for _ in range(M)]
     Np, Niter = int(rng.choice([8, 17, 40])), int(rng.integers(1, 3))
-    variant = int(rng.choice([0, 2, 8, 16, 52, 54]))
+    variant = int(rng.choice([0, 2, 8, 16]))
     g, o = [], []
     for n in Ns:
         pts = rng.standard_normal((D, n)) * rng.uniform(0.5, 2.0, size=(D, 1)) + rng.uniform(-1, 1, size=(D, 1))

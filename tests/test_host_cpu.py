@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol():
     from importlib import import_module
     bound = set(import_module("kdehip._lib").SIGNATURES)
     assert declared == bound, declared ^ bound
-    assert kdehip.version() == 400
+    assert kdehip.version() == 500
 
 
 def test_ctypes_signatures_match_the_header():
