@@ -262,7 +262,17 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
 
   // a step on an LDS tile with per-node bandwidths and at most 8 rows per lane whose first row `row` has been requested
   // already: broadcasts, the kept-rows draw (or the single-row one), adoption
+#ifdef KDEHIP_SCREEN_STAMPS
+  unsigned long long rstamp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, r_prev_end = 0;
+  bool rstamp_on = false;
+#define RSTAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define RSTAMP_ADD(slot, t0, t1) do { if (rstamp_on) rstamp[slot] += (t1) - (t0); } while (0)
+#else
+#define RSTAMP(var) do {} while (0)
+#define RSTAMP_ADD(slot, t0, t1) do {} while (0)
+#endif
   auto step_kept = [&](auto jc, const auto &ds, auto hdr, const auto &row, T mean, T cov, double u) {
+    RSTAMP(tr1);
     auto rows1 = hdr + kTileHeader;
     using P1 = decltype(rows1);
     using Ev = EvalFast<T, D, false>;
@@ -274,6 +284,11 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
       ev.center[d] = lane_read(mean, d);
       ev.cov[d] = lane_read(cov, d);
     }
+#ifdef KDEHIP_SCREEN_STAMPS
+    asm volatile("" ::"s"(ev.center[D - 1]), "s"(ev.cov[D - 1]));
+#endif
+    RSTAMP(tr2);
+    RSTAMP_ADD(1, tr1, tr2);
     int pos1;
     if (ds.B == 1) {
       const T S = ev(row);  // (= LaneAcc's total of a one-row lane: (v + 0) + (0 + 0))
@@ -283,7 +298,21 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
     } else {
       pos1 = draw_label_kept<T, P1, Ev, 8>(rows1, ds, lane, ev, u, fb, row);
     }
-    adopt(jc, ds, hdr, __builtin_amdgcn_readfirstlane(pos1));
+    pos1 = __builtin_amdgcn_readfirstlane(pos1);
+    RSTAMP(tr3);
+    RSTAMP_ADD(2, tr2, tr3);
+    adopt(jc, ds, hdr, pos1);
+#ifdef KDEHIP_SCREEN_STAMPS
+    {
+      const double sink = lam[decltype(jc)::value] + lmu[decltype(jc)::value];
+      asm volatile("" ::"v"(sink));
+    }
+#endif
+    RSTAMP(tr4);
+    RSTAMP_ADD(3, tr3, tr4);
+#ifdef KDEHIP_SCREEN_STAMPS
+    r_prev_end = tr4;
+#endif
   };
 
   // one (pass, density) step on a tile readable through one pointer: leave-one-out product (sweeps) or the point
@@ -296,10 +325,21 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
     // single-row step is one dependent chain, and this takes an LDS round trip out of it (profiles/r04_experiments.md).
     if constexpr (kCanPreloadImpl<decltype(hdr + kTileHeader), T, kPreloadBuild>) {
       if (!ds.uniform_bw && ds.B <= KDEHIP_PRELOAD_MAXB) {
+        RSTAMP(tr0);
+#ifdef KDEHIP_SCREEN_STAMPS
+        if (r_prev_end) RSTAMP_ADD(4, r_prev_end, tr0);
+#endif
         const auto row = EvalFast<T, D, false>().load(hdr + kTileHeader + lane * TileAddr<T>::kLane);
         T mean1 = x, cov1 = T(0);
         if (!first) product(jc, mean1, cov1);
         const double u1 = next_uniform();
+#ifdef KDEHIP_SCREEN_STAMPS
+        asm volatile("" ::"v"(mean1), "v"(cov1), "v"(u1));
+        {
+          RSTAMP(trp);
+          RSTAMP_ADD(0, tr0, trp);
+        }
+#endif
         step_kept(jc, ds, hdr, row, mean1, cov1, u1);
         return;
       }
@@ -319,23 +359,32 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
   // certified against the fp64 decision -- or repeated in fp64 from the plan's fp64 tile in global memory; the new kernel
   // always from the fp64 tile ----
   uint32_t n_screened = 0, n_repeated = 0;  // (diagnostic counters: kdehip_product_screen_stats)
+#ifdef KDEHIP_SCREEN_STAMPS
+  unsigned long long sstamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  bool sstamp_on = false;
+#endif
   auto step_screen = [&](auto jc, const auto &ds, int sc_lds_off, bool first, T x) {
     if constexpr (kScreen) {
+      SSTAMP(ts0);
+      // lanes = dimensions: what the centred operands and the error bound need from the tile's header (requested first:
+      // none of it depends on the chain)
+      const LdsPtr<float> h32 = (LdsPtr<float>)(pool + sc_lds_off);
+      const LdsPtr<double> h64 = (LdsPtr<double>)(pool + sc_lds_off);
+      const double mu0 = h64[dl], cmin = h64[8 + dl];
+      const float mmax = h32[32 + dl], valid = h32[40];
       T mean = x, cov = T(0);
       if (!first) product(jc, mean, cov);
       const double u = next_uniform();
-      const LdsPtr<float> h32 = (LdsPtr<float>)(pool + sc_lds_off);
-      const LdsPtr<double> h64 = (LdsPtr<double>)(pool + sc_lds_off);
-      // lanes = dimensions: centred operands and what the error bound needs
-      const double mu0 = h64[dl], cmin = h64[8 + dl];
-      const float mmax = h32[32 + dl], valid = h32[40];
+      SSTAMP(ts1);
+      SSTAMP_ADD(0, ts0, ts1);
       const float cen = static_cast<float>(mean - mu0);
       const float cf = static_cast<float>(cmin + cov), covf = static_cast<float>(cov);
       const float acen = fabsf(cen);
       const bool inr = (acen <= kScreenMaxAbsMean) && (covf <= static_cast<float>(kScreenMaxVar));  // (false for a NaN)
       int pos = -1;
+      const T *hdrg = data + ds.hdr_off();
       if (valid != 0.0f && __ballot(lane < D && !inr) == 0ull) {
-        const float t = mmax + acen;
+        const float t = fminf(mmax + acen, 2.0f * acen);
         float a2 = lane < D ? t * t * __builtin_amdgcn_rcpf(cf) : 0.0f;
         a2 += dpp_fetch<0x111, 0xF>(a2);  // row_shr:1, 2, 4: lane 7 holds the sum over the (at most 8) dimension lanes
         a2 += dpp_fetch<0x112, 0xF>(a2);
@@ -356,7 +405,7 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
             pr *= lane_read(cf, d);
           }
           ev.scale = __builtin_amdgcn_rsqf(pr);
-          pos = screen_draw<D, true>(rows32, ds.n, ds.B, ds.F, lane, ev, u);
+          pos = screen_draw<D, true>(rows32, ds.n, ds.B, ds.F, lane, ev, u SSTAMP_ARGS);
         } else {
           ScreenEval<D, false> ev;
           ev.A = A; ev.Bc = Bc; ev.scale = 1.0f;
@@ -365,19 +414,30 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
             ev.cen[d] = lane_read(cen, d);
             ev.b[d] = lane_read(covf, d);
           }
-          pos = screen_draw<D, false>(rows32, ds.n, ds.B, ds.F, lane, ev, u);
+          pos = screen_draw<D, false>(rows32, ds.n, ds.B, ds.F, lane, ev, u SSTAMP_ARGS);
         }
         pos = __builtin_amdgcn_readfirstlane(pos);
       }
+      SSTAMP(ts2);
+      SSTAMP_ADD(1, ts1, ts2);
       ++n_screened;
-      const T *hdrg = data + ds.hdr_off();
       if (pos < 0) {  // not certified (or out of the screen's range): the fp64 draw on the fp64 tile
         ++n_repeated;
         pos = __builtin_amdgcn_readfirstlane(draw(ds, hdrg, mean, cov, [&](const auto &ev) {
           return draw_rows(ds, hdrg + kTileHeader, ev, u);
         }));
       }
+      SSTAMP(ts3);
+      SSTAMP_ADD(2, ts2, ts3);
       adopt(jc, ds, hdrg, pos);
+#ifdef KDEHIP_SCREEN_STAMPS
+      {  // (the adopted kernel has arrived: make the stamp wait for it)
+        const double sink = lam[decltype(jc)::value] + lmu[decltype(jc)::value];
+        asm volatile("" ::"v"(sink));
+      }
+#endif
+      SSTAMP(ts4);
+      SSTAMP_ADD(3, ts3, ts4);
     }
   };
 
@@ -426,7 +486,14 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
     if constexpr (kScreen) {
       if (a.use_screen && vlev != 1) screened = scalar_copy(levels[M * (L + 1) + l].stage_mode) == kStageScreen;
     }
+#ifdef KDEHIP_SCREEN_STAMPS
+    rstamp_on = (vlev >= 300 && l == vlev - 300) && view.block == 3 && wave == 5;
+    r_prev_end = 0;
+#endif
     if (screened) {
+#ifdef KDEHIP_SCREEN_STAMPS
+      sstamp_on = (l == ((vlev >= 200) ? vlev - 200 : L)) && view.block == 3 && wave == 5;
+#endif
       // the level's M screen tiles are resident in LDS for the whole level: no barrier between steps
       auto screen = [&](int j) -> LevelDesc { return levels[(M + j) * (L + 1) + l]; };  // (j: a compile-time constant)
       staging_barrier();
@@ -612,6 +679,10 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
     }
   }
 
+#ifdef KDEHIP_SCREEN_STAMPS
+  if (view.block == 3 && wave == 5 && lane == 0)
+    for (int k = 0; k < 8; ++k) { g_screen_stamps[k] = sstamp[k]; g_screen_stamps[8 + k] = rstamp[k]; }
+#endif
   if constexpr (kScreen) {  // diagnostic counters in front of the level table: [-3] screened steps, [-2] repeated in fp64
     if (live && lane == 0 && n_screened != 0u) {
       unsigned long long *cnt = reinterpret_cast<unsigned long long *>(const_cast<LevelDesc *>(plan.levels));
@@ -703,6 +774,12 @@ int KDEHIP_CAT(launch_lean_batch_d, KDEHIP_DIM)(int M, const PlanDev &plan, cons
 // (a development build replaces this translation unit with ONE instantiation: no batched kernels)
 int KDEHIP_CAT(launch_lean_batch_d, KDEHIP_DIM)(int, const PlanDev &, const RunArgs &, void *) {
   return set_error(KDEHIP_ERR_UNSUPPORTED, "development library: no batched kernels");
+}
+#endif
+
+#if defined(KDEHIP_SCREEN_STAMPS)
+extern "C" int kdehip_debug_read_screen_stamps(unsigned long long *out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(kdehip::g_screen_stamps), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -5;
 }
 #endif
 

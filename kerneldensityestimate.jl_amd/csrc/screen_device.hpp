@@ -14,10 +14,12 @@
 // Error model (DESIGN.md "fp32 screening" has the derivation).  Entry i has the value v_i = front_i * 2^(x_i),
 // x_i = -c0 sum_d (m_id - centre_d)^2 / c_id <= 0, c0 = log2(e) / 2.  In fp32, on centred data (m' = m - mu0 and
 // centre' = centre - mu0 are formed in fp64 and rounded once, u = 2^-24):
-//   * the difference (m' - centre') carries |delta_d| <= u (|m'_d| + |centre'_d|) <= u (mmax_d + |centre'_d|) from the two
-//     roundings, which moves the exponent by at most 2 c0 sum_d |t_d| delta_d / sigma_d (t_d = the scaled difference,
-//     sigma_d^2 = c_id >= cmin_d) <= 2 sqrt(c0 |x_i|) |a'| by Cauchy-Schwarz, a'_d = u (mmax_d + |centre'_d|) / sqrt(cmin_d),
-//     and 2 sqrt(y) <= 1 + y gives the linear form  na (1 + |x_i|),  na = sqrt(c0) |a'|;
+//   * the difference (m' - centre') carries, from the two roundings, |delta_d| <= u (|m'_d| + |centre'_d|), which is at most
+//     u (mmax_d + |centre'_d|) and also at most u (|m'_d - centre'_d| + 2 |centre'_d|); the part proportional to the
+//     difference itself is a relative perturbation (counted in kx below), the rest, u g_d with g_d = min(mmax_d +
+//     |centre'_d|, 2 |centre'_d|), moves the exponent by at most 2 c0 sum_d |t_d| u g_d / sigma_d (t_d = the scaled
+//     difference, sigma_d^2 = c_id >= cmin_d) <= 2 sqrt(c0 |x_i|) |a'| by Cauchy-Schwarz, a'_d = u g_d / sqrt(cmin_d), and
+//     2 sqrt(y) <= 1 + y gives the linear form  na (1 + |x_i|),  na = sqrt(c0) |a'|;
 //   * every other operation (the subtraction itself, squares, the sums of non-negative terms, products of variances,
 //     rsq, the rounded operands) is a relative perturbation of x_i by at most kx u, kx = 32 covering D <= 8;
 //   * front_i, exp2 and the final product add at most 24 u relative to v_i; fp32 sums of n non-negative numbers in any
@@ -25,7 +27,7 @@
 // So |v~_i - v_i| <= v_i (A + Bc |x_i|) with the wave-uniform A = ln2 na + (B + 40) u, Bc = ln2 (na + kx u) (each with a
 // 1 % allowance for the second-order terms), every cumulative sum is within E = sum_i v~_i (A + Bc |x~_i|) of its fp64
 // value, and so is the target u * total.  A decision is certified when the boundaries on both sides of the target are
-// more than 2.5 E away (2 E would do).  Terms that fp32 flushes to zero or holds as denormals are below 2^-126 times a
+// more than 2.1 E away (2 E would do).  Terms that fp32 flushes to zero or holds as denormals are below 2^-126 times a
 // front that the range checks bound by 2^28 each: with total >= 2^-40 required, their sum is below 2^-40 of the margin.
 // Range checks (else the step runs in fp64): tile values (screen_build_kernel: |m'| <= 2^16, variances in [2^-7, 2^8],
 // weights in [0, 2]) and per step |centre'_d| <= 2^16, leave-one-out variance <= 2^8.
@@ -34,11 +36,26 @@
 
 namespace kdehip {
 
+// phase stamps of a screened step (diagnostic builds only: -DKDEHIP_SCREEN_STAMPS, scripts/screen_stamps.py)
+#ifdef KDEHIP_SCREEN_STAMPS
+static __device__ unsigned long long g_screen_stamps[32];
+#define SSTAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define SSTAMP_ADD(slot, t0, t1) do { if (sstamp_on) sstamp[slot] += (t1) - (t0); } while (0)
+#define SSTAMP_ARGS , sstamp, sstamp_on
+#define SSTAMP_PARAMS , unsigned long long *sstamp, bool sstamp_on
+#else
+#define SSTAMP_ARGS
+#define SSTAMP_PARAMS
+#define SSTAMP(var) do {} while (0)
+#define SSTAMP_ADD(slot, t0, t1) do {} while (0)
+#endif
+
 constexpr float kScreenU = 5.9604645e-8f;       // 2^-24
 constexpr float kScreenC0 = 0.72134752f;        // log2(e) / 2
 constexpr float kScreenSqrtC0 = 0.84932180f;    // sqrt(c0)
 constexpr float kScreenLn2 = 0.69314718f;
 constexpr float kScreenKx = 32.0f;
+constexpr double kScreenMargin = 2.1;  // boundaries farther than this many error sums from the target are decided (2 suffices)
 
 template <int D, bool UNI>
 struct ScreenEval {
@@ -86,12 +103,13 @@ struct ScreenEval {
     for (int f = 0; f < kFields; ++f) r.f[f] = load_pair(e + f * TA::kField);
     return r;
   }
-  __device__ __forceinline__ void pair(const Pair &r, kdehip_f2 &S, kdehip_f2 &E) const {
+  __device__ __forceinline__ kdehip_f2 pair(const Pair &r, kdehip_f2 &S, kdehip_f2 &E) const {
     kdehip_f2 x;
     const kdehip_f2 v = value<kdehip_f2>([&](int f) { return r.f[f]; }, x);
     S += v;
     const kdehip_f2 g = Num<kdehip_f2>::fma(-x, kdehip_f2(Bc), kdehip_f2(A));
     E = Num<kdehip_f2>::fma(v, g, E);
+    return v;
   }
   // one entry (second pass); e = (its row, field 0, its lane)
   __device__ __forceinline__ float one(LdsPtr<float> e) const {
@@ -104,9 +122,10 @@ struct ScreenEval {
 // the fp32 decision cannot be certified (the caller repeats the step in fp64).
 template <int D, bool UNI>
 __device__ __forceinline__ int screen_draw(LdsPtr<float> rows, int n, int B, int F, int lane, const ScreenEval<D, UNI> &ev,
-                                           double u) {
+                                           double u SSTAMP_PARAMS) {
   using TA = TileAddr<float>;
   const int RS = TA::stride(F);
+  SSTAMP(tq0);
   kdehip_f2 S = {0.0f, 0.0f}, E = {0.0f, 0.0f};
   LdsPtr<float> e = rows + lane * TA::kLane;
   const int npairs = (B + 1) >> 1;  // (the missing second row of the last pair is padding: weight 0)
@@ -128,17 +147,24 @@ __device__ __forceinline__ int screen_draw(LdsPtr<float> rows, int n, int B, int
   }
   KDEHIP_PRIO_CHAIN();
   const float s1 = S.x + S.y, e1 = E.x + E.y;
+#ifdef KDEHIP_SCREEN_STAMPS
+  asm volatile("" ::"v"(s1), "v"(e1));
+#endif
+  SSTAMP(tq1);
+  SSTAMP_ADD(4, tq0, tq1);
   const float incl = wave_inclusive_scan(s1);
   const float einc = wave_inclusive_scan(e1);
   const float total = lane_read(incl, 63), etot = lane_read(einc, 63);
   if (!(total >= 0x1p-40f && total < 0x1p100f)) return -1;  // (also a NaN)
-  const double td = u * static_cast<double>(total), md = 2.5 * static_cast<double>(etot);
+  const double td = u * static_cast<double>(total), md = kScreenMargin * static_cast<double>(etot);
   // first lane that certainly reaches the target = first lane that possibly does
   const double id = static_cast<double>(incl);
   const unsigned long long hitA = __ballot(td + md <= id), hitB = __ballot(td - md <= id);
   if (hitA == 0ull) return -1;
   const int lstar = __ffsll(hitA) - 1;
   if (__ffsll(hitB) - 1 != lstar) return -1;
+  SSTAMP(tq2);
+  SSTAMP_ADD(5, tq1, tq2);
   // second pass: the winning lane's block, lanes = rows
   const float base = lstar > 0 ? lane_read(incl, lstar - 1) : 0.0f;
   int len = n - lstar * B;
@@ -152,6 +178,8 @@ __device__ __forceinline__ int screen_draw(LdsPtr<float> rows, int n, int B, int
   if (hitA2 == 0ull) return -1;
   const int istar = __ffsll(hitA2) - 1;
   if (__ffsll(hitB2) - 1 != istar) return -1;
+  SSTAMP(tq3);
+  SSTAMP_ADD(6, tq2, tq3);
   return istar * 64 + lstar;
 }
 

@@ -9,8 +9,9 @@
 #
 # or, to route every existing caller (`*`, IncrementalInference, ...) through the GPU:
 #
-#   KernelDensityEstimateHIP.enable!()      # overrides KernelDensityEstimate.prodAppxMSGibbsS, .gibbs1,
-#                                           # kde!(points) and evaluateDualTree: the WHOLE `*` runs on the GPU
+#   KernelDensityEstimateHIP.enable!()      # overrides KernelDensityEstimate.prodAppxMSGibbsS, .gibbs1, kde!(points),
+#                                           # kde!(points, ks[, weights]) and evaluateDualTree: the WHOLE `*` -- product,
+#                                           # bandwidth search AND tree construction -- runs in libkdehip.so
 #
 # After enable!() a call of the reference's `prodAppxMSGibbsS` WITHOUT `randU=`/`randN=` (what `*` and every
 # JuliaRobotics caller does) no longer draws `rand(Np*Ndens*(Niter+2)*Nlevels)` / `randn(...)` on the host
@@ -69,9 +70,14 @@ reference_prodAppxMSGibbsS(args...; kw...) =
   ORIGINAL_PROD[] === nothing ? KDE.prodAppxMSGibbsS(args...; kw...) : ORIGINAL_PROD[](args...; kw...)
 
 # ... and for the callers either side of the product: `kde!(points)` (LOOCV bandwidth; the second half of `*`,
-# src/MSGibbs01.jl:725) and `evaluateDualTree` (src/DualTree01.jl:370-421)
+# src/MSGibbs01.jl:725), the explicit-bandwidth constructors `kde!(points, ks[, weights])` (src/KDE01.jl:34-76: every
+# tree of every caller) and `evaluateDualTree` (src/DualTree01.jl:370-421)
 const ORIGINAL_KDE_AUTO = Ref{Any}(nothing)
 reference_kde_auto(args...) = ORIGINAL_KDE_AUTO[] === nothing ? KDE.kde!(args...) : ORIGINAL_KDE_AUTO[](args...)
+const ORIGINAL_KDE_BW = Ref{Any}(nothing)     # kde!(points, ks, addop, diffop)
+const ORIGINAL_KDE_BWW = Ref{Any}(nothing)    # kde!(points, ks, weights, addop, diffop)
+reference_kde_bw(args...) = ORIGINAL_KDE_BW[] === nothing ? KDE.kde!(args...) : ORIGINAL_KDE_BW[](args...)
+reference_kde_bww(args...) = ORIGINAL_KDE_BWW[] === nothing ? KDE.kde!(args...) : ORIGINAL_KDE_BWW[](args...)
 const ORIGINAL_EVAL = Ref{Any}(nothing)
 const ORIGINAL_EVAL_BD = Ref{Any}(nothing)
 reference_evaluateDualTree(args...) =
@@ -282,12 +288,52 @@ function KDE.BallTreeDensity(d::DeviceDensity)
               (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64},
                Ptr{Int64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
               d.handle, centers, ranges, weights, left, right, lowest, highest, perm, means, bandwidth, bwmin, bwmax, C_NULL))
-  # the field order of the reference's constructors (src/BallTree01.jl:453-457, src/BallTreeDensity01.jl:225-226)
-  bt = KDE.BallTree(D, N, centers, ranges, weights, left, right, lowest, highest, perm, 0, KDE.swapDensity!,
+  return density_from_arrays(D, N, centers, ranges, weights, left, right, lowest, highest, perm, means, bandwidth, bwmin, bwmax)
+end
+
+# The reference's struct around twelve arrays the library filled: the field order of the reference's constructors
+# (src/BallTree01.jl:453-457, src/BallTreeDensity01.jl:225-226), the function handles makeBallTreeDensity installs
+# (src/BallTreeDensity01.jl:200-201), uniform bandwidth (multibandwidth = 0, :213), and `next` where buildTree! leaves it:
+# it starts at 2 and grows by one per internal node below the root (src/BallTree01.jl:384-393,430) = max(N, 2).
+function density_from_arrays(D::Int, N::Int, centers, ranges, weights, left, right, lowest, highest, perm, means, bandwidth,
+                             bwmin, bwmax)
+  bt = KDE.BallTree(D, N, centers, ranges, weights, left, right, lowest, highest, perm, max(N, 2), KDE.swapDensity!,
                     KDE.calcStatsDensity!, [])
   bd = KDE.BallTreeDensity(bt, KDE.GaussianKer, 0, means, bandwidth, bwmin, bwmax, bt.calcStatsHandle, bt.swapHandle)
   bd.bt.data = bd   # the circular reference the reference keeps "for emulating polymorphism"
   return bd
+end
+
+# whether `kde!(points, ks[, weights])` can be built by the library: Euclidean operators, uniform bandwidth given as 1 or D
+# standard deviations, at most 8 dimensions, at least one point (everything else: the reference's own constructor, with
+# the reference's own errors)
+builds_here(points, ks, addop, diffop) =
+  isEuclidOps(addop, diffop) && 1 <= size(points, 1) <= 8 && size(points, 2) >= 1 && (length(ks) == 1 || length(ks) == size(points, 1))
+
+"""
+    kde!(points, ks[, weights])
+
+`kde!(points, ks, weights)` / `kde!(points, ks)` (src/KDE01.jl:34-76 -> makeBallTreeDensity, src/BallTreeDensity01.jl:192-231
+-> buildTree!, src/BallTree01.jl:415-434) built by the library's pooled host builder (`kdehip_make_density`): the same
+twelve arrays as the reference's single-threaded quick-select gives, bit for bit (same split rule, swap order, node
+numbering and moment matching; pinned by the reference's own golden files).
+"""
+function kde!(points::AbstractMatrix{<:Real}, ks::Vector{Float64}, weights::Union{Nothing,Vector{Float64}}=nothing)
+  D, N = size(points)
+  pts = Matrix{Float64}(points)
+  weights === nothing || length(weights) == N || error("weights must have one entry per point")
+  centers, ranges, means, bandwidth = zeros(2N * D), zeros(2N * D), zeros(2N * D), zeros(2N * D)
+  bwmin, bwmax, w = zeros(N * D), zeros(N * D), zeros(2N)
+  left, right, lowest, highest, perm = zeros(Int, 2N), zeros(Int, 2N), zeros(Int, 2N), zeros(Int, 2N), zeros(Int, 2N)
+  GC.@preserve pts ks weights begin
+    check(ccall((:kdehip_make_density, libkdehip), Cint,
+                (Int64, Int64, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+                 Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+                 Ptr{Float64}),
+                D, N, pts, ks, length(ks), weights === nothing ? C_NULL : pointer(weights), centers, ranges, w, left, right,
+                lowest, highest, perm, means, bandwidth, bwmin, bwmax))
+  end
+  return density_from_arrays(D, N, centers, ranges, w, left, right, lowest, highest, perm, means, bandwidth, bwmin, bwmax)
 end
 
 function prodAppxMSGibbsS(npd0, trees::Vector{DeviceDensity}, anFcns, anParams;
@@ -330,8 +376,10 @@ end
 """
     kde!(points)
 
-`kde!(points)` (src/KDE01.jl:3-27): per-dimension LOOCV bandwidth found on the GPU, then the reference's
-own explicit-bandwidth constructor builds the density.
+`kde!(points)` (src/KDE01.jl:3-27) in ONE library call (`kdehip_make_density_auto`): the per-dimension LOOCV bandwidth is
+searched on the GPU while the library's pooled host builder makes the ball tree (topology, bounding boxes, weights and
+means do not depend on the bandwidth); the variances are filled in afterwards.  The arrays are those of
+`kde!(points, bw)` with the bandwidth found, bit for bit.
 """
 function kde!(points::AbstractMatrix{Float64}; device::Int=0)
   D, N = size(points)
@@ -339,13 +387,35 @@ function kde!(points::AbstractMatrix{Float64}; device::Int=0)
   bw = zeros(D)
   nev = Ref{Int32}(0)
   pts = Matrix{Float64}(points)
-  check(ccall((:kdehip_auto_bandwidth, libkdehip), Cint, (Int64, Int64, Ptr{Float64}, Ptr{Float64}, Ref{Int32}, Cint),
-              D, N, pts, bw, nev, device))
-  return KDE.kde!(pts, bw)
+  centers, ranges, means, bandwidth = zeros(2N * D), zeros(2N * D), zeros(2N * D), zeros(2N * D)
+  bwmin, bwmax, w = zeros(N * D), zeros(N * D), zeros(2N)
+  left, right, lowest, highest, perm = zeros(Int, 2N), zeros(Int, 2N), zeros(Int, 2N), zeros(Int, 2N), zeros(Int, 2N)
+  check(ccall((:kdehip_make_density_auto, libkdehip), Cint,
+              (Int64, Int64, Ptr{Float64}, Ptr{Float64}, Ref{Int32}, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+               Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+               Ptr{Float64}),
+              D, N, pts, bw, nev, device, centers, ranges, w, left, right, lowest, highest, perm, means, bandwidth, bwmin,
+              bwmax))
+  return density_from_arrays(D, N, centers, ranges, w, left, right, lowest, highest, perm, means, bandwidth, bwmin, bwmax)
 end
 
 """
-    enable!()
+    auto_bandwidth(points)
+
+The bandwidth `kde!(points)` selects (D standard deviations; `kdehip_auto_bandwidth`), without building the density.
+"""
+function auto_bandwidth(points::AbstractMatrix{Float64}; device::Int=0)
+  D, N = size(points)
+  bw = zeros(D)
+  nev = Ref{Int32}(0)
+  pts = Matrix{Float64}(points)
+  check(ccall((:kdehip_auto_bandwidth, libkdehip), Cint, (Int64, Int64, Ptr{Float64}, Ptr{Float64}, Ref{Int32}, Cint),
+              D, N, pts, bw, nev, device))
+  return bw
+end
+
+"""
+    enable!(; kde=true, trees=true, evaluate=true)
 
 Route `KernelDensityEstimate.prodAppxMSGibbsS` and `KernelDensityEstimate.gibbs1` -- and with them `*` and every
 downstream caller -- through libkdehip.so (method overwrites).  A product called without `randU`/`randN`
@@ -353,8 +423,14 @@ takes the device-RNG one-shot entry (`kdehip_prod_philox`: no host `rand`/`randn
 explicit streams are consumed in the reference's order by the `gibbs1` override.  The reference's own methods
 stay reachable for non-Euclidean manifolds and for shapes beyond the compiled limits: they are invoked in the
 world age in which they were defined.
+
+The callers either side of the product are switched by keyword (all on by default): `kde` = `kde!(points)` (LOOCV
+bandwidth + tree in one library call), `trees` = `kde!(points, ks)` and `kde!(points, ks, weights)` (every tree of every
+caller built by the library's pooled builder instead of the reference's single-threaded quick-select), `evaluate` = both
+forms of `evaluateDualTree`.  An override whose reference method cannot be found by its signature (another version of
+KernelDensityEstimate.jl) is skipped with a warning: the reference method stays in place.
 """
-function enable!()
+function enable!(; kde::Bool=true, trees::Bool=true, evaluate::Bool=true)
   devicecount() > 0 || error("libkdehip: no MI355X visible; refusing to enable (no CPU fallback in the library)")
   ORIGINAL_GIBBS1[] === nothing || return nothing   # already enabled
   orig = KDE.gibbs1
@@ -365,16 +441,31 @@ function enable!()
   invoke_original_prod(args...; kw...) = Base.invoke_in_world(mp.primary_world, origprod, args...; kw...)
   ORIGINAL_GIBBS1[] = invoke_original
   ORIGINAL_PROD[] = invoke_original_prod
-  # kde!(points, addop, diffop) (src/KDE01.jl:3-27) and the matrix / density forms of evaluateDualTree
-  # (src/DualTree01.jl:370-421): found by their signatures, invoked in the world they were defined in
+  # kde!(points, addop, diffop) (src/KDE01.jl:3-27), kde!(points, ks, addop, diffop) (:64-76), kde!(points, ks, weights,
+  # addop, diffop) (:34-57) and the matrix / density forms of evaluateDualTree (src/DualTree01.jl:370-421): found by
+  # concrete argument types, invoked in the world they were defined in; a miss leaves the reference method in place
   origkde = KDE.kde!
-  mk = which(origkde, Tuple{Matrix{Float64},Tuple,Tuple})
-  ORIGINAL_KDE_AUTO[] = (args...) -> Base.invoke_in_world(mk.primary_world, origkde, args...)
   origeval = KDE.evaluateDualTree
-  me = which(origeval, Tuple{BallTreeDensity,Matrix{Float64},Bool,Float64,Tuple,Tuple})
-  ORIGINAL_EVAL[] = (args...) -> Base.invoke_in_world(me.primary_world, origeval, args...)
-  mb = which(origeval, Tuple{BallTreeDensity,BallTreeDensity,Bool,Float64,Tuple,Tuple})
-  ORIGINAL_EVAL_BD[] = (args...) -> Base.invoke_in_world(mb.primary_world, origeval, args...)
+  Pl, Mi = Tuple{typeof(+)}, Tuple{typeof(-)}
+  function saved(f, sig, what)
+    try
+      mth = which(f, sig)
+      return (args...) -> Base.invoke_in_world(mth.primary_world, f, args...)
+    catch err
+      @warn "KernelDensityEstimateHIP.enable!: reference method not found, override skipped" what err
+      return nothing
+    end
+  end
+  kde_auto = kde ? saved(origkde, Tuple{Matrix{Float64},Pl,Mi}, "kde!(points, addop, diffop)") : nothing
+  kde_bw = trees ? saved(origkde, Tuple{Matrix{Float64},Vector{Float64},Pl,Mi}, "kde!(points, ks, addop, diffop)") : nothing
+  kde_bww = trees ? saved(origkde, Tuple{Matrix{Float64},Vector{Float64},Vector{Float64},Pl,Mi}, "kde!(points, ks, weights, addop, diffop)") : nothing
+  eval_m = evaluate ? saved(origeval, Tuple{BallTreeDensity,Matrix{Float64},Bool,Float64,Pl,Mi}, "evaluateDualTree(bd, pos::Matrix)") : nothing
+  eval_b = evaluate ? saved(origeval, Tuple{BallTreeDensity,BallTreeDensity,Bool,Float64,Pl,Mi}, "evaluateDualTree(bd, pos::BallTreeDensity)") : nothing
+  kde_auto === nothing || (ORIGINAL_KDE_AUTO[] = kde_auto)
+  kde_bw === nothing || (ORIGINAL_KDE_BW[] = kde_bw)
+  kde_bww === nothing || (ORIGINAL_KDE_BWW[] = kde_bww)
+  eval_m === nothing || (ORIGINAL_EVAL[] = eval_m)
+  eval_b === nothing || (ORIGINAL_EVAL_BD[] = eval_b)
   @eval KDE function gibbs1(Ndens::Int, trees::Array{BallTreeDensity,1}, Np::Int, Niter::Int,
                             pts::Array{Float64,1}, ind::Array{Int}, randU::Array{Float64,1},
                             randN::Array{Float64,1}; addop=(+,), diffop=(-,), getMu=(getEuclidMu,),
@@ -404,24 +495,39 @@ function enable!()
                                Np=Np, maxNp=maxNp, Nlevels=Nlevels, randU=randU, randN=randN,
                                partialDimMask=partialDimMask)
   end
-  # kde!(points) -- the second half of `*` (src/MSGibbs01.jl:725) and of every README usage: the LOOCV bandwidth search
-  # on the GPU (kdehip_auto_bandwidth), then the reference's own explicit-bandwidth constructor
-  @eval KDE function kde!(points::A, addop::Tuple=(+,), diffop::Tuple=(-,)) where {A <: AbstractArray{Float64,2}}
+  # kde!(points) -- the second half of `*` (src/MSGibbs01.jl:725) and of every README usage: LOOCV bandwidth search on the
+  # GPU and the tree on the library's host pool, one call (kdehip_make_density_auto)
+  kde_auto === nothing || @eval KDE function kde!(points::A, addop::Tuple=(+,), diffop::Tuple=(-,)) where {A <: AbstractArray{Float64,2}}
     if $(isEuclidOps)(addop, diffop) && size(points, 2) >= 2 && size(points, 1) <= 8
       return $(kde!)(points)
     end
     return $(reference_kde_auto)(points, addop, diffop)
   end
+  # kde!(points, ks) / kde!(points, ks, weights) -- every tree any caller builds (src/KDE01.jl:34-76): the library's pooled
+  # builder (kdehip_make_density); same signatures as the reference's methods, so these definitions replace them
+  kde_bw === nothing || @eval KDE function kde!(points::A, ks::Array{Float64,1}, addop::Tuple=(+,), diffop::Tuple=(-,)) where {A <: AbstractArray{Float64,2}}
+    if $(builds_here)(points, ks, addop, diffop)
+      return $(kde!)(points, ks, nothing)
+    end
+    return $(reference_kde_bw)(points, ks, addop, diffop)
+  end
+  kde_bww === nothing || @eval KDE function kde!(points::AbstractArray{<:Real,2}, ks::Array{Float64,1}, weights::Array{Float64,1},
+                                                 addop=(+,), diffop=(-,))
+    if $(builds_here)(points, ks, addop, diffop) && length(weights) == size(points, 2)
+      return $(kde!)(points, ks, weights)
+    end
+    return $(reference_kde_bww)(points, ks, weights, addop, diffop)
+  end
   # evaluateDualTree(bd, pos::Matrix) / bd(pos) / evaluateDualTree(bd, pos::BallTreeDensity): direct evaluation on the GPU
   # while the reference's own default FORCE_EVAL_DIRECT = true stands and the operators are Euclidean
-  @eval KDE function evaluateDualTree(bd::BallTreeDensity, pos::Array{Float64,2}, lvFlag::Bool=false, errTol::Float64=1e-3,
+  eval_m === nothing || @eval KDE function evaluateDualTree(bd::BallTreeDensity, pos::Array{Float64,2}, lvFlag::Bool=false, errTol::Float64=1e-3,
                                       addop=(+,), diffop=(-,))
     if $(isEuclidOps)(addop, diffop) && $(directEval)() && bd.bt.dims <= 8 && bd.multibandwidth == 0
       return $(evaluateDualTree)(bd, pos, lvFlag)
     end
     return $(reference_evaluateDualTree)(bd, pos, lvFlag, errTol, addop, diffop)
   end
-  @eval KDE function evaluateDualTree(bd::BallTreeDensity, pos::BallTreeDensity, lvFlag::Bool=false, errTol::Float64=1e-3,
+  eval_b === nothing || @eval KDE function evaluateDualTree(bd::BallTreeDensity, pos::BallTreeDensity, lvFlag::Bool=false, errTol::Float64=1e-3,
                                       addop=(+,), diffop=(-,))
     if $(isEuclidOps)(addop, diffop) && $(directEval)() && bd.bt.dims <= 8 && bd.multibandwidth == 0
       bd.bt.dims == pos.bt.dims || error("bd and pos must have the same dimension")
@@ -436,10 +542,10 @@ end
     overridden_methods()
 
 What `enable!()` replaces in `KernelDensityEstimate` (pinned by tests/test_julia_shim_syntax.py): after it, an unchanged
-caller of `*` runs product, bandwidth search and evaluation on the GPU; the trees are still built by the reference's own
-`kde!(points, bw)`.
+caller of `*` runs product, bandwidth search, tree construction and evaluation in libkdehip.so -- no stage of `*` is left
+on the reference's single-threaded Julia path.
 """
-overridden_methods() = ["gibbs1", "prodAppxMSGibbsS", "kde!", "evaluateDualTree(bd, pos::Array{Float64,2})",
-                        "evaluateDualTree(bd, pos::BallTreeDensity)"]
+overridden_methods() = ["gibbs1", "prodAppxMSGibbsS", "kde!(points)", "kde!(points, ks)", "kde!(points, ks, weights)",
+                        "evaluateDualTree(bd, pos::Array{Float64,2})", "evaluateDualTree(bd, pos::BallTreeDensity)"]
 
 end # module

@@ -105,7 +105,7 @@ def test_screen_statistics_of_config_3():
     (5.0e3, 40.0, "wide data, large bandwidths"),
 ])
 def test_screen_range_rules(shift, scale, why):
-    D, Ns, Np, Niter = 3, [1000, 900, 1000], 256, 3
+    D, Ns, Np, Niter = 6, [1000, 900, 1000], 256, 3
     g, o = _trees(77, D, Ns, shift=shift, scale=scale)
     with kdehip.ProductPlan(g) as plan:
         res = _run_variants(plan, Np, Niter, 13)
@@ -114,6 +114,7 @@ def test_screen_range_rules(shift, scale, why):
     for v in (5, 1):
         for a, b in zip(res[0], res[v]):
             assert np.array_equal(a, b), (v, why)
+    assert st["levels"] >= 1 and st["steps"] > 0, st
     if scale in (3.0e4, 1.0e-3):
         assert st["repeats"] == st["steps"], (st, why)   # never certified: every step ran in fp64
     else:

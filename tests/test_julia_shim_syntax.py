@@ -195,39 +195,63 @@ def test_prodAppxMSGibbsS_keyword_surface_is_the_references():
     assert any(re.search(r"anParams\s*,\s*Niter::Int\s*$", s.strip()) for s in pos_sigs), "positional Niter method"
 
 
+def _enable_body(code):
+    start = re.search(r"function enable!\(", code).start()
+    return code[start:code.index("overridden_methods() =")]
+
+
 def test_enable_routes_default_rng_callers_to_the_device_rng():
     """enable!() overrides prodAppxMSGibbsS with `randU=nothing, randN=nothing` defaults (no host rand(...) of
     Np*Ndens*(Niter+2)*Nlevels doubles, src/MSGibbs01.jl:661-662) and the front end sends that case to
     kdehip_prod_philox; explicit streams go through the gibbs1 drop-in."""
     code = strip_code(open(SHIM).read())
-    enable = code[code.index("function enable!()"):]
+    enable = _enable_body(code)
     assert "@eval KDE function prodAppxMSGibbsS" in enable and "@eval KDE function gibbs1" in enable
     override = [s for s in _signatures(enable, "prodAppxMSGibbsS")][0]
     assert re.search(r"randU\s*=\s*nothing", override) and re.search(r"randN\s*=\s*nothing", override)
-    front = code[code.index("function prodAppxMSGibbsS("):code.index("function enable!()")]
+    front = code[code.index("function prodAppxMSGibbsS("):re.search(r"function enable!\(", code).start()]
     assert ":kdehip_prod_philox" in front and "gibbs1(Ndens, trees, Np, Niter, points, indices, randU, randN" in front
 
 
 def test_enable_overrides_the_whole_star_operator():
     """The reference's `*` is product THEN `kde!(pGM)` (src/MSGibbs01.jl:724-725 -> src/KDE01.jl:3-27 ->
-    src/CrossValidation.jl:110-120): enable!() must replace both halves, and `evaluateDualTree` (src/DualTree01.jl:370-421),
-    or an unchanged caller gets a GPU product followed by the reference's CPU bandwidth search.  The list of overridden
-    methods is pinned here."""
+    src/CrossValidation.jl:110-120), and every input of it came out of `kde!(points, ks[, weights])` (src/KDE01.jl:34-76 ->
+    makeBallTreeDensity -> buildTree!, src/BallTree01.jl:415-434): enable!() must replace the product, the bandwidth search,
+    the TREE CONSTRUCTORS and `evaluateDualTree` (src/DualTree01.jl:370-421), or an unchanged caller is left with a stage of
+    `*` on the reference's single-threaded Julia path (missing 1).  The list of SEVEN overridden methods is
+    pinned here."""
     code = strip_code(open(SHIM).read())
-    enable = code[code.index("function enable!()"):code.index("overridden_methods() =")]
-    installed = [(m.group(1), enable[m.end():m.end() + 160]) for m in re.finditer(r"@eval KDE function\s+([A-Za-z_!0-9]+)\(", enable)]
+    enable = _enable_body(code)
+    installed = [(m.group(1), enable[m.end():m.end() + 200]) for m in re.finditer(r"@eval KDE function\s+([A-Za-z_!0-9]+)\(", enable)]
     names = [n for n, _ in installed]
-    assert names == ["gibbs1", "prodAppxMSGibbsS", "kde!", "evaluateDualTree", "evaluateDualTree"], names
-    sig = dict((n + str(k), a) for k, (n, a) in enumerate(installed))
-    assert "points::A" in sig["kde!2"] and "addop::Tuple" in sig["kde!2"] and "diffop::Tuple" in sig["kde!2"]
-    assert "pos::Array{Float64,2}" in sig["evaluateDualTree3"] and "pos::BallTreeDensity" in sig["evaluateDualTree4"]
+    assert names == ["gibbs1", "prodAppxMSGibbsS", "kde!", "kde!", "kde!", "evaluateDualTree", "evaluateDualTree"], names
+    sig = [a for _, a in installed]
+    # the three kde! methods carry the reference's own signatures (src/KDE01.jl:1-3, 64, 34-38): same signature = replaced
+    assert "points::A" in sig[2] and "addop::Tuple" in sig[2] and "ks::" not in sig[2]
+    assert "points::A" in sig[3] and "ks::Array{Float64,1}" in sig[3] and "addop::Tuple" in sig[3] and "weights" not in sig[3]
+    assert "points::AbstractArray{<:Real,2}" in sig[4] and "ks::Array{Float64,1}" in sig[4] and "weights::Array{Float64,1}" in sig[4]
+    assert "pos::Array{Float64,2}" in sig[5] and "pos::BallTreeDensity" in sig[6]
     # each override keeps the reference reachable: non-Euclidean operators, FORCE_EVAL_DIRECT = false, sizes beyond the limits
-    for ref in ("reference_kde_auto", "reference_evaluateDualTree", "reference_evaluateDualTree_bd", "invoke_original"):
+    for ref in ("reference_kde_auto", "reference_kde_bw", "reference_kde_bww", "reference_evaluateDualTree",
+                "reference_evaluateDualTree_bd", "invoke_original"):
         assert ref in enable, ref
-    assert "directEval" in enable and "isEuclidOps" in enable
-    # ... through the world age in which the reference's methods were defined
-    assert enable.count("Base.invoke_in_world") == 5
-    # the GPU entries the overrides land on
-    body = code[:code.index("function enable!()")]
-    for sym in (":kdehip_auto_bandwidth", ":kdehip_evaluate", ":kdehip_mul_device", ":kdehip_density_download"):
+    assert "directEval" in enable and "isEuclidOps" in enable and "builds_here" in enable
+    # ... through the world age in which the reference's methods were defined (gibbs1, prodAppxMSGibbsS, and ONE helper
+    # for the five signature look-ups, each of which may miss without taking enable!() down)
+    assert enable.count("Base.invoke_in_world") == 3
+    assert enable.count("saved(orig") == 5 and "catch" in enable
+    # the switches of the callers either side of the product (ADVICE round 4)
+    assert re.search(r"function enable!\(;\s*kde::Bool=true,\s*trees::Bool=true,\s*evaluate::Bool=true\)", code)
+    # the library entries the overrides land on: ONE call for kde!(points), the pooled builder for the explicit forms
+    body = code[:re.search(r"function enable!\(", code).start()]
+    for sym in (":kdehip_make_density_auto", ":kdehip_make_density,", ":kdehip_auto_bandwidth", ":kdehip_evaluate",
+                ":kdehip_mul_device", ":kdehip_density_download"):
         assert sym in body, sym
+    # kde!(points) no longer ends in the reference's constructor
+    auto = body[body.index("function kde!(points::AbstractMatrix{Float64}; device"):]
+    auto = auto[:auto.index("\nend")]
+    assert "KDE.kde!(" not in auto and ":kdehip_make_density_auto" in auto
+    # the struct is assembled in ONE place, with `next` where buildTree! leaves it (src/BallTree01.jl:384-393,430)
+    assert body.count("KDE.BallTree(") == 1 and "max(N, 2), KDE.swapDensity!" in body
+    listed = re.search(r"overridden_methods\(\) = \[(.*?)\]", open(SHIM).read(), flags=re.S).group(1)
+    assert listed.count('"') == 14
