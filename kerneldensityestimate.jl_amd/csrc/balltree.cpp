@@ -10,6 +10,7 @@
 //
 // Compiled with -ffp-contract=off: the moment-matching expressions must not be fused.
 #include <cfloat>
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <exception>
@@ -18,6 +19,7 @@
 #include <vector>
 
 #include "../../include/kdehip.h"
+#include "device_density.hpp"
 #include "host_pool.hpp"
 #include "kdehip_internal.hpp"
 
@@ -320,7 +322,38 @@ extern "C" int kdehip_make_density(int64_t D, int64_t N, const double *points, c
 extern "C" int kdehip_density_set_bandwidth(int64_t D, int64_t N, const double *ks, int64_t nks, const double *weights,
                                             const int64_t *left_child, const int64_t *right_child, const double *means,
                                             double *bandwidth, double *bandwidthMin, double *bandwidthMax) {
-  using namespace kdehip;
+  return kdehip::set_bandwidth_examined(D, N, ks, nks, weights, left_child, right_child, means, bandwidth, bandwidthMin,
+                                        bandwidthMax, nullptr, nullptr);
+}
+
+// internal nodes 1 .. N-1 in pre-order from the root (read back to front: every node after its descendants)
+int kdehip::children_first_order(int64_t N, const int64_t *left_child, const int64_t *right_child, std::vector<int64_t> &order) {
+  std::vector<int64_t> stack;
+  stack.reserve(64);
+  order.clear();
+  order.reserve(static_cast<size_t>(N));
+  if (N < 2) return KDEHIP_OK;
+  stack.push_back(1);
+  while (!stack.empty()) {
+    const int64_t id = stack.back();
+    stack.pop_back();
+    if (id < 1 || id >= N) return set_error(KDEHIP_ERR_ARG, "kdehip_density_set_bandwidth: malformed tree");
+    order.push_back(id);
+    const int64_t a = left_child[id - 1], b = right_child[id - 1];
+    if (a <= N && a >= 1 && a != id) stack.push_back(a);
+    if (b <= N && b >= 1 && b != id) stack.push_back(b);
+    if (static_cast<int64_t>(order.size()) > N) return set_error(KDEHIP_ERR_ARG, "kdehip_density_set_bandwidth: malformed tree");
+  }
+  return KDEHIP_OK;
+}
+
+// The same, and -- on the values it walks through anyway -- what examine_frontiers' `look` would find on this tree:
+// the range of the variances per dimension and whether every mean, variance and weight is fit for the fast arithmetic
+// form (every node of a well-formed tree is on some frontier, so "all nodes" is "all frontier nodes").
+int kdehip::set_bandwidth_examined(int64_t D, int64_t N, const double *ks, int64_t nks, const double *weights,
+                                   const int64_t *left_child, const int64_t *right_child, const double *means,
+                                   double *bandwidth, double *bandwidthMin, double *bandwidthMax, NodeStats *st,
+                                   const std::vector<int64_t> *order_in) {
   if (D < 1 || N < 1) return set_error(KDEHIP_ERR_ARG, "kdehip_density_set_bandwidth: need D >= 1 and N >= 1");
   if (nks != 1 && nks != D) return set_error(KDEHIP_ERR_ARG, "kdehip_density_set_bandwidth: ks must have 1 or D entries");
   if (!ks || !weights || !left_child || !right_child || !means || !bandwidth || !bandwidthMin || !bandwidthMax)
@@ -345,21 +378,17 @@ extern "C" int kdehip_density_set_bandwidth(int64_t D, int64_t N, const double *
     }
     return KDEHIP_OK;
   }
-  // internal nodes 1 .. N-1, children before parents: an explicit post-order walk from the root
-  std::vector<int64_t> stack, order;
-  stack.reserve(64);
-  order.reserve(static_cast<size_t>(N));
-  stack.push_back(1);
-  while (!stack.empty()) {
-    const int64_t id = stack.back();
-    stack.pop_back();
-    if (id < 1 || id >= N) return set_error(KDEHIP_ERR_ARG, "kdehip_density_set_bandwidth: malformed tree");
-    order.push_back(id);
-    const int64_t a = left_child[id - 1], b = right_child[id - 1];
-    if (a <= N && a >= 1 && a != id) stack.push_back(a);
-    if (b <= N && b >= 1 && b != id) stack.push_back(b);
-    if (static_cast<int64_t>(order.size()) > N) return set_error(KDEHIP_ERR_ARG, "kdehip_density_set_bandwidth: malformed tree");
+  // internal nodes 1 .. N-1, children before parents
+  std::vector<int64_t> own;
+  if (!order_in) {
+    const int rc = children_first_order(N, left_child, right_child, own);
+    if (rc != KDEHIP_OK) return rc;
   }
+  const std::vector<int64_t> &order = order_in ? *order_in : own;
+  // (with `st`: the range of the variances is kept on the values as they are formed)
+  double vlo[KDEHIP_MAX_DIMS], vhi[KDEHIP_MAX_DIMS];
+  for (int64_t k = 0; k < KDEHIP_MAX_DIMS; ++k) { vlo[k] = k < D ? var[static_cast<size_t>(k)] : INFINITY; vhi[k] = k < D ? var[static_cast<size_t>(k)] : 0.0; }
+  bool vbad = false;
   for (size_t t = order.size(); t-- > 0;) {  // reverse pre-order: every node after its descendants
     const int64_t id = order[t];
     const int64_t a = left_child[id - 1], b = right_child[id - 1];
@@ -371,8 +400,38 @@ extern "C" int kdehip_density_set_bandwidth(int64_t D, int64_t N, const double *
     for (int64_t k = 0; k < D; ++k) {
       const double ma = means[(a - 1) * D + k], mb = means[(b - 1) * D + k];
       const double m = wa * ma + wb * mb;
-      bandwidth[(id - 1) * D + k] = wa * (bandwidth[(a - 1) * D + k] + ma * ma) + wb * (bandwidth[(b - 1) * D + k] + mb * mb) - m * m;
+      const double v = wa * (bandwidth[(a - 1) * D + k] + ma * ma) + wb * (bandwidth[(b - 1) * D + k] + mb * mb) - m * m;
+      bandwidth[(id - 1) * D + k] = v;
+      if (st && k < KDEHIP_MAX_DIMS) {
+        vbad |= !(v > 0.0) | !(v < INFINITY);
+        vlo[k] = v < vlo[k] ? v : vlo[k];
+        vhi[k] = v > vhi[k] ? v : vhi[k];
+      }
     }
+  }
+  if (st) {
+    // what is left of the examination: every mean below 1e100 in magnitude, every weight finite and not negative (flat
+    // sweeps over contiguous arrays: the nodes 1 .. N-1 and N+1 .. 2N; slot N is not a node), the leaf variances
+    bool bad = vbad;
+    for (int64_t k = 0; k < D; ++k) bad = bad || !(var[static_cast<size_t>(k)] > 0.0) || !(var[static_cast<size_t>(k)] < INFINITY);
+    // (the leaves decide: an internal node's mean is a convex combination of leaf means -- it cannot leave their range
+    // by more than rounding, and a NaN or an infinity among them reaches the root -- and its weight a sum of leaf weights)
+    double macc = 0.0;
+    bool nan = false;
+    for (int64_t i = N * D; i < 2 * N * D; ++i) {
+      const double a = std::fabs(means[i]);
+      nan |= !(a == a);
+      macc = a > macc ? a : macc;
+    }
+    for (int64_t k = 0; k < D; ++k) { const double a = std::fabs(means[k]); nan |= !(a == a); macc = a > macc ? a : macc; }  // the root
+    bad = bad || nan || !(macc < 1e100);
+    for (int64_t id = N + 1; id <= 2 * N; ++id) {
+      const double w = weights[id - 1];
+      bad |= !(w >= 0.0) | !(w < INFINITY);
+    }
+    bad = bad || !(weights[0] >= 0.0) || !(weights[0] < INFINITY);
+    st->bad = bad;
+    for (int k = 0; k < KDEHIP_MAX_DIMS; ++k) { st->lo[k] = vlo[k]; st->hi[k] = vhi[k]; }
   }
   return KDEHIP_OK;
 }

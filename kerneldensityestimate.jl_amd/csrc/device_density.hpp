@@ -12,6 +12,7 @@ namespace kdehip {
 // so they are expanded once -- per product by the host packer, per density for densities kept on the device.
 struct Frontiers {
   std::vector<int32_t> ids;      // node ids (1-based), level l at [off[l], off[l+1])
+  std::vector<uint8_t> fresh;    // per id: 1 where the node enters the frontier (a leaf stays as its own child: 0 from then on)
   std::vector<int64_t> off;      // L + 2 entries
   std::vector<uint8_t> uniform;  // L + 1: every node of the frontier has the bandwidth vector of its first node
   std::vector<double> uratio;    // L + 1, uniform frontiers: max over nodes and dimensions of |mean_d| / sqrt(2 bandwidth_d)
@@ -22,6 +23,10 @@ struct Frontiers {
 };
 // `look`: also examine every node once (the conditions of the fast arithmetic form, pack_levels.cpp).
 int expand_frontiers(const kdehip_density &t, int D, int L, bool look, Frontiers &out);
+// The same in two steps: the ids depend on the child arrays only, the flags (shared bandwidth per level, ranges, finiteness)
+// on the values -- kde!(points) of a device matrix expands the ids while the GPU still searches the bandwidth.
+int expand_frontier_ids(const kdehip_density &t, int D, int L, Frontiers &out);
+void examine_frontiers(const kdehip_density &t, int D, int L, bool look, Frontiers &out);
 
 // The shape of one tile: all pack_layout needs once the frontiers are known.
 struct TileShape {
@@ -52,6 +57,15 @@ int launch_fill_tiles(int precision, const FillJob *d_jobs, int ntiles, int maxB
 // (density, level); enqueue only.
 int launch_screen_build(const PlanDev &plan, void *stream);
 
+// kdehip_density_set_bandwidth (balltree.cpp) that also reports what the packers' examination of the nodes would find
+struct NodeStats { bool bad; double lo[KDEHIP_MAX_DIMS], hi[KDEHIP_MAX_DIMS]; };
+// (`order`: the internal nodes, every node AFTER its descendants when read back to front -- children_first_order -- when the
+// caller has worked it out already; it depends on the child arrays only)
+int set_bandwidth_examined(int64_t D, int64_t N, const double *ks, int64_t nks, const double *weights, const int64_t *left_child,
+                           const int64_t *right_child, const double *means, double *bandwidth, double *bandwidthMin,
+                           double *bandwidthMax, NodeStats *st, const std::vector<int64_t> *order = nullptr);
+int children_first_order(int64_t N, const int64_t *left_child, const int64_t *right_child, std::vector<int64_t> &order);
+
 }  // namespace kdehip
 
 // A BallTreeDensity resident on one device (include/kdehip.h "densities in HBM").
@@ -67,11 +81,19 @@ struct kdehip_device_density {
   const int64_t *perm = nullptr;
   const int32_t *front = nullptr;
   // A density the library built itself (kdehip_density_from_device_points) keeps the reference's twelve arrays as a
-  // host mirror for kdehip_density_download: hf = centers, ranges, means, bandwidth (2ND each), bandwidthMin,
-  // bandwidthMax (ND each), weights (2N); hi = left, right, lowest, highest, permutation (2N each)
+  // host mirror for kdehip_density_download, in ONE pinned block from the library's cache (a fresh 1 MB heap block per
+  // density is an mmap of its own: 250 page faults to fill it and -- in a process with a live HIP runtime, whose driver
+  // hooks every unmap -- a munmap of ~2 ms to drop it: the "host tree alone 2.1 ms" of profiles/r04p): the head of the
+  // block IS the image of the device block ([means | bandwidth | weights | permutation | frontier ids], uploaded
+  // straight from here), the other eight arrays follow
   bool built = false;
-  std::vector<double> hf;
-  std::vector<int64_t> hi;
+  void *mirror = nullptr;
+  size_t mirror_bytes = 0;
+  struct Mirror {
+    double *centers = nullptr, *ranges = nullptr, *means = nullptr, *bandwidth = nullptr, *bwmin = nullptr, *bwmax = nullptr,
+           *weights = nullptr;
+    int64_t *left = nullptr, *right = nullptr, *lowest = nullptr, *highest = nullptr, *perm = nullptr;
+  } m;
   double bw[KDEHIP_MAX_DIMS] = {};  // its LOOCV bandwidth (standard deviations)
 };
 

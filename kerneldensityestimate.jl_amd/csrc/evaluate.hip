@@ -290,8 +290,8 @@ constexpr double kGoldenTol = 1e-2;  // ksize, src/CrossValidation.jl:116
 constexpr int kCounterStride = 32;   // loo_round_pairs_kernel's slot counters: a 128-byte line each (neighbours in one line
                                      // make it bounce between the XCDs' L2s)
 constexpr int kPrepThreads = 1024;
-constexpr int64_t kPrepMaxN = 2048;  // marginals up to this size are prepared on the device (LDS: 40 bytes per point of the
-                                     // next power of two: 80 KiB; 4096 points would need all 160 KiB plus the statics)
+constexpr int64_t kPrepMaxN = kLoocvPrepMaxN;  // marginals up to this size are prepared on the device (LDS: 40 bytes per point
+                                               // of the next power of two: 80 KiB; 4096 points would need all 160 KiB plus the statics)
 
 // State of one 1-D golden-section search (golden, src/CrossValidation.jl:44-98) + what ksize needs around it.
 struct Golden {
@@ -745,7 +745,7 @@ __global__ void loo_finalize_kernel(const LooRound r) {
 // sampled (kdehip_density_from_device_points): the marginals are then prepared straight from it, nothing is uploaded.
 // Marginals beyond kPrepMaxN points are prepared on the host and need `points`.
 int kdehip::auto_bandwidth_run(int D, int64_t N, const double *points, const double *d_points, void *stream,
-                               double *bw_out, int32_t *nevals_out) {
+                               double *bw_out, int32_t *nevals_out, const std::function<void()> *overlap) {
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (!points && !(d_points && N <= kPrepMaxN)) return set_error(KDEHIP_ERR_ARG, "auto_bandwidth_run: no host copy of the points");
   const bool timing = std::getenv("KDEHIP_TIMING") != nullptr;
@@ -869,6 +869,7 @@ int kdehip::auto_bandwidth_run(int D, int64_t N, const double *points, const dou
     hipLaunchKernelGGL(loo_finalize_kernel, dim3(1), dim3(64), 0, st, r);
     KDEHIP_CHECK(hipGetLastError());
     KDEHIP_CHECK(hipMemcpyAsync(h_state, r.state + (r.round & 1) * D, sizeof(Golden) * D, hipMemcpyDeviceToHost, st));
+    if (overlap && batches == 0) (*overlap)();  // (the first batch is in flight: the caller's host work runs under it)
     KDEHIP_CHECK(hipStreamSynchronize(st));
     ++batches;
     bool done = true;

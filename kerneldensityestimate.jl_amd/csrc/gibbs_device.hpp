@@ -934,6 +934,12 @@ struct LevelTable {
 };
 // conditional-table descriptors (32 B each) through the constant address space, like LevelTable
 typedef int kdehip_v8i __attribute__((ext_vector_type(8)));
+// step descriptors (StepDesc, 32 B): the RAW eight dwords, so that a step can ask for its successor's descriptor and
+// leave it in flight (unpacked a step later)
+struct StepTable {
+  const __attribute__((address_space(4))) kdehip_v8i *p;
+  __device__ __forceinline__ kdehip_v8i raw(int idx) const { return p[idx]; }  // one s_load_dwordx8
+};
 struct TabTable {
   const __attribute__((address_space(4))) kdehip_v8i *p;
   __device__ __forceinline__ TabDesc operator[](int idx) const {

@@ -72,15 +72,30 @@ struct LeanTile {
   __device__ __forceinline__ int64_t hdr_off() const {
     return (static_cast<int64_t>(hdr_hi) << 32) | static_cast<uint32_t>(hdr_lo);
   }
-  __device__ __forceinline__ void load(const LevelDesc &d) {
-    n = scalar_copy(d.n);
-    flags = scalar_copy(d.last_lane | (d.uniform_bw << 8));
-    lds_off = scalar_copy(d.lds_off);
-    stage_bytes = scalar_copy(d.stage_bytes);
-    chunk_rows = scalar_copy(d.chunk_rows);
-    seg = scalar_copy(d.seg);
-    hdr_lo = scalar_copy(static_cast<int>(d.hdr_off));
-    hdr_hi = scalar_copy(static_cast<int>(d.hdr_off >> 32));
+  // a packed step word (pack_step_word) + hdr_off / 8: the tiles of a level that sit in LDS for the whole level
+  __device__ __forceinline__ void unpack(int w, int h8) {
+    const unsigned u = static_cast<unsigned>(w);
+    n = static_cast<int>(u & 0x1FFFu);
+    last_lane = static_cast<int>((u >> 13) & 63u);
+    uniform_bw = static_cast<int>((u >> 19) & 1u);
+    flags = last_lane | (uniform_bw << 8);
+    lds_off = static_cast<int>(u >> 20) << 10;
+    stage_bytes = 0; chunk_rows = 0; seg = 0;
+    const uint64_t off = static_cast<uint64_t>(static_cast<unsigned>(h8)) << 3;
+    hdr_lo = static_cast<int>(off & 0xFFFFFFFFu);
+    hdr_hi = static_cast<int>(off >> 32);
+    B = (n + 63) >> 6;
+    F = uniform_bw ? D + 1 : 2 * D + 1;
+  }
+  __device__ __forceinline__ void load(const kdehip_v8i &d) {  // (a StepDesc's eight dwords)
+    n = scalar_copy(d[0]);
+    flags = scalar_copy(d[1]);
+    lds_off = scalar_copy(d[2]);
+    stage_bytes = scalar_copy(d[3]);
+    chunk_rows = scalar_copy(d[4]);
+    seg = scalar_copy(d[5]);
+    hdr_lo = scalar_copy(d[6]);
+    hdr_hi = scalar_copy(d[7]);
     B = (n + 63) >> 6;
     last_lane = flags & 0xFF;
     uniform_bw = flags >> 8;
@@ -133,6 +148,10 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
   const int L = plan.L;
   const T *__restrict__ data = static_cast<const T *>(plan.data);
   const LevelTable levels{(const __attribute__((address_space(4))) kdehip_v16i *)(plan.levels)};
+  const StepTable steps{(const __attribute__((address_space(4))) kdehip_v8i *)(plan.levels + 2 * plan.M * (plan.L + 1))};
+  // the packed step words: [2][L+1] x 8 dwords behind the step descriptors (32 B each: half a LevelDesc)
+  const StepTable words{(const __attribute__((address_space(4))) kdehip_v8i *)(plan.levels + 2 * plan.M * (plan.L + 1)) +
+                        plan.M * (plan.L + 1)};
   unsigned char *pool = smem + kPoolOff;
   const int dl = lane < D ? lane : D - 1;  // this lane's dimension in the "lanes = dimensions" phases
   const int vlev = a.variant % 1000;
@@ -473,9 +492,10 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
     // scratch in their per-step code (config 4 with 16,384 chains: 39 ms against 31 ms; config 3: 4.32 against 4.22 ms)
     // and bought the 8-wavefront builds nothing (0.6255 against 0.6222 ms).
     const int level_mode = scalar_copy(levels[l].stage_mode);
-    auto tile = [&](int j) -> LeanTile<D> {  // (j is a compile-time constant at every call site)
+    auto tile_raw = [&](int j) -> kdehip_v8i { return steps.raw(j * (L + 1) + l); };  // (j: a compile-time constant)
+    auto tile = [&](int j) -> LeanTile<D> {
       LeanTile<D> t;
-      t.load(levels[j * (L + 1) + l]);
+      t.load(tile_raw(j));
       return t;
     };
     const int mode = vlev == 1 ? int(kStageGlobal) : level_mode;
@@ -503,11 +523,17 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
                           pool + sc.lds_off, sc.stage_bytes, wave, lane);
       });
       staging_barrier();
+      // the level's M tiles as ONE dword each (+ the fp64 tile's place in global memory), fetched once per level: no
+      // descriptor load on a step's path (a level the packer could not pack: the step descriptors)
+      const kdehip_v8i w8 = words.raw(l), h8 = words.raw(L + 1 + l);
+      const bool packed = w8[0] != 0;
       for (int p = 0; p < npass; ++p)
         static_for<M>([&](auto jc) {
-          const LeanTile<D> ds = tile(decltype(jc)::value);
-          const int sc_off = scalar_copy(screen(decltype(jc)::value).lds_off);
-          step_screen(jc, ds, sc_off, p == 0, x);
+          constexpr int j = decltype(jc)::value;
+          LeanTile<D> ds;
+          if (packed) ds.unpack(w8[j], h8[j]);
+          else ds.load(tile_raw(j));
+          step_screen(jc, ds, ds.lds_off, p == 0, x);  // (on a screened level lds_off is the screen tile's)
         });
     } else if (mode == kStageResident) {
       staging_barrier();  // every wavefront is done reading the previous level's images
@@ -516,9 +542,14 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
         stage_tile<WAVES>(reinterpret_cast<const unsigned char *>(data + ds.hdr_off()), pool + ds.lds_off, ds.stage_bytes, wave, lane);
       });
       staging_barrier();
+      const kdehip_v8i w8 = words.raw(l);  // (one dword per tile, once per level: see the screened levels)
+      const bool packed = w8[0] != 0;
       for (int p = 0; p < npass; ++p)
         static_for<M>([&](auto jc) {
-          const LeanTile<D> ds = tile(decltype(jc)::value);
+          constexpr int j = decltype(jc)::value;
+          LeanTile<D> ds;
+          if (packed) ds.unpack(w8[j], 0);
+          else ds.load(tile_raw(j));
           step(jc, ds, (RowPtr)(pool + ds.lds_off), p == 0, x);
         });
     } else if (mode == kStageStream) {

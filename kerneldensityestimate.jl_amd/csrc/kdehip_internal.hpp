@@ -5,6 +5,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -119,6 +120,32 @@ static_assert(sizeof(LevelDesc) == 64, "LevelDesc is read with scalar loads; kee
 // Descriptors: a second [M][L+1] table of LevelDesc right behind the plan's level table; entry (j, l) has stage_mode ==
 // kStageScreen when LEVEL l is screened, n / B / F / uniform_bw / last_lane of the fp64 tile, hdr_off = offset of the
 // screen tile's header in FLOATS from the plan's data, lds_off / stage_bytes of its LDS image.
+// ---- step descriptors (round 5) --------------------------------------------------------------------------------------
+// What a draw step of the register-resident sampler needs of a tile, 32 bytes, read with ONE s_load_dwordx8 that is issued
+// a step AHEAD (the 16-dword LevelDesc was fetched at the start of the step that needed it: ~200 cycles of scalar-cache
+// latency on every step's critical path).  A third [M][L+1] table behind the level and screen tables (which are both
+// always present: the screen table is all zero when no level is screened).
+struct StepDesc {
+  int32_t n;            // frontier size
+  int32_t flags;        // last_lane | uniform_bw << 8
+  int32_t lds_off;      // LDS offset of the tile's image: the fp64 tile's on a resident level, the SCREEN tile's on a screened one
+  int32_t stage_bytes;  // bytes of the fp64 image (streamed mode)
+  int32_t chunk_rows;   // rows per chunk (chunked mode)
+  int32_t seg;          // LevelDesc.seg
+  int32_t hdr_lo, hdr_hi;  // element offset of the fp64 tile's header in the plan's data
+};
+static_assert(sizeof(StepDesc) == 32, "StepDesc is read with one 32-byte scalar load");
+// ... and for the levels whose tiles sit in LDS for the whole level (resident fp64 tiles, screen tiles: at most 4096
+// nodes, images at multiples of 1 KiB) even that load goes: ONE dword per tile -- n | last_lane << 13 | uniform_bw << 19 |
+// (lds_off >> 10) << 20 -- in a LEVEL-major table of 8 dwords per level, fetched once per level and kept in scalar registers
+// (products of up to 8 densities), plus a second such table with hdr_off / 8 (tiles start at multiples of 8 elements) for the
+// screened levels, whose steps adopt from the fp64 tile in global memory.  0 = the level's steps use StepDesc.
+constexpr int kStepWordsPerLevel = 8;
+inline uint32_t pack_step_word(int32_t n, int32_t last_lane, int32_t uniform_bw, int32_t lds_off) {
+  return static_cast<uint32_t>(n) | (static_cast<uint32_t>(last_lane) << 13) | (static_cast<uint32_t>(uniform_bw) << 19) |
+         (static_cast<uint32_t>(lds_off >> 10) << 20);
+}
+
 constexpr int kScreenHeaderFloats = 48;
 constexpr int kScreenMaxRows = 64;           // rows per lane up to which a level is screened (one second-pass round)
 constexpr float kScreenMaxAbsMean = 65536.0f;  // |m'_d|, |centre'_d| <= 2^16
@@ -239,6 +266,8 @@ struct PackedProduct {
   bool all_active = true;          // every dimension of every density is informed by another density
   std::vector<TabDesc> tabdesc;    // [M][L+1]
   std::vector<LevelDesc> screens;  // [M][L+1] screen descriptors ("fp32 screening"), empty = no level is screened
+  std::vector<StepDesc> steps;     // [M][L+1] step descriptors
+  std::vector<uint32_t> words;     // [2][L+1][kStepWordsPerLevel]: packed step words, then hdr_off / 8
   int nscreened = 0;               // screened levels
   int Lt = 0;                      // tabulated levels 1..Lt
   int64_t tab_entries = 0, tab_rows = 0;
@@ -261,6 +290,7 @@ bool pack_fill(const PackedProduct &pp, const kdehip_density *trees, void *data,
 
 // floor(log(maxNp)/log(2) + 1), reference src/MSGibbs01.jl:568
 int nlevels_for(int64_t maxNp);
+
 
 // ---- kernel launch (gibbs_kernel.hip) ----------------------------------------------------------
 // Arithmetic form of the kernel evaluation (see gibbs_kernel.hip).
@@ -302,8 +332,12 @@ int launch_tables_batch(int D, const PlanDev &plan, const RunArgs &args, void *s
 
 // kde!(points)'s LOOCV bandwidth search (evaluate.hip) on `stream` of the current device, from the host's copy of the
 // D x N matrix and/or a copy that already lives in HBM (`d_points`: nothing is uploaded then).  Blocking.
+// `overlap` (optional) is called ONCE, on the calling thread, after the preparation and the first batch of rounds have
+// been enqueued and before the host waits for them: work that needs the host but not the bandwidth runs under the search.
+// (kLoocvPrepMaxN: marginals up to this size are prepared by the device from the matrix as it is -- no host copy needed.)
+constexpr int64_t kLoocvPrepMaxN = 2048;
 int auto_bandwidth_run(int D, int64_t N, const double *points, const double *d_points, void *stream, double *bw_out,
-                       int32_t *nevals_out);
+                       int32_t *nevals_out, const std::function<void()> *overlap = nullptr);
 
 // Chains per workgroup (= wavefronts per CU, one workgroup per CU at a time) of a sampling launch: 4, 8 or 16,
 // the width with the smallest estimated time rounds(width) * cost(width) unless `variant` pins it

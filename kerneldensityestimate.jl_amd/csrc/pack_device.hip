@@ -12,9 +12,14 @@
 // the same bytes the host packer (pack_levels.cpp pack_fill) writes, tested bit for bit.
 #include <hip/hip_runtime.h>
 
+#include <cfloat>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <functional>
 #include <mutex>
 #include <new>
 #include <string>
@@ -205,17 +210,37 @@ int launch_screen_build(const PlanDev &plan, void *stream_) {
 
 namespace {
 
+// The one device block of a density: [means | bandwidth | weights | permutation | frontier ids].
+struct BlockLayout {
+  size_t o_mean = 0, o_bw = 0, o_w = 0, o_perm = 0, o_front = 0, total = 0, nd = 0, n2 = 0;
+  BlockLayout(int64_t N, int64_t D, size_t nfront) {
+    auto al = [](size_t x) { return (x + 255) & ~static_cast<size_t>(255); };
+    nd = sizeof(double) * 2 * N * D;
+    n2 = sizeof(double) * 2 * N;
+    o_mean = 0; o_bw = al(o_mean + nd); o_w = al(o_bw + nd); o_perm = al(o_w + n2);
+    o_front = al(o_perm + sizeof(int64_t) * 2 * N);
+    total = al(o_front + sizeof(int32_t) * nfront);
+  }
+};
+void bind_block(kdehip_device_density *h, const BlockLayout &bl) {
+  unsigned char *db = static_cast<unsigned char *>(h->d_blob);
+  h->means = reinterpret_cast<const double *>(db + bl.o_mean);
+  h->bandwidth = reinterpret_cast<const double *>(db + bl.o_bw);
+  h->weights = reinterpret_cast<const double *>(db + bl.o_w);
+  h->perm = reinterpret_cast<const int64_t *>(db + bl.o_perm);
+  h->front = reinterpret_cast<const int32_t *>(db + bl.o_front);
+  std::vector<int32_t>().swap(h->fr.ids);  // (the ids live on the device now; sizes, offsets and flags stay)
+  std::vector<uint8_t>().swap(h->fr.fresh);
+}
+
 // Frontiers, the arithmetic-form examination and the one device block of a density whose six arrays `host` describes
 // (h->device, N, D, Lown are set; the device is current).  Everything travels on `st`, which is waited for.
 int upload_common(kdehip_device_density *h, const kdehip_density &host, hipStream_t st) {
   const int64_t N = h->N, D = h->D;
   int rc = expand_frontiers(host, h->D, h->Lown, /*look=*/true, h->fr);
   if (rc != KDEHIP_OK) return rc;
-  auto al = [](size_t x) { return (x + 255) & ~static_cast<size_t>(255); };
-  const size_t nd = sizeof(double) * 2 * N * D, n2 = sizeof(double) * 2 * N;
-  const size_t o_mean = 0, o_bw = al(o_mean + nd), o_w = al(o_bw + nd), o_perm = al(o_w + n2);
-  const size_t o_front = al(o_perm + sizeof(int64_t) * 2 * N);
-  const size_t total = al(o_front + sizeof(int32_t) * h->fr.ids.size());
+  const BlockLayout bl(N, D, h->fr.ids.size());
+  const size_t total = bl.total;
   void *pin = nullptr;
   hipError_t e = cached_host_malloc(&pin, total);
   if (e == hipSuccess) e = cached_malloc(&h->d_blob, total);
@@ -226,11 +251,11 @@ int upload_common(kdehip_device_density *h, const kdehip_density &host, hipStrea
   }
   h->blob_bytes = total;
   unsigned char *hp = static_cast<unsigned char *>(pin);
-  std::memcpy(hp + o_mean, host.means, nd);
-  std::memcpy(hp + o_bw, host.bandwidth, nd);
-  std::memcpy(hp + o_w, host.weights, n2);
-  std::memcpy(hp + o_perm, host.permutation, sizeof(int64_t) * 2 * N);
-  std::memcpy(hp + o_front, h->fr.ids.data(), sizeof(int32_t) * h->fr.ids.size());
+  std::memcpy(hp + bl.o_mean, host.means, bl.nd);
+  std::memcpy(hp + bl.o_bw, host.bandwidth, bl.nd);
+  std::memcpy(hp + bl.o_w, host.weights, bl.n2);
+  std::memcpy(hp + bl.o_perm, host.permutation, sizeof(int64_t) * 2 * N);
+  std::memcpy(hp + bl.o_front, h->fr.ids.data(), sizeof(int32_t) * h->fr.ids.size());
   e = hipMemcpyAsync(h->d_blob, pin, total, hipMemcpyHostToDevice, st);
   const hipError_t se = hipStreamSynchronize(st);
   cached_host_free(pin, total);
@@ -239,14 +264,24 @@ int upload_common(kdehip_device_density *h, const kdehip_density &host, hipStrea
     h->d_blob = nullptr;
     return set_error(KDEHIP_ERR_HIP, std::string("density upload: ") + hipGetErrorString(e != hipSuccess ? e : se));
   }
-  unsigned char *db = static_cast<unsigned char *>(h->d_blob);
-  h->means = reinterpret_cast<const double *>(db + o_mean);
-  h->bandwidth = reinterpret_cast<const double *>(db + o_bw);
-  h->weights = reinterpret_cast<const double *>(db + o_w);
-  h->perm = reinterpret_cast<const int64_t *>(db + o_perm);
-  h->front = reinterpret_cast<const int32_t *>(db + o_front);
-  std::vector<int32_t>().swap(h->fr.ids);  // (the ids live on the device now; sizes, offsets and flags stay)
+  bind_block(h, bl);
   return KDEHIP_OK;
+}
+
+// A stream of the calling thread's own beside hipStreamPerThread, per device (created on first use, never destroyed --
+// like the per-thread stream itself): copies that must not queue behind the work already on the thread's stream.
+hipStream_t side_stream(int device) {
+  static thread_local hipStream_t streams[64] = {};
+  static thread_local bool tried[64] = {};
+  if (device < 0 || device >= 64) return nullptr;
+  if (!tried[device]) {
+    tried[device] = true;
+    if (hipStreamCreateWithFlags(&streams[device], hipStreamNonBlocking) != hipSuccess) {
+      streams[device] = nullptr;
+      (void)hipGetLastError();
+    }
+  }
+  return streams[device];
 }
 
 int check_shape(int64_t N, int64_t D) {
@@ -310,52 +345,149 @@ extern "C" int kdehip_density_from_device_points(kdehip_device_density **out, co
   DeviceGuard guard;
   rc = guard.enter(device);
   if (rc != KDEHIP_OK) return rc;
+  static const bool timing = std::getenv("KDEHIP_TIMING") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
+  auto us = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); };
   hipStream_t cs = hipStreamPerThread, ps = static_cast<hipStream_t>(stream);
   if (ps != cs) KDEHIP_CHECK(hipStreamSynchronize(ps));  // the producer of d_points (blocking entry: the host waits anyway)
   kdehip_device_density *h = new (std::nothrow) kdehip_device_density();
   if (!h) return set_error(KDEHIP_ERR_ALLOC, "out of host memory");
   struct Cleanup {
     kdehip_device_density *h; void *pin = nullptr; size_t pin_bytes = 0;
-    ~Cleanup() { if (pin) cached_host_free(pin, pin_bytes); delete h; }
+    hipStream_t s1 = nullptr, s2 = nullptr;
+    ~Cleanup() {  // (error paths: nothing may still be in flight into or out of the blocks that go back to the caches)
+      if (s1) (void)hipStreamSynchronize(s1);
+      if (s2) (void)hipStreamSynchronize(s2);
+      if (pin) cached_host_free(pin, pin_bytes);
+      if (h && h->d_blob) cached_free(h->d_blob, h->blob_bytes);
+      if (h && h->mirror) cached_host_free(h->mirror, h->mirror_bytes);
+      delete h;
+    }
   } cl{h};
   h->device = device; h->N = N; h->D = static_cast<int>(D); h->Lown = nlevels_for(N);
   cl.pin_bytes = sizeof(double) * N * D;
   KDEHIP_CHECK(cached_host_malloc(&cl.pin, cl.pin_bytes));
-  KDEHIP_CHECK(hipMemcpyAsync(cl.pin, d_points, cl.pin_bytes, hipMemcpyDeviceToHost, cs));
-  KDEHIP_CHECK(hipStreamSynchronize(cs));
-  const double *pts = static_cast<const double *>(cl.pin);
-  // the reference's twelve arrays, kept as the handle's host mirror (kdehip_density_download)
-  const size_t nd = static_cast<size_t>(2 * N * D), n2 = static_cast<size_t>(2 * N);
-  try {
-    h->hf.assign(4 * nd + nd + n2, 0.0);
-    h->hi.assign(5 * n2, 0);
-  } catch (const std::exception &) { return set_error(KDEHIP_ERR_ALLOC, "out of host memory"); }
-  double *centers = h->hf.data(), *ranges = centers + nd, *means = ranges + nd, *bandwidth = means + nd;
-  double *bwmin = bandwidth + nd, *bwmax = bwmin + nd / 2, *weights = bwmax + nd / 2;
-  int64_t *left = h->hi.data(), *right = left + n2, *lowest = right + n2, *highest = lowest + n2, *perm = highest + n2;
-  double bw[KDEHIP_MAX_DIMS];
-  int tree_rc = KDEHIP_OK;
-  try {
-    TaskGroup group(HostPool::get());
-    group.run([&] {
-      const double one = 1.0;  // (placeholder: only `bandwidth`, bandwidthMin/Max depend on the bandwidth)
-      tree_rc = kdehip_make_density(D, N, pts, &one, 1, nullptr, centers, ranges, weights, left, right, lowest, highest,
-                                    perm, means, bandwidth, bwmin, bwmax);
-    });
-    rc = auto_bandwidth_run(static_cast<int>(D), N, pts, d_points, cs, bw, nevals);
-    group.wait();
-  } catch (const std::exception &e) {
-    return set_error(KDEHIP_ERR_ALLOC, std::string("kdehip_density_from_device_points: ") + e.what());
+  // The matrix comes down on a stream of its own, behind an event on the thread's stream (the product that made it may
+  // still be running there): with marginals the device prepares itself (N <= kLoocvPrepMaxN) the bandwidth search is
+  // enqueued right behind that event too and needs no host copy -- the copy, the tree, the frontiers and the upload of
+  // everything that does not depend on the bandwidth then all run UNDER the search.
+  hipStream_t xs = side_stream(device);
+  const bool under = xs != nullptr && N <= kLoocvPrepMaxN;
+  cl.s1 = cs; cl.s2 = xs;
+  if (under) {
+    hipEvent_t ev = nullptr;
+    KDEHIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipError_t e = hipEventRecord(ev, cs);
+    if (e == hipSuccess) e = hipStreamWaitEvent(xs, ev, 0);
+    (void)hipEventDestroy(ev);  // (released by the runtime once the wait has been served)
+    if (e != hipSuccess) return set_error(KDEHIP_ERR_HIP, std::string("kdehip_density_from_device_points: ") + hipGetErrorString(e));
+    KDEHIP_CHECK(hipMemcpyAsync(cl.pin, d_points, cl.pin_bytes, hipMemcpyDeviceToHost, xs));
+  } else {
+    KDEHIP_CHECK(hipMemcpyAsync(cl.pin, d_points, cl.pin_bytes, hipMemcpyDeviceToHost, cs));
+    KDEHIP_CHECK(hipStreamSynchronize(cs));
   }
-  if (rc != KDEHIP_OK) return rc;
+  const double *pts = static_cast<const double *>(cl.pin);
+  // The reference's twelve arrays, kept as the handle's host mirror (kdehip_density_download), in one pinned block whose
+  // head is the image of the device block (device_density.hpp).  The frontier ids of a tree of N leaves number at most
+  // (Lown + 1) * N; the layout reserves that much.
+  const size_t nd = static_cast<size_t>(2 * N * D), n2 = static_cast<size_t>(2 * N);
+  const BlockLayout bl(N, D, static_cast<size_t>(h->Lown + 1) * static_cast<size_t>(N) + 64);
+  auto al = [](size_t x) { return (x + 255) & ~static_cast<size_t>(255); };
+  const size_t o_extra = bl.total;  // centers, ranges (nd each), bwmin, bwmax (nd / 2 each), left, right, lowest, highest (n2 each)
+  h->mirror_bytes = al(o_extra + sizeof(double) * (2 * nd + nd) + sizeof(int64_t) * 4 * n2);
+  KDEHIP_CHECK(cached_host_malloc(&h->mirror, h->mirror_bytes));
+  unsigned char *mb = static_cast<unsigned char *>(h->mirror);
+  double *means = reinterpret_cast<double *>(mb + bl.o_mean), *bandwidth = reinterpret_cast<double *>(mb + bl.o_bw);
+  double *weights = reinterpret_cast<double *>(mb + bl.o_w);
+  int64_t *perm = reinterpret_cast<int64_t *>(mb + bl.o_perm);
+  double *centers = reinterpret_cast<double *>(mb + o_extra), *ranges = centers + nd, *bwmin = ranges + nd, *bwmax = bwmin + nd / 2;
+  int64_t *left = reinterpret_cast<int64_t *>(bwmax + nd / 2), *right = left + n2, *lowest = right + n2, *highest = lowest + n2;
+  h->m = {centers, ranges, means, bandwidth, bwmin, bwmax, weights, left, right, lowest, highest, perm};
+  const kdehip_density host{N, D, means, bandwidth, weights, left, right, perm};
+  double bw[KDEHIP_MAX_DIMS];
+  int tree_rc = KDEHIP_OK, side_rc = KDEHIP_OK;
+  std::string side_msg;
+  double us_tree = 0.0, us_side = 0.0;
+  const double one = 1.0;  // (placeholder: only `bandwidth`, bandwidthMin/Max depend on the bandwidth)
+  // what needs the host but not the bandwidth: the tree (topology, bounding boxes, weights, means), the frontier ids,
+  // the device block and the upload of everything in it but the variances
+  std::vector<int64_t> order;
+  auto host_side = [&]() {
+    if (hipStreamSynchronize(xs) != hipSuccess) { side_rc = KDEHIP_ERR_HIP; side_msg = "the copy of the points failed"; return; }
+    tree_rc = kdehip_make_density(D, N, pts, &one, 1, nullptr, centers, ranges, weights, left, right, lowest, highest, perm,
+                                  means, bandwidth, bwmin, bwmax);
+    us_tree = us();
+    if (tree_rc != KDEHIP_OK) return;
+    side_rc = expand_frontier_ids(host, h->D, h->Lown, h->fr);
+    if (side_rc != KDEHIP_OK) { side_msg = kdehip_last_error(); return; }
+    side_rc = children_first_order(N, left, right, order);  // (the order the variances are filled in: topology only)
+    if (side_rc != KDEHIP_OK) { side_msg = kdehip_last_error(); return; }
+    if (h->fr.ids.size() > static_cast<size_t>(h->Lown + 1) * static_cast<size_t>(N) + 64) {
+      side_rc = KDEHIP_ERR_ARG; side_msg = "more frontier ids than a tree of N leaves has"; return;
+    }
+    hipError_t e = cached_malloc(&h->d_blob, bl.total);
+    if (e == hipSuccess) h->blob_bytes = bl.total; else h->d_blob = nullptr;
+    if (e == hipSuccess) {  // everything but the variances, straight from the mirror (pinned): no staging copy
+      std::memcpy(mb + bl.o_front, h->fr.ids.data(), sizeof(int32_t) * h->fr.ids.size());
+      unsigned char *db = static_cast<unsigned char *>(h->d_blob);
+      e = hipMemcpyAsync(db + bl.o_mean, mb + bl.o_mean, bl.nd, hipMemcpyHostToDevice, xs);
+      if (e == hipSuccess)
+        e = hipMemcpyAsync(db + bl.o_w, mb + bl.o_w, bl.o_front + sizeof(int32_t) * h->fr.ids.size() - bl.o_w, hipMemcpyHostToDevice, xs);
+    }
+    if (e != hipSuccess) { side_rc = KDEHIP_ERR_HIP; side_msg = std::string("density block: ") + hipGetErrorString(e); }
+    us_side = us();
+  };
+  if (under) {
+    const std::function<void()> fn = host_side;
+    rc = auto_bandwidth_run(static_cast<int>(D), N, nullptr, d_points, cs, bw, nevals, &fn);
+    if (rc != KDEHIP_OK) return rc;
+  } else {
+    // (larger marginals are prepared on the host: the search needs the copy first; the tree still builds under it)
+    try {
+      TaskGroup group(HostPool::get());
+      group.run([&] {
+        tree_rc = kdehip_make_density(D, N, pts, &one, 1, nullptr, centers, ranges, weights, left, right, lowest, highest,
+                                      perm, means, bandwidth, bwmin, bwmax);
+      });
+      rc = auto_bandwidth_run(static_cast<int>(D), N, pts, d_points, cs, bw, nevals);
+      group.wait();
+    } catch (const std::exception &e) {
+      return set_error(KDEHIP_ERR_ALLOC, std::string("kdehip_density_from_device_points: ") + e.what());
+    }
+    if (rc != KDEHIP_OK) return rc;
+  }
+  const double us_search = us();
   if (tree_rc != KDEHIP_OK) return set_error(tree_rc, "kdehip_density_from_device_points: the tree build failed");
-  rc = kdehip_density_set_bandwidth(D, N, bw, D, weights, left, right, means, bandwidth, bwmin, bwmax);
-  if (rc != KDEHIP_OK) return rc;
+  if (side_rc != KDEHIP_OK) return set_error(side_rc, "kdehip_density_from_device_points: " + side_msg);
+  double us_setbw = 0.0, us_exam = 0.0, us_copy = 0.0;
   for (int k = 0; k < D; ++k) { h->bw[k] = bw[k]; if (bw_out) bw_out[k] = bw[k]; }
   h->built = true;
-  const kdehip_density host{N, D, means, bandwidth, weights, left, right, perm};
-  rc = upload_common(h, host, cs);
-  if (rc != KDEHIP_OK) return rc;
+  if (under) {
+    // the bandwidth-dependent rest: the variances (and, on the values it walks through, what the packers' examination of
+    // the nodes needs), then their upload from the pinned mirror with the per-level flags formed under the transfer
+    NodeStats stats{};
+    rc = set_bandwidth_examined(D, N, bw, D, weights, left, right, means, bandwidth, bwmin, bwmax, &stats, &order);
+    if (rc != KDEHIP_OK) return rc;
+    us_setbw = us();
+    unsigned char *db = static_cast<unsigned char *>(h->d_blob);
+    KDEHIP_CHECK(hipMemcpyAsync(db + bl.o_bw, mb + bl.o_bw, bl.nd, hipMemcpyHostToDevice, xs));  // (from the pinned mirror)
+    us_copy = us();
+    examine_frontiers(host, h->D, h->Lown, /*look=*/false, h->fr);
+    h->fr.bad = stats.bad;
+    for (int k = 0; k < KDEHIP_MAX_DIMS; ++k) { h->fr.lo[k] = stats.lo[k]; h->fr.hi[k] = stats.hi[k]; }
+    us_exam = us();
+    KDEHIP_CHECK(hipStreamSynchronize(xs));
+    bind_block(h, bl);
+  } else {
+    rc = kdehip_density_set_bandwidth(D, N, bw, D, weights, left, right, means, bandwidth, bwmin, bwmax);
+    if (rc != KDEHIP_OK) return rc;
+    rc = upload_common(h, host, cs);
+    if (rc != KDEHIP_OK) return rc;
+  }
+  if (timing)
+    std::fprintf(stderr, "kdehip_density_from_device_points D=%lld N=%lld: tree built at %.0f us | block prepared at %.0f us | search over at %.0f us | variances %.0f | flags %.0f | staged %.0f | done at %.0f us\n",
+                 static_cast<long long>(D), static_cast<long long>(N), us_tree, us_side, us_search, us_setbw, us_exam, us_copy, us());
+  cl.s1 = cl.s2 = nullptr;  // (everything has been waited for)
   cl.h = nullptr;
   *out = h;
   return KDEHIP_OK;
@@ -417,13 +549,12 @@ extern "C" int kdehip_density_download(const kdehip_device_density *h, double *c
   if (!h) return set_error(KDEHIP_ERR_ARG, "null density");
   if (!h->built) return set_error(KDEHIP_ERR_UNSUPPORTED, "this density was uploaded by the caller, who holds its arrays");
   const size_t nd = static_cast<size_t>(2 * h->N * h->D), n2 = static_cast<size_t>(2 * h->N);
-  const double *f = h->hf.data();
-  const int64_t *i = h->hi.data();
+  const kdehip_device_density::Mirror &m = h->m;
   auto cp = [](auto *dst, const auto *src, size_t n) { if (dst) std::memcpy(dst, src, n * sizeof(*src)); };
-  cp(centers, f, nd); cp(ranges, f + nd, nd); cp(means, f + 2 * nd, nd); cp(bandwidth, f + 3 * nd, nd);
-  cp(bandwidthMin, f + 4 * nd, nd / 2); cp(bandwidthMax, f + 4 * nd + nd / 2, nd / 2); cp(weights, f + 5 * nd, n2);
-  cp(left_child, i, n2); cp(right_child, i + n2, n2); cp(lowest_leaf, i + 2 * n2, n2); cp(highest_leaf, i + 3 * n2, n2);
-  cp(permutation, i + 4 * n2, n2);
+  cp(centers, m.centers, nd); cp(ranges, m.ranges, nd); cp(means, m.means, nd); cp(bandwidth, m.bandwidth, nd);
+  cp(bandwidthMin, m.bwmin, nd / 2); cp(bandwidthMax, m.bwmax, nd / 2); cp(weights, m.weights, n2);
+  cp(left_child, m.left, n2); cp(right_child, m.right, n2); cp(lowest_leaf, m.lowest, n2); cp(highest_leaf, m.highest, n2);
+  cp(permutation, m.perm, n2);
   if (bw_out) for (int k = 0; k < h->D; ++k) bw_out[k] = h->bw[k];
   return KDEHIP_OK;
 }
@@ -434,7 +565,9 @@ extern "C" void kdehip_density_free(kdehip_device_density *h) {
   if (guard.enter(h->device) == KDEHIP_OK) {
     (void)hipDeviceSynchronize();  // products enqueued on caller streams may still read the block
     if (h->d_blob) cached_free(h->d_blob, h->blob_bytes);
+    if (h->mirror) cached_host_free(h->mirror, h->mirror_bytes);
   }
+  else if (h->mirror) (void)hipHostFree(h->mirror);  // (no device to enter: hand the pinned block back to the driver)
   delete h;
 }
 

@@ -43,19 +43,61 @@ bool variances_in_range(const double *bw_lo, const double *bw_hi, int D, int pre
   return (precision == 64) ? (up < 1e120 && dn > 1e-120) : (up < 1e15 && dn > 1e-15);
 }
 
-// The frontiers of one density, levels 0..L (levelInit! / levelDown!, src/MSGibbs01.jl:467-475, 503-511), and with
-// `look` every node examined ONCE, at the level where it enters the frontier (a leaf re-enters the next frontier as its
-// own left child: not new): finiteness and the bandwidth range of the arithmetic-form decision.
-int expand_frontiers(const kdehip_density &t, int D, int L, bool look, Frontiers &out) {
+// The frontiers of one density, levels 0..L (levelInit! / levelDown!, src/MSGibbs01.jl:467-475, 503-511): the node ids
+// only -- they depend on the child arrays alone -- with `fresh` marking the level at which a node ENTERS the frontier
+// (a leaf re-enters the next frontier as its own left child: not new).
+int expand_frontier_ids(const kdehip_density &t, int D, int L, Frontiers &out) {
+  (void)D;
   const int64_t N = t.npts;
   out.ids.clear();
+  out.fresh.clear();
   out.ids.reserve(static_cast<size_t>(N) * (L + 1) / 2 + 64);
+  out.fresh.reserve(static_cast<size_t>(N) * (L + 1) / 2 + 64);
   out.off.assign(static_cast<size_t>(L) + 2, 0);
+  out.nodes = 0;
+  for (int l = 0; l <= L; ++l) {
+    const size_t begin = out.ids.size();
+    out.off[l] = static_cast<int64_t>(begin);
+    if (l == 0) {
+      out.ids.push_back(1);  // levelInit!: frontier = {root()}
+      out.fresh.push_back(1);
+    } else {
+      const size_t pb = static_cast<size_t>(out.off[l - 1]), pe = begin;
+      out.ids.resize(begin + 2 * (pe - pb));  // (at most two children per node; trimmed below)
+      out.fresh.resize(begin + 2 * (pe - pb));
+      int32_t *dst = out.ids.data() + begin;
+      uint8_t *fr = out.fresh.data() + begin;
+      const int32_t *src = out.ids.data() + pb;
+      size_t cnt = 0;
+      for (size_t z = 0; z < pe - pb; ++z) {
+        const int64_t node = src[z];
+        const int64_t a = t.left_child[node - 1], b = t.right_child[node - 1];
+        if (a > 0 && a <= 2 * N) {  // validIndex, BallTree01.jl:83
+          fr[cnt] = a != node;
+          dst[cnt++] = static_cast<int32_t>(a);
+        }
+        if (b > 0 && b <= 2 * N) {
+          fr[cnt] = b != node;
+          dst[cnt++] = static_cast<int32_t>(b);
+        }
+      }
+      out.ids.resize(begin + cnt);
+      out.fresh.resize(begin + cnt);
+      const int64_t n = static_cast<int64_t>(cnt);
+      if (n == 0 || n > N) return set_error(KDEHIP_ERR_ARG, "malformed tree: frontier empty or larger than Npts");
+      out.nodes += n;
+    }
+  }
+  out.off[static_cast<size_t>(L) + 1] = static_cast<int64_t>(out.ids.size());
+  return KDEHIP_OK;
+}
+
+// What the VALUES of the frontier nodes say (needs the ids above): whether a level shares one bandwidth vector, and with
+// `look` every node examined ONCE, at the level where it enters the frontier -- finiteness and the bandwidth range of the
+// arithmetic-form decision.
+void examine_frontiers(const kdehip_density &t, int D, int L, bool look, Frontiers &out) {
   out.uniform.assign(static_cast<size_t>(L) + 1, 1);
   out.uratio.assign(static_cast<size_t>(L) + 1, 0.0);
-  out.bad = false;
-  out.nodes = 0;
-  for (int d = 0; d < KDEHIP_MAX_DIMS; ++d) { out.lo[d] = INFINITY; out.hi[d] = 0.0; }
   bool bad = false;
   double lo[KDEHIP_MAX_DIMS], hi[KDEHIP_MAX_DIMS];
   for (int d = 0; d < KDEHIP_MAX_DIMS; ++d) { lo[d] = INFINITY; hi[d] = 0.0; }
@@ -71,59 +113,49 @@ int expand_frontiers(const kdehip_density &t, int D, int L, bool look, Frontiers
     bad |= !(w >= 0.0) | !(w < INFINITY);
   };
   for (int l = 0; l <= L; ++l) {
-    const size_t begin = out.ids.size();
-    out.off[l] = static_cast<int64_t>(begin);
-    if (l == 0) {
-      out.ids.push_back(1);  // levelInit!: frontier = {root()}
-      if (look) look_at(1);
-    } else {
-      const size_t pb = static_cast<size_t>(out.off[l - 1]), pe = begin;
-      out.ids.resize(begin + 2 * (pe - pb));  // (at most two children per node; trimmed below)
-      int32_t *dst = out.ids.data() + begin;
-      const int32_t *src = out.ids.data() + pb;
-      size_t cnt = 0;
-      for (size_t z = 0; z < pe - pb; ++z) {
-        const int64_t node = src[z];
-        const int64_t a = t.left_child[node - 1], b = t.right_child[node - 1];
-        if (a > 0 && a <= 2 * N) {  // validIndex, BallTree01.jl:83
-          dst[cnt++] = static_cast<int32_t>(a);
-          if (a != node && look) look_at(a);
-        }
-        if (b > 0 && b <= 2 * N) {
-          dst[cnt++] = static_cast<int32_t>(b);
-          if (b != node && look) look_at(b);
-        }
-      }
-      out.ids.resize(begin + cnt);
-      const int64_t n = static_cast<int64_t>(cnt);
-      if (n == 0 || n > N) return set_error(KDEHIP_ERR_ARG, "malformed tree: frontier empty or larger than Npts");
-      out.nodes += n;
-    }
+    const size_t begin = static_cast<size_t>(out.off[l]), end = static_cast<size_t>(out.off[l + 1]);
+    if (look)
+      for (size_t z = begin; z < end; ++z)
+        if (out.fresh[z]) look_at(out.ids[z]);
     // one bandwidth vector shared by the whole frontier?  (stops at the first node that differs: frontiers with
     // internal nodes are decided after a node or two, only the all-leaf frontiers are scanned in full)
     const double *bw0 = t.bandwidth + (static_cast<int64_t>(out.ids[begin]) - 1) * D;
     bool uni = true;
-    for (size_t z = begin + 1; z < out.ids.size() && uni; ++z) {
+    for (size_t z = begin + 1; z < end && uni; ++z) {
       const double *v = t.bandwidth + (static_cast<int64_t>(out.ids[z]) - 1) * D;
       for (int d = 0; d < D; ++d)
         if (v[d] != bw0[d]) uni = false;
     }
     out.uniform[l] = uni ? 1 : 0;
     if (uni) {  // (all-leaf frontiers: scanned in full above anyway)
-      double ratio = 0.0;
-      for (size_t z = begin; z < out.ids.size(); ++z) {
+      // max over nodes and dimensions of |mean_d| / sqrt(2 bandwidth_d): the division by a positive constant is monotone,
+      // so the largest quotient is the quotient of the largest |mean_d| -- one square root and one division per
+      // DIMENSION instead of per node (they were 100 us of a 2048-point density's 110)
+      double amax[KDEHIP_MAX_DIMS];
+      for (int d = 0; d < D; ++d) amax[d] = 0.0;
+      for (size_t z = begin; z < end; ++z) {
         const double *mu = t.means + (static_cast<int64_t>(out.ids[z]) - 1) * D;
         for (int d = 0; d < D; ++d) {
-          const double r = std::fabs(mu[d]) / std::sqrt(2.0 * bw0[d]);
-          ratio = r > ratio ? r : ratio;   // (a NaN mean or a non-positive bandwidth: caught by `look` / pack_fill)
+          const double a = std::fabs(mu[d]);
+          amax[d] = a > amax[d] ? a : amax[d];   // (a NaN mean or a non-positive bandwidth: caught by `look` / pack_fill)
         }
+      }
+      double ratio = 0.0;
+      for (int d = 0; d < D; ++d) {
+        const double r = amax[d] / std::sqrt(2.0 * bw0[d]);
+        ratio = r > ratio ? r : ratio;
       }
       out.uratio[l] = ratio;
     }
   }
-  out.off[static_cast<size_t>(L) + 1] = static_cast<int64_t>(out.ids.size());
   out.bad = bad;
-  for (int d = 0; d < D; ++d) { out.lo[d] = lo[d]; out.hi[d] = hi[d]; }
+  for (int d = 0; d < KDEHIP_MAX_DIMS; ++d) { out.lo[d] = lo[d]; out.hi[d] = hi[d]; }
+}
+
+int expand_frontiers(const kdehip_density &t, int D, int L, bool look, Frontiers &out) {
+  const int rc = expand_frontier_ids(t, D, L, out);
+  if (rc != KDEHIP_OK) return rc;
+  examine_frontiers(t, D, L, look, out);
   return KDEHIP_OK;
 }
 
@@ -350,6 +382,39 @@ int pack_layout_shapes(int M, int D, int L, const TileShape *shapes, const uint8
     }
   }
   out.data_elems = nelem + 1024 / 4;  // staged copies are rounded up to whole KiB: keep the tail readable
+  out.steps.resize(out.levels.size());
+  for (size_t idx = 0; idx < out.levels.size(); ++idx) {
+    const LevelDesc &ds = out.levels[idx];
+    StepDesc &s = out.steps[idx];
+    s.n = ds.n;
+    s.flags = ds.last_lane | (ds.uniform_bw << 8);
+    s.lds_off = ds.lds_off;
+    if (!out.screens.empty() && out.screens[idx].stage_mode == kStageScreen) s.lds_off = out.screens[idx].lds_off;
+    s.stage_bytes = ds.stage_bytes;
+    s.chunk_rows = ds.chunk_rows;
+    s.seg = ds.seg;
+    s.hdr_lo = static_cast<int32_t>(ds.hdr_off & 0xFFFFFFFF);
+    s.hdr_hi = static_cast<int32_t>(ds.hdr_off >> 32);
+  }
+  out.words.assign(static_cast<size_t>(2) * (L + 1) * kStepWordsPerLevel, 0u);
+  if (M <= kStepWordsPerLevel)
+    for (int l = 1; l <= L; ++l) {
+      bool ok = true;
+      for (int j = 0; j < M && ok; ++j) {
+        const size_t idx = static_cast<size_t>(j) * (L + 1) + l;
+        const LevelDesc &ds = out.levels[idx];
+        const bool scr = !out.screens.empty() && out.screens[idx].stage_mode == kStageScreen;
+        ok = (scr || ds.stage_mode == kStageResident) && ds.n <= 4096 && (out.steps[idx].lds_off & 1023) == 0 &&
+             out.steps[idx].lds_off < (128 << 10) && (ds.hdr_off & 7) == 0 && (ds.hdr_off >> 3) < (int64_t(1) << 32);
+      }
+      if (!ok) continue;
+      for (int j = 0; j < M; ++j) {
+        const size_t idx = static_cast<size_t>(j) * (L + 1) + l;
+        const LevelDesc &ds = out.levels[idx];
+        out.words[static_cast<size_t>(l) * kStepWordsPerLevel + j] = pack_step_word(ds.n, ds.last_lane, ds.uniform_bw, out.steps[idx].lds_off);
+        out.words[static_cast<size_t>(L + 1 + l) * kStepWordsPerLevel + j] = static_cast<uint32_t>(ds.hdr_off >> 3);
+      }
+    }
 
   // ---- phase 4: conditional tables (gibbs_kernel.hip): levels whose frontiers all fit one wavefront row
   // and have power-of-two sizes, as long as the rows of all densities stay within the entry budget
