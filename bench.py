@@ -179,13 +179,20 @@ def main():
     # i+1; a slot is written again only after its previous gather has been waited for
     slots = [sp._buffers(Np_total, 0), sp._buffers(Np_total, 1)]
 
+    gather_wait = [0.0]  # host seconds this rank spent waiting for all-gathers (N > 1)
+
+    def wait_gather(bufs):
+        if bufs["pending"] is not None:
+            tw = time.perf_counter()
+            bufs["pending"].wait()
+            gather_wait[0] += time.perf_counter() - tw
+            bufs["pending"] = None
+
     def one_call(i):
         """ONE prodAppxMSGibbsS-equivalent call: tiles packed on the GPU from the resident densities + conditional
         tables + sampling of this rank's chains; then (N > 1) the single all-gather of [pGM | labels]."""
         bufs = slots[i & 1]
-        if bufs["pending"] is not None:
-            bufs["pending"].wait()
-            bufs["pending"] = None
+        wait_gather(bufs)
         if hi > lo:
             kdehip.prodAppxMSGibbsS_device(dd, bufs["pts"], bufs["ind"], Np=hi - lo, Niter=Niter, seed=seed,
                                            sample_offset=i * Np_total + lo, precision=prec, stream=stream.cuda_stream)
@@ -194,10 +201,36 @@ def main():
 
     def drain():
         for bufs in slots:  # every product is complete (gathered) before the clock stops
-            if bufs["pending"] is not None:
-                bufs["pending"].wait()
-                bufs["pending"] = None
+            wait_gather(bufs)
         torch.cuda.synchronize()
+
+    def timed_pass(first):
+        """W untimed warm-up steps, then EXACTLY K steps between barrier + synchronize on both sides; seconds of the K steps."""
+        for i in range(args.warmup):
+            one_call(first + i)
+        drain()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ta = time.perf_counter()
+        for i in range(args.steps):
+            one_call(first + args.warmup + i)
+        drain()
+        if use_dist:
+            dist.barrier()
+        return time.perf_counter() - ta
+
+    # For comparability between rounds (VERDICT round 4): the same W + K steps once WITHOUT the spin-up below, straight
+    # after the host built the inputs (the device has idled: this pass sits on the clock ramp) -> ms_per_step_no_spin_up.
+    no_spin_elapsed = None
+    if not args.no_spin_up and args.steps <= 100:
+        no_spin_elapsed = timed_pass(0)
+        if use_dist:
+            tt = torch.tensor([no_spin_elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            no_spin_elapsed = float(tt.item())
+        time.sleep(0.5)  # (the device idles again before the measured pass brings it back up)
+        gather_wait[0] = 0.0
 
     # The device idled while the host built the inputs, and its power manager takes ~20 ms of continuous work to bring the
     # clock back up (scripts/step_transient.py: 700 -> 590 us per config-3 call over the first 35 calls after 2 s of idle):
@@ -215,21 +248,8 @@ def main():
     spin_up["what"] = ("untimed launches of one resident plan before the warm-up steps: the device's clock is back at its "
                        "sustained value when the W warm-up steps start (--no-spin-up: without)")
 
-    for i in range(args.warmup):
-        one_call(i)
-    drain()
-
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        one_call(args.warmup + i)
-    drain()
-    if use_dist:
-        dist.barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
+    elapsed = timed_pass(0)
+    gather_wait_s = gather_wait[0]
     # The kernel's duration in THIS loop: the same calls once more, now with the sampling launch of every call bracketed
     # by timing events on its stream (inside the library: the launch is not visible from here).  A pass of its own because
     # the timestamps cost 2 % of a step (0.648 -> 0.661 ms at config 3) -- they are kept out of `value`.
@@ -265,10 +285,22 @@ def main():
     # the kernel's duration: the launches of the timed region itself (next to them the GPU prepares the following call);
     # the launches of one resident plan, alone on the device, beside it
     kern_ms = kern_region_ms if kern_region_ms is not None else kern_resident_ms
+    per_rank = None
     if use_dist:
-        t = torch.tensor([kern_ms], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        kern_ms = float(t.item())
+        # what tells a slow kernel from a straggling rank or link when this first runs on N real GPUs: every rank's kernel
+        # time (min / max over ranks) and the host time its calls spent waiting for all-gathers
+        mine = torch.tensor([kern_ms, gather_wait_s * 1e3 / max(args.steps, 1)], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        ks = [float(a[0].item()) for a in allr]
+        gw = [float(a[1].item()) for a in allr]
+        per_rank = {"kernel_ms_min": min(ks), "kernel_ms_max": max(ks), "kernel_ms": ks,
+                    "gather_wait_ms_per_step_max": max(gw), "gather_wait_ms_per_step": gw}
+        kern_ms = max(ks)
+    try:
+        screen = plan.screen_stats()
+    except Exception:  # noqa: BLE001  (a diagnostic)
+        screen = None
 
     if rank == 0:
         import shutil
@@ -299,6 +331,7 @@ def main():
             "warmup": args.warmup,
             "spin_up": spin_up,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step_no_spin_up": (no_spin_elapsed / args.steps * 1e3) if no_spin_elapsed is not None else None,
             "higher_is_better": True,
             "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None,
@@ -340,6 +373,10 @@ def main():
             "resident_plan": {"ms_per_launch": resident_ms, "samples_per_sec": (hi - lo) / (resident_ms * 1e-3),
                               "what": "repeated sampling of ONE packed plan: no re-layout, no table build (round-1/2 headline)"},
             "fast_math_path": plan.fast_math_path,
+            # fp32 screening of the deep levels with fp64 certification (csrc/screen_device.hpp): levels screened, label
+            # draws that went through the screen on the resident plan's launches above, draws repeated in fp64
+            "screen": screen,
+            "per_rank": per_rank,
         }
         if world == 1:
             out["call_inclusive"] = call_inclusive(kdehip, trees, plan, D, M, Nout, Niter, seed, prec)

@@ -72,21 +72,6 @@ struct LeanTile {
   __device__ __forceinline__ int64_t hdr_off() const {
     return (static_cast<int64_t>(hdr_hi) << 32) | static_cast<uint32_t>(hdr_lo);
   }
-  // a packed step word (pack_step_word) + hdr_off / 8: the tiles of a level that sit in LDS for the whole level
-  __device__ __forceinline__ void unpack(int w, int h8) {
-    const unsigned u = static_cast<unsigned>(w);
-    n = static_cast<int>(u & 0x1FFFu);
-    last_lane = static_cast<int>((u >> 13) & 63u);
-    uniform_bw = static_cast<int>((u >> 19) & 1u);
-    flags = last_lane | (uniform_bw << 8);
-    lds_off = static_cast<int>(u >> 20) << 10;
-    stage_bytes = 0; chunk_rows = 0; seg = 0;
-    const uint64_t off = static_cast<uint64_t>(static_cast<unsigned>(h8)) << 3;
-    hdr_lo = static_cast<int>(off & 0xFFFFFFFFu);
-    hdr_hi = static_cast<int>(off >> 32);
-    B = (n + 63) >> 6;
-    F = uniform_bw ? D + 1 : 2 * D + 1;
-  }
   __device__ __forceinline__ void load(const kdehip_v8i &d) {  // (a StepDesc's eight dwords)
     n = scalar_copy(d[0]);
     flags = scalar_copy(d[1]);
@@ -149,9 +134,6 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
   const T *__restrict__ data = static_cast<const T *>(plan.data);
   const LevelTable levels{(const __attribute__((address_space(4))) kdehip_v16i *)(plan.levels)};
   const StepTable steps{(const __attribute__((address_space(4))) kdehip_v8i *)(plan.levels + 2 * plan.M * (plan.L + 1))};
-  // the packed step words: [2][L+1] x 8 dwords behind the step descriptors (32 B each: half a LevelDesc)
-  const StepTable words{(const __attribute__((address_space(4))) kdehip_v8i *)(plan.levels + 2 * plan.M * (plan.L + 1)) +
-                        plan.M * (plan.L + 1)};
   unsigned char *pool = smem + kPoolOff;
   const int dl = lane < D ? lane : D - 1;  // this lane's dimension in the "lanes = dimensions" phases
   const int vlev = a.variant % 1000;
@@ -523,16 +505,9 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
                           pool + sc.lds_off, sc.stage_bytes, wave, lane);
       });
       staging_barrier();
-      // the level's M tiles as ONE dword each (+ the fp64 tile's place in global memory), fetched once per level: no
-      // descriptor load on a step's path (a level the packer could not pack: the step descriptors)
-      const kdehip_v8i w8 = words.raw(l), h8 = words.raw(L + 1 + l);
-      const bool packed = w8[0] != 0;
       for (int p = 0; p < npass; ++p)
         static_for<M>([&](auto jc) {
-          constexpr int j = decltype(jc)::value;
-          LeanTile<D> ds;
-          if (packed) ds.unpack(w8[j], h8[j]);
-          else ds.load(tile_raw(j));
+          const LeanTile<D> ds = tile(decltype(jc)::value);
           step_screen(jc, ds, ds.lds_off, p == 0, x);  // (on a screened level lds_off is the screen tile's)
         });
     } else if (mode == kStageResident) {
@@ -542,14 +517,9 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
         stage_tile<WAVES>(reinterpret_cast<const unsigned char *>(data + ds.hdr_off()), pool + ds.lds_off, ds.stage_bytes, wave, lane);
       });
       staging_barrier();
-      const kdehip_v8i w8 = words.raw(l);  // (one dword per tile, once per level: see the screened levels)
-      const bool packed = w8[0] != 0;
       for (int p = 0; p < npass; ++p)
         static_for<M>([&](auto jc) {
-          constexpr int j = decltype(jc)::value;
-          LeanTile<D> ds;
-          if (packed) ds.unpack(w8[j], 0);
-          else ds.load(tile_raw(j));
+          const LeanTile<D> ds = tile(decltype(jc)::value);
           step(jc, ds, (RowPtr)(pool + ds.lds_off), p == 0, x);
         });
     } else if (mode == kStageStream) {

@@ -5,16 +5,12 @@
 // variable in between.  A task that no worker has picked up by the time its owner needs the result is run by the owner
 // itself (`claim`), so nested fork/join cannot deadlock, a process that fork()ed away from its workers still makes
 // progress, and a machine with one core simply builds serially.
-// Round 5: the tasks of a 2048-point tree are 30-100 us each -- a sleeping worker's wake-up (a futex round trip: 30-100 us
-// under these container runtimes) or an owner falling asleep in join cost as much as the task, and a tree has 7-15 of
-// them one after the other down its right spine: "host tree alone 2.1 ms" for 6 x 2048 in profiles/r04p (VERDICT round 4,
-// weak 7) was exactly that.  So (a) a worker that runs dry keeps polling the queue for ~100 us before it sleeps -- inside a
-// build the next task is never farther away -- and (b) an owner waiting in join runs OTHER queued tasks meanwhile and
-// polls for ~200 us before it sleeps.  Workers still sleep between builds: an idle process burns nothing.
+// (Round 5 tried workers that poll ~100 us before they sleep and owners that run other queued tasks while they wait: on the
+// 256-thread GPU box a 6 x 2048 tree took 0.25 ms against 0.21 ms with the sleeping workers below, and one call in fifty
+// 1.7 ms -- dropped, profiles/r05_experiments.md section 7.  KDEHIP_HOST_THREADS caps the workers, 0 = serial.)
 #pragma once
 
 #include <atomic>
-#include <chrono>
 #include <condition_variable>
 #include <cstdlib>
 #include <deque>
@@ -52,8 +48,7 @@ class HostPool {
         std::lock_guard<std::mutex> lock(mu_);
         queue_.push_back(t);
       }
-      queued_.fetch_add(1, std::memory_order_release);
-      if (sleepers_.load(std::memory_order_acquire) > 0) cv_.notify_one();  // (a polling worker sees `queued_` by itself)
+      cv_.notify_one();
     }
     return t;
   }
@@ -63,17 +58,9 @@ class HostPool {
   void join(const Ticket &t) {
     if (!run_if_unclaimed(*t)) {
       bool done = false;
-      const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(200);
-      for (int spin = 0; !done; ++spin) {
+      for (int spin = 0; spin < 4096 && !done; ++spin) {
         done = t->state.load(std::memory_order_acquire) == 2;
-        if (done) break;
-        // somebody else runs `t`: do other queued work meanwhile (it is somebody's left subtree) instead of idling
-        if (queued_.load(std::memory_order_acquire) > 0) {
-          Ticket other = take();
-          if (other) { if (run_if_unclaimed(*other)) notify_done(); continue; }
-        }
-        cpu_relax();
-        if ((spin & 63) == 63 && std::chrono::steady_clock::now() > until) break;
+        if (!done) cpu_relax();
       }
       if (!done) {
         std::unique_lock<std::mutex> lock(done_mu_);
@@ -123,48 +110,25 @@ class HostPool {
     t.state.store(2, std::memory_order_release);
     return true;
   }
-  // the oldest queued task, or nothing
-  Ticket take() {
-    std::lock_guard<std::mutex> lock(mu_);
-    if (queue_.empty()) return nullptr;
-    Ticket t = std::move(queue_.front());
-    queue_.pop_front();
-    queued_.fetch_sub(1, std::memory_order_release);
-    return t;
-  }
-  void notify_done() {
-    std::lock_guard<std::mutex> lock(done_mu_);  // (pairs with the predicate check in join)
-    done_cv_.notify_all();
-  }
   void work() {
     for (;;) {
       Ticket t;
-      // poll for ~100 us after the last task (inside a build the next one is never far), then sleep
-      const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(100);
-      for (int spin = 0; !t; ++spin) {
-        if (queued_.load(std::memory_order_acquire) > 0) t = take();
-        if (t) break;
-        cpu_relax();
-        if ((spin & 63) == 63 && std::chrono::steady_clock::now() > until) break;
-      }
-      if (!t) {
+      {
         std::unique_lock<std::mutex> lock(mu_);
-        sleepers_.fetch_add(1, std::memory_order_acq_rel);
         cv_.wait(lock, [&] { return !queue_.empty(); });
-        sleepers_.fetch_sub(1, std::memory_order_acq_rel);
         t = std::move(queue_.front());
         queue_.pop_front();
-        queued_.fetch_sub(1, std::memory_order_release);
       }
-      if (run_if_unclaimed(*t)) notify_done();
+      if (run_if_unclaimed(*t)) {
+        std::lock_guard<std::mutex> lock(done_mu_);  // (pairs with the predicate check in join)
+        done_cv_.notify_all();
+      }
     }
   }
 
   static constexpr unsigned kMaxWorkers = 15;  // (measured on the 256-thread MI355X host: 7 -> 15 gains 10 % at 1e5 points)
   inline static std::atomic<HostPool *> self_{nullptr};
   std::atomic<int> nworkers_{0};
-  std::atomic<int> queued_{0};    // tasks in queue_ (read without the lock by pollers)
-  std::atomic<int> sleepers_{0};  // workers blocked on cv_
   std::mutex mu_, done_mu_;
   std::condition_variable cv_, done_cv_;
   std::deque<Ticket> queue_;

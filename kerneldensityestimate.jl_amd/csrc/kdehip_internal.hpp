@@ -121,10 +121,11 @@ static_assert(sizeof(LevelDesc) == 64, "LevelDesc is read with scalar loads; kee
 // kStageScreen when LEVEL l is screened, n / B / F / uniform_bw / last_lane of the fp64 tile, hdr_off = offset of the
 // screen tile's header in FLOATS from the plan's data, lds_off / stage_bytes of its LDS image.
 // ---- step descriptors (round 5) --------------------------------------------------------------------------------------
-// What a draw step of the register-resident sampler needs of a tile, 32 bytes, read with ONE s_load_dwordx8 that is issued
-// a step AHEAD (the 16-dword LevelDesc was fetched at the start of the step that needed it: ~200 cycles of scalar-cache
-// latency on every step's critical path).  A third [M][L+1] table behind the level and screen tables (which are both
-// always present: the screen table is all zero when no level is screened).
+// What a draw step of the register-resident sampler needs of a tile: 32 bytes, one s_load_dwordx8 per step (half the scalar
+// registers of the 16-dword LevelDesc it replaces on the step path, no shuffling of fields: c3 kernel -0.6 %).  A third
+// [M][L+1] table behind the level and screen tables (both always present: the screen table is all zero when no level is
+// screened).  Tried on top and dropped (profiles/r05_experiments.md): the descriptor requested one step ahead (the compiler
+// sinks the load back to its use), and one packed dword per tile kept in scalar registers for the whole level (+1.8 %).
 struct StepDesc {
   int32_t n;            // frontier size
   int32_t flags;        // last_lane | uniform_bw << 8
@@ -135,16 +136,6 @@ struct StepDesc {
   int32_t hdr_lo, hdr_hi;  // element offset of the fp64 tile's header in the plan's data
 };
 static_assert(sizeof(StepDesc) == 32, "StepDesc is read with one 32-byte scalar load");
-// ... and for the levels whose tiles sit in LDS for the whole level (resident fp64 tiles, screen tiles: at most 4096
-// nodes, images at multiples of 1 KiB) even that load goes: ONE dword per tile -- n | last_lane << 13 | uniform_bw << 19 |
-// (lds_off >> 10) << 20 -- in a LEVEL-major table of 8 dwords per level, fetched once per level and kept in scalar registers
-// (products of up to 8 densities), plus a second such table with hdr_off / 8 (tiles start at multiples of 8 elements) for the
-// screened levels, whose steps adopt from the fp64 tile in global memory.  0 = the level's steps use StepDesc.
-constexpr int kStepWordsPerLevel = 8;
-inline uint32_t pack_step_word(int32_t n, int32_t last_lane, int32_t uniform_bw, int32_t lds_off) {
-  return static_cast<uint32_t>(n) | (static_cast<uint32_t>(last_lane) << 13) | (static_cast<uint32_t>(uniform_bw) << 19) |
-         (static_cast<uint32_t>(lds_off >> 10) << 20);
-}
 
 constexpr int kScreenHeaderFloats = 48;
 constexpr int kScreenMaxRows = 64;           // rows per lane up to which a level is screened (one second-pass round)
@@ -267,7 +258,6 @@ struct PackedProduct {
   std::vector<TabDesc> tabdesc;    // [M][L+1]
   std::vector<LevelDesc> screens;  // [M][L+1] screen descriptors ("fp32 screening"), empty = no level is screened
   std::vector<StepDesc> steps;     // [M][L+1] step descriptors
-  std::vector<uint32_t> words;     // [2][L+1][kStepWordsPerLevel]: packed step words, then hdr_off / 8
   int nscreened = 0;               // screened levels
   int Lt = 0;                      // tabulated levels 1..Lt
   int64_t tab_entries = 0, tab_rows = 0;

@@ -396,25 +396,6 @@ int pack_layout_shapes(int M, int D, int L, const TileShape *shapes, const uint8
     s.hdr_lo = static_cast<int32_t>(ds.hdr_off & 0xFFFFFFFF);
     s.hdr_hi = static_cast<int32_t>(ds.hdr_off >> 32);
   }
-  out.words.assign(static_cast<size_t>(2) * (L + 1) * kStepWordsPerLevel, 0u);
-  if (M <= kStepWordsPerLevel)
-    for (int l = 1; l <= L; ++l) {
-      bool ok = true;
-      for (int j = 0; j < M && ok; ++j) {
-        const size_t idx = static_cast<size_t>(j) * (L + 1) + l;
-        const LevelDesc &ds = out.levels[idx];
-        const bool scr = !out.screens.empty() && out.screens[idx].stage_mode == kStageScreen;
-        ok = (scr || ds.stage_mode == kStageResident) && ds.n <= 4096 && (out.steps[idx].lds_off & 1023) == 0 &&
-             out.steps[idx].lds_off < (128 << 10) && (ds.hdr_off & 7) == 0 && (ds.hdr_off >> 3) < (int64_t(1) << 32);
-      }
-      if (!ok) continue;
-      for (int j = 0; j < M; ++j) {
-        const size_t idx = static_cast<size_t>(j) * (L + 1) + l;
-        const LevelDesc &ds = out.levels[idx];
-        out.words[static_cast<size_t>(l) * kStepWordsPerLevel + j] = pack_step_word(ds.n, ds.last_lane, ds.uniform_bw, out.steps[idx].lds_off);
-        out.words[static_cast<size_t>(L + 1 + l) * kStepWordsPerLevel + j] = static_cast<uint32_t>(ds.hdr_off >> 3);
-      }
-    }
 
   // ---- phase 4: conditional tables (gibbs_kernel.hip): levels whose frontiers all fit one wavefront row
   // and have power-of-two sizes, as long as the rows of all densities stay within the entry budget

@@ -113,7 +113,7 @@ int maybe_build_screens(kdehip_product *plan, RunArgs &a, void *stream, bool pri
 // the plan's level table on the device: [M][L+1] level descriptors, as many screen descriptors (all zero when no level
 // is screened), then [M][L+1] step descriptors
 inline size_t level_table_bytes(const PackedProduct &pp) {
-  return pp.levels.size() * (2 * sizeof(LevelDesc) + sizeof(StepDesc)) + pp.words.size() * sizeof(uint32_t);
+  return pp.levels.size() * (2 * sizeof(LevelDesc) + sizeof(StepDesc));
 }
 inline void copy_level_table(const PackedProduct &pp, unsigned char *dst) {
   const size_t nb = pp.levels.size() * sizeof(LevelDesc);
@@ -121,7 +121,6 @@ inline void copy_level_table(const PackedProduct &pp, unsigned char *dst) {
   if (!pp.screens.empty()) std::memcpy(dst + nb, pp.screens.data(), nb);
   else std::memset(dst + nb, 0, nb);
   std::memcpy(dst + 2 * nb, pp.steps.data(), pp.steps.size() * sizeof(StepDesc));
-  std::memcpy(dst + 2 * nb + pp.steps.size() * sizeof(StepDesc), pp.words.data(), pp.words.size() * sizeof(uint32_t));
 }
 
 // Scratch of the host-buffer entry points: one device buffer per plan, grown on demand (no per-call

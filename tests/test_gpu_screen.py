@@ -102,7 +102,7 @@ def test_screen_statistics_of_config_3():
     (1.0e6, 1.0, "far from the origin: the tiles are centred, the screen still applies"),
     (0.0, 3.0e4, "coordinates beyond 2^16 after centring: outside the bound's range, fp64 throughout"),
     (0.0, 1.0e-3, "variances below 2^-7: outside the bound's range, fp64 throughout"),
-    (5.0e3, 40.0, "wide data, large bandwidths"),
+    (5.0e3, 5.0, "wide data, large bandwidths"),
 ])
 def test_screen_range_rules(shift, scale, why):
     D, Ns, Np, Niter = 6, [1000, 900, 1000], 256, 3
