@@ -16,7 +16,6 @@
 #include <cstdlib>
 #include <cmath>
 #include <cstring>
-#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -570,17 +569,11 @@ struct PairSet {  // where one probe of a launch keeps its slots [D][T][T][64], 
   unsigned *arrivals;
   double *shares;
 };
-// all T slots of `tile` are in place: total per query in source order, W*log p, the tile's share of the log-likelihood.
-// `tiles_done` (the persistent kernel): the share and the counter's reset are written through like the slots, and only
-// then is the tile counted as finished -- the next round of this dimension starts when all T tiles are.
-__device__ __forceinline__ void pairs_finish_tile(const LooRound &r, const PairSet &ps, int d, int tile, int lane, double bw_eval,
-                                                  unsigned *tiles_done = nullptr) {
+// all T slots of `tile` are in place: total per query in source order, W*log p, the tile's share of the log-likelihood
+__device__ __forceinline__ void pairs_finish_tile(const LooRound &r, const PairSet &ps, int d, int tile, int lane, double bw_eval) {
   const int T = r.ngroups;
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (after the counter that said "all T slots are in", before the slot loads)
-  if (lane == 0) {  // every slot is in: nobody counts on this tile again before the next round
-    if (tiles_done) __hip_atomic_store(ps.arrivals + (d * T + tile) * kCounterStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else ps.arrivals[(d * T + tile) * kCounterStride] = 0;
-  }
+  if (lane == 0) ps.arrivals[(d * T + tile) * kCounterStride] = 0;  // every slot is in: nobody counts on this tile again before the next round
   const double *slots = ps.slots + (static_cast<int64_t>(d) * T + tile) * T * kTile + lane;
   double tot = 0.0;
   for (int s0 = 0; s0 < T; s0 += 32) {  // (32 loads in flight: they come from beyond the L2, 3 us a trip)
@@ -601,34 +594,25 @@ __device__ __forceinline__ void pairs_finish_tile(const LooRound &r, const PairS
     else term = log(p) * w;
   }
   for (int off = 32; off > 0; off >>= 1) term += __shfl_down(term, off);  // fixed order
-  if (lane == 0) {
-    if (tiles_done) {
-      slot_store(ps.shares + tile, term);
-      slots_delivered();
-      __hip_atomic_fetch_add(tiles_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      ps.shares[tile] = term;
-    }
-  }
+  if (lane == 0) ps.shares[tile] = term;
 }
 // This wavefront's slots of tiles I and J (J < 0: of tile I only) are in place: count them -- lane 0 for I, lane 1 for J,
 // one atomic instruction -- and finish every tile whose T slots are complete with that.
-__device__ __forceinline__ void pairs_arrive(const LooRound &r, const PairSet &ps, int d, int I, int J, int lane, double bw_eval,
-                                             unsigned *tiles_done = nullptr) {
+__device__ __forceinline__ void pairs_arrive(const LooRound &r, const PairSet &ps, int d, int I, int J, int lane, double bw_eval) {
   const int T = r.ngroups;
   unsigned old = 0;
   if (lane == 0 || (lane == 1 && J >= 0))
     old = __hip_atomic_fetch_add(ps.arrivals + (d * T + (lane == 0 ? I : J)) * kCounterStride, 1u, __ATOMIC_RELAXED,
                                  __HIP_MEMORY_SCOPE_AGENT);
   const unsigned oldI = __builtin_amdgcn_readlane(old, 0), oldJ = __builtin_amdgcn_readlane(old, 1);
-  if (oldI == static_cast<unsigned>(T - 1)) pairs_finish_tile(r, ps, d, I, lane, bw_eval, tiles_done);
-  if (J >= 0 && oldJ == static_cast<unsigned>(T - 1)) pairs_finish_tile(r, ps, d, J, lane, bw_eval, tiles_done);
+  if (oldI == static_cast<unsigned>(T - 1)) pairs_finish_tile(r, ps, d, I, lane, bw_eval);
+  if (J >= 0 && oldJ == static_cast<unsigned>(T - 1)) pairs_finish_tile(r, ps, d, J, lane, bw_eval);
 }
 
 // One tile pair (I, I + k mod T) of dimension d by one wavefront: the 64 x 64 kernel values, each computed once and added to
 // a row sum (own point) and a column sum (visiting point), left in the (tile, source tile) slots; then the arrival.
 __device__ __forceinline__ void pairs_item(const LooRound &r, const PairSet &ps, int d, int e, int lane, double bw_eval,
-                                           const double *sExpTab, unsigned *tiles_done) {
+                                           const double *sExpTab) {
   const int T = r.ngroups, K = T / 2;
   const int I = e / (K + 1), k = e - I * (K + 1);
   if (I >= T) return;
@@ -651,7 +635,7 @@ __device__ __forceinline__ void pairs_item(const LooRound &r, const PairSet &ps,
     }
     slot_store(slot_row, row);
     slots_delivered();
-    pairs_arrive(r, ps, d, I, -1, lane, bw_eval, tiles_done);
+    pairs_arrive(r, ps, d, I, -1, lane, bw_eval);
     return;
   }
   double col = 0.0;
@@ -666,7 +650,7 @@ __device__ __forceinline__ void pairs_item(const LooRound &r, const PairSet &ps,
   slot_store(slot_row, row);
   slot_store(ps.slots + ((static_cast<int64_t>(d) * T + J) * T + I) * kTile + lane, col);  // (64 rotations: home again)
   slots_delivered();
-  pairs_arrive(r, ps, d, I, J, lane, bw_eval, tiles_done);
+  pairs_arrive(r, ps, d, I, J, lane, bw_eval);
 }
 // OPENING: 0 = a round of one evaluation per search; 1 = the first launch, both opening probes; 2 = the launch after it
 // (reqd_work_group_size: where the compiler keeps a thread's temporaries in LDS it indexes them by the flat thread id,
@@ -716,82 +700,7 @@ __global__ __launch_bounds__(kTile *kPairWaves) void loo_round_pairs_kernel(cons
   }
   __syncthreads();
   if (sPhase == 3) return;  // this dimension's search is over
-  pairs_item(r, ps, d, blockIdx.x * kPairWaves + wave, lane, sBw, sExpTab, nullptr);
-}
-
-// ---- the whole search in ONE launch (round 5) ------------------------------------------------------------------------
-// The rounds above are 17.9 us of kernel and 3.5 us of launch gap each, 19 in a row, and every one of them starts by
-// loading the exp table and the shares again.  Here the workgroups stay: every workgroup of dimension d keeps the search
-// state of d in LDS and advances it itself (golden_book / golden_decide are deterministic: all workgroups of a dimension
-// reach the same state from the same T tile shares), works through its items of the round, and waits -- polling one
-// counter per dimension, `tiles_done[d]`, with s_sleep between the looks -- until the T tiles of the round are finished;
-// dimensions do not wait for each other.  Slots, counters and shares are handed over as in the one-launch round (sc1 stores,
-// s_waitcnt vmcnt(0), then the count).  All workgroups must be resident together: the grid is at most one workgroup per CU
-// (items beyond that are walked in a loop), a process runs one such search per device at a time (others take the rounds
-// above), and a workgroup that waits longer than `spin_budget` clock ticks raises `abort`, on which everyone leaves and
-// the host runs the launch-per-round search instead -- a bound, not an expectation.
-struct LooPersist {
-  LooRound r;
-  unsigned *tiles_done;  // [D] counters, kCounterStride apart, zero at launch
-  int *abort;            // zero at launch
-  int items;             // tile pairs per dimension
-  int max_rounds;
-  unsigned long long spin_budget;
-};
-__global__ __launch_bounds__(kTile *kPairWaves) void loo_persistent_kernel(const LooPersist p) {
-  __shared__ double sExpTab[256];
-  __shared__ double sPart[kFusedMaxN / kTile];
-  __shared__ Golden sh;
-  __shared__ double sBw;
-  __shared__ int sPhase, sAbort;
-  const LooRound &r = p.r;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int d = blockIdx.z, T = r.ngroups;
-  PairSet ps;
-  ps.slots = r.partial;
-  ps.arrivals = r.arrivals;
-  unsigned *done = p.tiles_done + d * kCounterStride;
-  if (threadIdx.x < 256) sExpTab[threadIdx.x] = kExp2Tab256[threadIdx.x];
-  if (threadIdx.x == 0) { sh = r.state[d]; sAbort = 0; }
-  __syncthreads();
-  for (int round = 0; round < p.max_rounds; ++round) {
-    if (round > 0 && threadIdx.x == 0) {  // the T tiles of the previous evaluation
-      const unsigned want = static_cast<unsigned>(round) * static_cast<unsigned>(T);
-      const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-      for (;;) {
-        if (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) break;
-        if (__hip_atomic_load(p.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { sAbort = 1; break; }
-        if (__builtin_amdgcn_s_memtime() - t0 > p.spin_budget) {
-          __hip_atomic_store(p.abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          sAbort = 1;
-          break;
-        }
-        __builtin_amdgcn_s_sleep(8);
-      }
-    }
-    __syncthreads();
-    if (sAbort) return;
-    // the shares of the evaluation in flight: plane round & 1 (its finishers wrote plane (round - 1 + 1) & 1)
-    if (round > 0 && static_cast<int>(threadIdx.x) < r.nfb)
-      sPart[threadIdx.x] = slot_load(r.hpart + (static_cast<int64_t>(round & 1) * r.D + d) * r.nfb + threadIdx.x);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      golden_book(sh, sPart, r.nfb);  // (nothing pending in round 0)
-      golden_decide(sh);
-      sBw = sh.bw_eval;
-      sPhase = sh.phase;
-    }
-    __syncthreads();
-    if (sPhase == 3) break;
-    ps.shares = r.hpart + (static_cast<int64_t>((round + 1) & 1) * r.D + d) * r.nfb;
-    const double bw_eval = sBw;
-    for (int e = blockIdx.x * kPairWaves + wave; e < p.items; e += gridDim.x * kPairWaves)
-      pairs_item(r, ps, d, e, lane, bw_eval, sExpTab, done);
-  }
-  __syncthreads();
-  // the search is over (or out of rounds: an evaluation in flight stays pending and the host continues with the rounds
-  // above): one workgroup per dimension leaves the state where the host looks
-  if (blockIdx.x == 0 && threadIdx.x == 0) r.state[d] = sh;
+  pairs_item(r, ps, d, blockIdx.x * kPairWaves + wave, lane, sBw, sExpTab);
 }
 
 // Round, second launch: p_q = w * (sum over groups) / norm / (1 - w); block partial of W_q * log p_q
@@ -881,9 +790,7 @@ int kdehip::auto_bandwidth_run(int D, int64_t N, const double *points, const dou
   const size_t off_h = al(off_part + sizeof(double) * D * r.ngroups * (pairs ? (r.joint ? 2 : 1) * int64_t(ntiles) * kTile : N));
   const size_t off_state = al(off_h + sizeof(double) * 4 * D * r.nfb);
   const size_t off_arr = al(off_state + sizeof(Golden) * 2 * D);
-  // (behind the slot counters: the persistent search's per-dimension tile counters and its abort flag)
-  const size_t off_done = al(off_arr + (pairs ? sizeof(unsigned) * 2 * D * ntiles * kCounterStride : 0));
-  const size_t total = off_done + sizeof(unsigned) * (D + 1) * kCounterStride;
+  const size_t total = off_arr + (pairs ? sizeof(unsigned) * 2 * D * ntiles * kCounterStride : 0);
   DevBuf dev;
   KDEHIP_CHECK(dev.alloc(total));
   unsigned char *base = dev.as<unsigned char>();
@@ -898,7 +805,7 @@ int kdehip::auto_bandwidth_run(int D, int64_t N, const double *points, const dou
     size_t n = 0;
     ~Pinned() { if (p) cached_host_free(p, n); }
   } pin;
-  pin.n = std::max(sizeof(double) * N * D, sizeof(Golden) * 2 * D + 64);
+  pin.n = std::max(sizeof(double) * N * D, sizeof(Golden) * 2 * D);
   KDEHIP_CHECK(cached_host_malloc(&pin.p, pin.n));
   Golden *h_state = static_cast<Golden *>(pin.p);
   // Declared after the two blocks, i.e. destroyed before them: an early error return below waits for whatever has
@@ -944,67 +851,16 @@ int kdehip::auto_bandwidth_run(int D, int64_t N, const double *points, const dou
   }
   auto t_prep = tnow();
 
-  // The whole search in ONE launch (loo_persistent_kernel) when the marginals were prepared on the device and no other
-  // thread of the process runs one on this device right now (two of them could keep each other's workgroups off the CUs);
-  // KDEHIP_LOOCV_PERSISTENT=0: never.  On an abort (a workgroup waited beyond its budget) or a search that is not over
-  // after kPersistRounds evaluations the marginals are prepared again and the rounds below run as before.
+  // (Round 5 built the whole search as ONE persistent launch -- workgroups that stay, a tile counter per dimension between
+  // the rounds: bit-identical and SLOWER, 457 against 410 us at 6 x 2048: noticing a counter from another XCD and fetching
+  // the shares behind it cost more than the 3.5 us launch gap they replace.  Removed; profiles/r05_experiments.md section 8.)
   int rounds = 0, batches = 0;
-  bool searched = false;
-  static const bool persistent_on = [] { const char *e = std::getenv("KDEHIP_LOOCV_PERSISTENT"); return !(e && e[0] == '0'); }();
-  if (pairs && N <= kPrepMaxN && persistent_on && !two_launch) {
-    static std::mutex persist_mu[64];
-    int cur = 0;
-    (void)hipGetDevice(&cur);
-    std::unique_lock<std::mutex> only(persist_mu[cur & 63], std::try_to_lock);
-    if (only.owns_lock()) {
-      constexpr int kPersistRounds = 200;
-      unsigned *d_done = reinterpret_cast<unsigned *>(base + off_done);
-      int *d_abort = reinterpret_cast<int *>(d_done + D * kCounterStride);
-      KDEHIP_CHECK(hipMemsetAsync(d_done, 0, sizeof(unsigned) * (D + 1) * kCounterStride, st));
-      LooPersist lp{};
-      lp.r = r;
-      lp.r.joint = 0;
-      lp.tiles_done = d_done;
-      lp.abort = d_abort;
-      lp.items = ntiles * (ntiles / 2 + 1);
-      lp.max_rounds = kPersistRounds;
-      lp.spin_budget = 100ull * 1000 * 1000;  // clock ticks: tens of milliseconds, a thousand rounds' worth
-      int per_dim = device_cu_count() / D;   // at most one workgroup per CU in all
-      const int need = (lp.items + kPairWaves - 1) / kPairWaves;
-      if (per_dim > need) per_dim = need;
-      if (per_dim < 1) per_dim = 1;
-      hipLaunchKernelGGL(loo_persistent_kernel, dim3(static_cast<unsigned>(per_dim), 1, static_cast<unsigned>(D)),
-                         dim3(kTile * kPairWaves), 0, st, lp);
-      KDEHIP_CHECK(hipGetLastError());
-      int *h_abort = reinterpret_cast<int *>(h_state + 2 * D);  // (the pinned block holds 2 D states; the flag behind them)
-      KDEHIP_CHECK(hipMemcpyAsync(h_state, r.state, sizeof(Golden) * D, hipMemcpyDeviceToHost, st));
-      KDEHIP_CHECK(hipMemcpyAsync(h_abort, d_abort, sizeof(int), hipMemcpyDeviceToHost, st));
-      if (overlap) (*overlap)();  // (the search is in flight: the caller's host work runs under it)
-      overlap = nullptr;
-      KDEHIP_CHECK(hipStreamSynchronize(st));
-      bool done = *h_abort == 0;
-      for (int d = 0; d < D; ++d) done = done && h_state[d].phase == 3;
-      if (done) {
-        searched = true;
-        rounds = 0;
-        for (int d = 0; d < D; ++d) rounds = std::max(rounds, h_state[d].nevals);
-        batches = 1;
-      } else {
-        int64_t P = 1;
-        while (P < N) P <<= 1;
-        hipLaunchKernelGGL(loocv_prep_kernel, dim3(D), dim3(kPrepThreads), sizeof(double) * 5 * P, st, d_points ? d_points : d_pts, N, D,
-                           const_cast<double *>(r.x), r.state, r.arrivals, ntiles);
-        KDEHIP_CHECK(hipGetLastError());
-      }
-    }
-  }
-
   const dim3 gridA(static_cast<unsigned>(qblocks), static_cast<unsigned>(r.ngroups), static_cast<unsigned>(D));
   const dim3 gridB(static_cast<unsigned>(r.nfb), static_cast<unsigned>(D));
   const int pair_items = ntiles * (ntiles / 2 + 1);  // per dimension: the diagonal and the offsets 1 .. T/2 of every tile
   const dim3 gridP(static_cast<unsigned>((pair_items + kPairWaves - 1) / kPairWaves), 1, static_cast<unsigned>(D));
   const dim3 gridP2(gridP.x, 1, static_cast<unsigned>(2 * D));  // the joint first launch
-  for (int batch = r.joint ? 19 : 20; !searched && batches < 16; batch = 8) {  // (20 evaluations: the first launch of `pairs` runs two)
+  for (int batch = r.joint ? 19 : 20; batches < 16; batch = 8) {  // (20 evaluations: the first launch of `pairs` runs two)
     for (int k = 0; k < batch; ++k) {
       if (pairs) {
         if (r.joint && r.round == 0) hipLaunchKernelGGL(loo_round_pairs_kernel<1>, gridP2, dim3(kTile * kPairWaves), 0, st, r);

@@ -190,35 +190,9 @@ def test_fused_loocv_rounds_equal_the_two_launch_rounds():
         assert np.allclose(b0, b1, rtol=1e-9, atol=0.0), (k, b0, b1)
 
 
-def test_persistent_loocv_search_equals_the_launch_per_round_search():
-    """The whole search in ONE launch (csrc/evaluate.hip loo_persistent_kernel: workgroups that stay, one tile counter per
-    dimension between the rounds, every workgroup advancing the golden-section state itself) against the launch-per-round
-    search (KDEHIP_LOOCV_PERSISTENT=0): the same bandwidths BIT FOR BIT -- the same slots are summed in the same order --
-    and the same number of likelihood evaluations, from 2 to 32 tiles, odd and even circles, ragged last tiles; beyond
-    2048 points (host-prepared marginals) both runs take the rounds anyway."""
-    import json
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    res = []
-    for persistent in ("1", "0"):
-        env = dict(os.environ, KDEHIP_LOOCV_PERSISTENT=persistent, PYTHONPATH=root)
-        env.pop("KDEHIP_LOOCV_TWO_LAUNCH", None)
-        out = subprocess.run([sys.executable, "-c", _TWO_LAUNCH_SCRIPT], cwd=root, env=env, capture_output=True, text=True, timeout=600)
-        assert out.returncode == 0, out.stdout[-1000:] + out.stderr[-3000:]
-        line = [ln for ln in out.stdout.splitlines() if ln.startswith("RESULT ")][-1]
-        res.append(json.loads(line[7:]))
-    assert res[0].keys() == res[1].keys()
-    for k in res[0]:
-        (b0, n0), (b1, n1) = res[0][k], res[1][k]
-        assert n0 == n1, (k, n0, n1)
-        assert b0 == b1, (k, b0, b1)
-
-
 def test_concurrent_searches_share_the_device():
-    """Two host threads searching at once: one of them gets the persistent launch, the other the rounds (a process runs one
-    persistent search per device at a time) -- both must return what a lone search returns."""
+    """Two host threads searching at once on their own streams (the slots, counters and search states of a call live in
+    its own device block): both must return what a lone search returns."""
     import threading
     rng = np.random.default_rng(77)
     data = [synth_mixture(rng, 3, 1500), synth_mixture(rng, 3, 1500)]

@@ -136,7 +136,9 @@ def test_screen_through_every_entry_point():
     assert np.array_equal(pts, ref[0]) and np.array_equal(ind, ref[1])
     u, n = kdehip.philox_streams(seed, 0, Np, K, R)
     pts, ind = kdehip.prodAppxMSGibbsS(None, g, None, None, Niter=Niter, Np=Np, randU=u, randN=n)
-    assert np.array_equal(pts, ref[0]) and np.array_equal(ind, ref[1])
+    # (caller streams: the host twin's normals may differ from the device's in the last bit -- libm against the device's
+    # logarithm and sine / cosine -- so the points agree to an ulp, the labels exactly)
+    assert np.array_equal(ind, ref[1]) and np.allclose(pts, ref[0], rtol=0.0, atol=1e-12)
     dd = [kdehip.DeviceDensity(t) for t in g]
     try:
         pts, ind = kdehip.prodAppxMSGibbsS_resident(dd, Np=Np, Niter=Niter, seed=seed)
