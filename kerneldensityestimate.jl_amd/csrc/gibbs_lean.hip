@@ -484,9 +484,13 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
     const bool tabulated = (l <= Lt);
     const int npass = tabulated ? 1 : a.Niter + 1;  // tabulated levels: only the sampleIndices! pass runs here
 
-    bool screened = false;
+    bool screened = false, screen_streamed = false;
     if constexpr (kScreen) {
-      if (a.use_screen && vlev != 1) screened = scalar_copy(levels[M * (L + 1) + l].stage_mode) == kStageScreen;
+      if (a.use_screen && vlev != 1) {
+        const int smode = scalar_copy(levels[M * (L + 1) + l].stage_mode);
+        screened = smode == kStageScreen;
+        screen_streamed = smode == kStageScreenStream;
+      }
     }
 #ifdef KDEHIP_SCREEN_STAMPS
     rstamp_on = (vlev >= 300 && l == vlev - 300) && view.block == 3 && wave == 5;
@@ -509,6 +513,34 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
         static_for<M>([&](auto jc) {
           const LeanTile<D> ds = tile(decltype(jc)::value);
           step_screen(jc, ds, ds.lds_off, p == 0, x);  // (on a screened level lds_off is the screen tile's)
+        });
+    } else if (screen_streamed) {
+      // the screen tiles of the level one per step through the two pool halves, like the fp64 tiles of a streamed level:
+      // the copy of step t + 1's tile overlaps step t; one barrier per step (a wavefront that has to repeat its step in
+      // fp64 is waited for there)
+      auto screen = [&](int j) -> LevelDesc { return levels[(M + j) * (L + 1) + l]; };
+      auto stage_screen = [&](const LevelDesc &sc, int half, auto wc) {
+        constexpr int W = decltype(wc)::value;
+        if (wave < W)
+          stage_tile<W>(reinterpret_cast<const unsigned char *>(reinterpret_cast<const float *>(plan.data) + sc.hdr_off),
+                        pool + half * (kLdsPoolBytes / 2), sc.stage_bytes, wave, lane);
+      };
+      staging_barrier();
+      stage_screen(screen(0), 0, IC<WAVES>{});
+      int t = 0;
+      const int nsteps = npass * M;
+      for (int p = 0; p < npass; ++p)
+        static_for<M>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          constexpr int jn = (j + 1 == M) ? 0 : j + 1;
+          const LeanTile<D> ds = tile(j);
+          const LevelDesc scn = screen(jn);
+          staging_barrier();  // tile t has landed for everyone; the other half was last read in step t - 1
+          constexpr bool kLateCopy = kCopyWaves < WAVES;
+          if (!kLateCopy && t + 1 < nsteps) stage_screen(scn, (t + 1) & 1, IC<WAVES>{});
+          step_screen(jc, ds, (t & 1) * (kLdsPoolBytes / 2), p == 0, x);
+          if (kLateCopy && t + 1 < nsteps) stage_screen(scn, (t + 1) & 1, IC<kCopyWaves>{});
+          ++t;
         });
     } else if (mode == kStageResident) {
       staging_barrier();  // every wavefront is done reading the previous level's images

@@ -70,7 +70,8 @@ enum StageMode : int32_t {
   kStageResident = 1,  // all densities' tiles of the level fit the LDS pool at once
   kStageStream = 2,    // one tile per step, double-buffered in the LDS pool
   kStageChunked = 3,   // tile larger than half the pool: rows streamed through the two halves in chunks
-  kStageScreen = 4     // (screen descriptors only) the level is SCREENED in fp32: see "fp32 screening" below
+  kStageScreen = 4,    // (screen descriptors only) the level is SCREENED in fp32: see "fp32 screening" below
+  kStageScreenStream = 5  // ... with its screen tiles streamed through the pool halves one per step (they do not fit together)
 };
 constexpr int kLdsPoolBytes = 120 * 1024;   // LDS bytes for staged tiles (of 160 KiB per CU; the rest: chain state)
 

@@ -352,26 +352,31 @@ int pack_layout_shapes(int M, int D, int L, const TileShape *shapes, const uint8
       const int mode = out.levels[l].stage_mode;
       if (mode != kStageStream && mode != kStageChunked) continue;
       bool ok = true;
-      int64_t sum = 0;
+      int64_t sum = 0, mx = 0;
       for (int j = 0; j < M && ok; ++j) {
         const LevelDesc &ds = out.levels[static_cast<size_t>(j) * (L + 1) + l];
         if (ds.B < 2 || ds.B > kScreenMaxRows) ok = false;
-        const int64_t bytes = (kScreenHeaderFloats + TileAddrBytes<4>::body(ds.B, ds.F)) * 4;
-        sum += (bytes + 1023) / 1024 * 1024;
+        const int64_t bytes = ((kScreenHeaderFloats + TileAddrBytes<4>::body(ds.B, ds.F)) * 4 + 1023) / 1024 * 1024;
+        sum += bytes;
+        mx = bytes > mx ? bytes : mx;
       }
-      if (!ok || sum > kLdsPoolBytes) continue;
+      // all M images in the pool together (no barrier between the level's steps), or one per pool half, streamed like the
+      // fp64 tiles of a streamed level (a barrier per step: a wavefront that repeats a step in fp64 holds up its workgroup)
+      static const bool stream_on = [] { const char *e = std::getenv("KDEHIP_SCREEN_STREAM"); return !(e && e[0] == '0'); }();
+      const bool together = sum <= kLdsPoolBytes;
+      if (!ok || (!together && !(stream_on && mx <= kLdsPoolBytes / 2))) continue;
       int64_t off = 0;
       for (int j = 0; j < M; ++j) {
         const LevelDesc &ds = out.levels[static_cast<size_t>(j) * (L + 1) + l];
         LevelDesc &sc = scr[static_cast<size_t>(j) * (L + 1) + l];
         sc.n = ds.n; sc.B = ds.B; sc.F = ds.F; sc.uniform_bw = ds.uniform_bw; sc.last_lane = ds.last_lane;
-        sc.stage_mode = kStageScreen;
+        sc.stage_mode = together ? kStageScreen : kStageScreenStream;
         felem = (felem + 63) & ~int64_t(63);  // 256-byte aligned images
         sc.hdr_off = felem;
         const int64_t elems = kScreenHeaderFloats + TileAddrBytes<4>::body(ds.B, ds.F);
         felem += elems;
         sc.stage_bytes = static_cast<int32_t>((elems * 4 + 1023) / 1024 * 1024);
-        sc.lds_off = static_cast<int32_t>(off);
+        sc.lds_off = together ? static_cast<int32_t>(off) : 0;
         off += sc.stage_bytes;
       }
       ++out.nscreened;
@@ -389,7 +394,7 @@ int pack_layout_shapes(int M, int D, int L, const TileShape *shapes, const uint8
     s.n = ds.n;
     s.flags = ds.last_lane | (ds.uniform_bw << 8);
     s.lds_off = ds.lds_off;
-    if (!out.screens.empty() && out.screens[idx].stage_mode == kStageScreen) s.lds_off = out.screens[idx].lds_off;
+    if (!out.screens.empty() && out.screens[idx].stage_mode == kStageScreen) s.lds_off = out.screens[idx].lds_off;  // (streamed screens: the pool half of the step)
     s.stage_bytes = ds.stage_bytes;
     s.chunk_rows = ds.chunk_rows;
     s.seg = ds.seg;

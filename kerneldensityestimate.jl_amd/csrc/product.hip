@@ -1071,7 +1071,7 @@ int kdehip_prod_philox_batch(int nprod, const kdehip_batch_item *items, int prec
     if (groups[k].members.size() == 1) { singles.push_back(groups[k].members[0]); groups.erase(groups.begin() + k); } else ++k;
   // Whether a member's conditional tables pay for themselves INSIDE the batch: a table row costs about as much as a full
   // step of one chain, a tabulated sweep step saves ~60 % of one -- and the many small products a batch is made of have few
-  // chains per table row (config 2's shape: 4,092 rows for 256 chains).  Measured on MI355X (profiles/r04_batch.md):
+  // chains per table row (config 2's shape: 4,092 rows for 256 chains).  Measured on MI355X (profiles/r04_experiments.md section 6):
   // tables when chains x tabulated levels x sweeps x densities >= 6.5 x rows.  KDEHIP_BATCH_TABLES=0/1 forces never/always.
   static const int force_tables = [] { const char *e = std::getenv("KDEHIP_BATCH_TABLES"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
   auto has_tables = [&](int i) {

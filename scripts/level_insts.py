@@ -5,7 +5,8 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import kdehip, bench
-D, M, N, Nout, Niter, prec, cid = bench.CONFIGS["c3"]
+CFG = os.environ.get("KDEHIP_LEVEL_CONFIG", "c3")
+D, M, N, Nout, Niter, prec, cid = bench.CONFIGS[CFG]
 pts, bws = bench.synth_inputs(kdehip, D, M, N, cid)
 plan = kdehip.ProductPlan([kdehip.kde(p, b) for p, b in zip(pts, bws)], precision=prec)
 dev = torch.device("cuda", 0)

@@ -21,16 +21,17 @@ def load(d):
         rows.setdefault(int(r["Dispatch_Id"]), {})[r["Counter_Name"]] = float(r["Counter_Value"])
     return [v for k, v in sorted(rows.items())]
 a, b = load("pmc"), load("pmc2")
-a, b = a[-10:], b[-10:]   # the ten cut-off launches are the last ten
+NL, NCH, NST = int('${KDEHIP_LEVELS:-10}'), int('${KDEHIP_CHAINS:-2048}'), int('${KDEHIP_STEPS_PER_LEVEL:-44}')
+a, b = a[-NL:], b[-NL:]   # the cut-off launches are the last L
 prev = {}
 print("level | VALU SALU LDS SMEM per chain-step | wave-quads active wait_any wait_inst per chain-step")
 tot = collections.Counter()
 for k, (x, y) in enumerate(zip(a, b), 1):
     z = dict(x); z.update(y)
-    d = {c: (z[c] - prev.get(c, 0.0)) / 2048 / 44 for c in z}
+    d = {c: (z[c] - prev.get(c, 0.0)) / NCH / NST for c in z}
     prev = z
     print(f"{k:5d} | {d['SQ_INSTS_VALU']:6.0f} {d['SQ_INSTS_SALU']:6.0f} {d['SQ_INSTS_LDS']:5.0f} {d['SQ_INSTS_SMEM']:5.0f} | "
           f"{d['SQ_WAVE_CYCLES']:7.0f} {d['SQ_ACTIVE_INST_ANY']:7.0f} {d['SQ_WAIT_ANY']:7.0f} {d['SQ_WAIT_INST_ANY']:7.0f}")
-print("per chain, whole run: " + " ".join(f"{c}={prev[c]/2048:.0f}" for c in sorted(prev)))
+print("per chain, whole run: " + " ".join(f"{c}={prev[c]/NCH:.0f}" for c in sorted(prev)))
 PY
 rm -rf $OUT

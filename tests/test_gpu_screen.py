@@ -43,6 +43,8 @@ def _run_variants(plan, Np, Niter, seed, variants=(0, 5, 1)):
     (2, [3000, 2500], 200, 3, False, None),
     (4, [2000] * 4, 128, 2, False, None),
     (3, [1500] * 8, 96, 2, False, None),     # 8 densities: the register-resident kernel's other translation unit
+    (6, [2048] * 4, 136, 3, False, 3),       # levels 9 (resident), 10 and 11 (screen tiles streamed one per step)
+    (3, [3000, 2048, 2500], 100, 3, True, None),  # streamed screen tiles of ragged sizes, weighted
 ])
 def test_screened_run_is_the_fp64_run(D, Ns, Np, Niter, weighted, levels):
     g, o = _trees(4200 + D + len(Ns), D, Ns, weighted=weighted, want_oracle=(Np <= 300))
