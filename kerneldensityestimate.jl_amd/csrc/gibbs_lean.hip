@@ -91,7 +91,10 @@ struct LeanTile {
 // (see `step`: the builds with registers to spare and the kept-rows second pass, on tiles that sit in LDS)
 template <typename P, typename T, bool OK> constexpr bool kCanPreloadImpl = OK && kIsLdsPtr<P> && sizeof(T) == 8;
 
-template <typename T, int D, int M, int WAVES, bool BATCH = false>
+// SCHUNK: the build that also knows CHUNKED screen tiles (kStageScreenChunked).  A build of its own, launched only for plans
+// that have such a level: with that code in every build, config 3 -- which never runs it -- was 3.3 % slower (32 more
+// vector registers, 200 more scalar spills; profiles/r05_experiments.md section 10).
+template <typename T, int D, int M, int WAVES, bool BATCH = false, bool SCHUNK = false>
 __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, RunArgs a_) {
   const LaunchView<BATCH> view(plan_, a_);
   const PlanDev &plan = view.plan;
@@ -364,6 +367,62 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
   unsigned long long sstamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   bool sstamp_on = false;
 #endif
+  // (chunked screen tiles, step_screen_chunked below) The fp32 evaluator and the error-bound coefficients of a screened
+  // step, from the screen tile's header values (lanes = dimensions) and the chain's leave-one-out product; body(ev, ok):
+  // ok = the step is inside the ranges the bound assumes (wave-uniform; with !ok the evaluator must not be used for a
+  // decision -- every wavefront still has to walk the chunks: their barriers).  step_screen spells the same set-up out
+  // itself: written through these two helpers it was 1.2 % slower on config 3 (A/B of development libraries, round 5).
+  auto screen_eval = [&](const auto &ds, double mu0, double cmin, float mmax, float valid, T mean, T cov, auto &&body) -> int {
+    const float cen = static_cast<float>(mean - mu0);
+    const float cf = static_cast<float>(cmin + cov), covf = static_cast<float>(cov);
+    const float acen = fabsf(cen);
+    const bool inr = (acen <= kScreenMaxAbsMean) && (covf <= static_cast<float>(kScreenMaxVar));  // (false for a NaN)
+    const bool ok = valid != 0.0f && __ballot(lane < D && !inr) == 0ull;
+    const float t = fminf(mmax + acen, 2.0f * acen);
+    float a2 = lane < D ? t * t * __builtin_amdgcn_rcpf(cf) : 0.0f;
+    a2 += dpp_fetch<0x111, 0xF>(a2);  // row_shr:1, 2, 4: lane 7 holds the sum over the (at most 8) dimension lanes
+    a2 += dpp_fetch<0x112, 0xF>(a2);
+    a2 += dpp_fetch<0x114, 0xF>(a2);
+    const float na = __builtin_sqrtf(lane_read(a2, 7)) * (kScreenU * kScreenSqrtC0 * 1.01f);
+    const float Bc = (kScreenLn2 * 1.01f) * (na + kScreenKx * kScreenU);
+    const float A = (kScreenLn2 * 1.01f) * na + static_cast<float>(ds.B + 40) * kScreenU;
+    if (ds.uniform_bw) {
+      ScreenEval<D, true> ev;
+      ev.A = A; ev.Bc = Bc;
+      const float ninv = -kScreenC0 * __builtin_amdgcn_rcpf(cf);
+      float pr = 1.0f;
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        ev.cen[d] = lane_read(cen, d);
+        ev.b[d] = lane_read(ninv, d);
+        pr *= lane_read(cf, d);
+      }
+      ev.scale = __builtin_amdgcn_rsqf(pr);
+      return body(ev, ok);
+    } else {
+      ScreenEval<D, false> ev;
+      ev.A = A; ev.Bc = Bc; ev.scale = 1.0f;
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        ev.cen[d] = lane_read(cen, d);
+        ev.b[d] = lane_read(covf, d);
+      }
+      return body(ev, ok);
+    }
+  };
+  // what follows the screen's verdict: the fp64 draw on the fp64 tile in global memory when it is not certified (or out of
+  // the screen's range), and the new kernel from the fp64 tile
+  auto screen_finish = [&](auto jc, const auto &ds, int pos, T mean, T cov, double u) {
+    const T *hdrg = data + ds.hdr_off();
+    ++n_screened;
+    if (pos < 0) {
+      ++n_repeated;
+      pos = __builtin_amdgcn_readfirstlane(draw(ds, hdrg, mean, cov, [&](const auto &ev) {
+        return draw_rows(ds, hdrg + kTileHeader, ev, u);
+      }));
+    }
+    adopt(jc, ds, hdrg, pos);
+  };
   auto step_screen = [&](auto jc, const auto &ds, int sc_lds_off, bool first, T x) {
     if constexpr (kScreen) {
       SSTAMP(ts0);
@@ -455,6 +514,55 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
     if (wave < kCopyWaves) stage_tile<kCopyWaves>(src, pool + half * (kLdsPoolBytes / 2), bytes, wave, lane);
   };
 
+  // ---- a step on a screened level whose screen tile comes through the pool halves in CHUNKS of whole row pairs (chunk 0
+  // carries the header); one barrier per chunk, the copy of the next chunk -- or of the next step's chunk 0 -- overlaps the
+  // evaluation of this one; the second pass reads the screen tile in global memory ----
+  auto stage_schunk = [&](const LevelDesc &sc, int p0, int half) {
+    using TA = TileAddr<float>;
+    const int RS = TA::stride(sc.F), cp = sc.chunk_rows >> 1, npairs = (sc.B + 1) >> 1;
+    const int np = (npairs - p0 < cp) ? (npairs - p0) : cp;
+    const int head = p0 == 0 ? kScreenHeaderFloats : 0;
+    const int bytes = ((head + np * RS) * 4 + 1023) & ~1023;
+    const unsigned char *src = reinterpret_cast<const unsigned char *>(reinterpret_cast<const float *>(plan.data) + sc.hdr_off +
+                                                                       (p0 == 0 ? 0 : kScreenHeaderFloats + p0 * RS));
+    if (wave < kCopyWaves) stage_tile<kCopyWaves>(src, pool + half * (kLdsPoolBytes / 2), bytes, wave, lane);
+  };
+  auto step_screen_chunked = [&](auto jc, const auto &ds, const LevelDesc &sc, const LevelDesc &scn, bool more, bool first, T x) {
+    if constexpr (kScreen && SCHUNK) {
+      using TA = TileAddr<float>;
+      T mean = x, cov = T(0);
+      if (!first) product(jc, mean, cov);
+      const double u = next_uniform();
+      const int RS = TA::stride(sc.F), cp = sc.chunk_rows >> 1, npairs = (sc.B + 1) >> 1;
+      staging_barrier();  // chunk 0 has landed for every wavefront; the other half is free again
+      if (cp < npairs) stage_schunk(sc, cp, (gchunk + 1) & 1);
+      else if (more) stage_schunk(scn, 0, (gchunk + 1) & 1);
+      const LdsPtr<float> h32 = (LdsPtr<float>)(pool + (gchunk & 1) * (kLdsPoolBytes / 2));
+      const LdsPtr<double> h64 = (LdsPtr<double>)(pool + (gchunk & 1) * (kLdsPoolBytes / 2));
+      const double mu0 = h64[dl], cmin = h64[8 + dl];
+      const float mmax = h32[32 + dl], valid = h32[40];
+      const float *grows = reinterpret_cast<const float *>(plan.data) + sc.hdr_off + kScreenHeaderFloats;
+      const int pos = __builtin_amdgcn_readfirstlane(screen_eval(ds, mu0, cmin, mmax, valid, mean, cov, [&](const auto &ev, bool ok) {
+        using Ev = std::decay_t<decltype(ev)>;
+        kdehip_f2 S = {0.0f, 0.0f}, E = {0.0f, 0.0f};
+        KDEHIP_PRIO_ROWS();
+        if (ok) screen_rows<D, Ev::kUni>(h32 + kScreenHeaderFloats + lane * TA::kLane, npairs < cp ? npairs : cp, RS, ev, S, E);
+        ++gchunk;
+        for (int p0 = cp; p0 < npairs; p0 += cp, ++gchunk) {
+          staging_barrier();
+          if (p0 + cp < npairs) stage_schunk(sc, p0 + cp, (gchunk + 1) & 1);
+          else if (more) stage_schunk(scn, 0, (gchunk + 1) & 1);
+          const int np = (npairs - p0 < cp) ? (npairs - p0) : cp;
+          if (ok) screen_rows<D, Ev::kUni>((LdsPtr<float>)(pool + (gchunk & 1) * (kLdsPoolBytes / 2)) + lane * TA::kLane, np, RS, ev, S, E);
+        }
+        KDEHIP_PRIO_CHAIN();
+        if (!ok) return -1;
+        return screen_decide<D, Ev::kUni, true>(grows, ds.n, ds.B, RS, lane, ev, u, S.x + S.y, E.x + E.y SSTAMP_ARGS);
+      }));
+      screen_finish(jc, ds, pos, mean, cov, u);
+    }
+  };
+
 #ifdef KDEHIP_EXPERIMENTS  // diagnostic builds: variant 100+k stops after level k (scripts/level_profile.sh)
   const int Lrun = (vlev >= 100 && vlev - 100 < L) ? vlev - 100 : L;
 #else
@@ -484,12 +592,13 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
     const bool tabulated = (l <= Lt);
     const int npass = tabulated ? 1 : a.Niter + 1;  // tabulated levels: only the sampleIndices! pass runs here
 
-    bool screened = false, screen_streamed = false;
+    bool screened = false, screen_streamed = false, screen_chunked = false;
     if constexpr (kScreen) {
       if (a.use_screen && vlev != 1) {
         const int smode = scalar_copy(levels[M * (L + 1) + l].stage_mode);
         screened = smode == kStageScreen;
         screen_streamed = smode == kStageScreenStream;
+        if constexpr (SCHUNK) screen_chunked = smode == kStageScreenChunked;
       }
     }
 #ifdef KDEHIP_SCREEN_STAMPS
@@ -540,6 +649,20 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
           if (!kLateCopy && t + 1 < nsteps) stage_screen(scn, (t + 1) & 1, IC<WAVES>{});
           step_screen(jc, ds, (t & 1) * (kLdsPoolBytes / 2), p == 0, x);
           if (kLateCopy && t + 1 < nsteps) stage_screen(scn, (t + 1) & 1, IC<kCopyWaves>{});
+          ++t;
+        });
+    } else if (screen_chunked) {
+      auto screen = [&](int j) -> LevelDesc { return levels[(M + j) * (L + 1) + l]; };
+      staging_barrier();
+      stage_schunk(screen(0), 0, gchunk & 1);
+      int t = 0;
+      const int nsteps = npass * M;
+      for (int p = 0; p < npass; ++p)
+        static_for<M>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          constexpr int jn = (j + 1 == M) ? 0 : j + 1;
+          const LeanTile<D> ds = tile(j);
+          step_screen_chunked(jc, ds, screen(j), screen(jn), t + 1 < nsteps, p == 0, x);
           ++t;
         });
     } else if (mode == kStageResident) {
@@ -740,6 +863,13 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
 template <typename T, int D, int M, int WAVES>
 static void launch_lean_waves(const PlanDev &plan, const RunArgs &args, hipStream_t stream) {
   const int64_t blocks = (args.Np + WAVES - 1) / WAVES;
+  if constexpr (sizeof(T) == 8 && WAVES >= 8) {  // (4 chains per workgroup: small runs; chunked screen levels run in fp64 there)
+    if (plan.screened == 2 && args.use_screen) {
+      hipLaunchKernelGGL((gibbs_lean_kernel<T, D, M, WAVES, false, true>), dim3(static_cast<unsigned>(blocks)), dim3(WAVES * 64),
+                         0, stream, plan, args);
+      return;
+    }
+  }
   hipLaunchKernelGGL((gibbs_lean_kernel<T, D, M, WAVES>), dim3(static_cast<unsigned>(blocks)), dim3(WAVES * 64), 0,
                      stream, plan, args);
 }

@@ -71,7 +71,8 @@ enum StageMode : int32_t {
   kStageStream = 2,    // one tile per step, double-buffered in the LDS pool
   kStageChunked = 3,   // tile larger than half the pool: rows streamed through the two halves in chunks
   kStageScreen = 4,    // (screen descriptors only) the level is SCREENED in fp32: see "fp32 screening" below
-  kStageScreenStream = 5  // ... with its screen tiles streamed through the pool halves one per step (they do not fit together)
+  kStageScreenStream = 5,  // ... with its screen tiles streamed through the pool halves one per step (they do not fit together)
+  kStageScreenChunked = 6  // ... in chunks of chunk_rows rows (a screen tile is larger than half the pool); chunk 0 carries the header
 };
 constexpr int kLdsPoolBytes = 120 * 1024;   // LDS bytes for staged tiles (of 160 KiB per CU; the rest: chain state)
 
@@ -140,6 +141,7 @@ static_assert(sizeof(StepDesc) == 32, "StepDesc is read with one 32-byte scalar 
 
 constexpr int kScreenHeaderFloats = 48;
 constexpr int kScreenMaxRows = 64;           // rows per lane up to which a level is screened (one second-pass round)
+constexpr int kScreenMaxRowsChunked = 128;   // ... when its screen tiles are chunked (second pass from global memory, two rounds)
 constexpr float kScreenMaxAbsMean = 65536.0f;  // |m'_d|, |centre'_d| <= 2^16
 constexpr double kScreenMinVar = 1.0 / 128.0, kScreenMaxVar = 256.0;  // variances (tile, leave-one-out) in [2^-7, 2^8]
 
@@ -169,7 +171,7 @@ struct PlanDev {
   const TabDesc *tabdesc;    // [M][L+1]
   int64_t tab_rows_total;
   int32_t M, L, D, Lt;       // Lt: levels 1..Lt are tabulated (0 = none)
-  int32_t screened;          // 1: the plan carries screen tiles (descriptors behind the level table) and they are built
+  int32_t screened;          // 1: the plan carries screen tiles (descriptors behind the level table) and they are built; 2: some chunked
   int32_t reserved_[3];
 };
 

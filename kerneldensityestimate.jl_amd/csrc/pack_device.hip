@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void screen_build_kernel(PlanDev plan) {
   const int M = plan.M, L = plan.L, D = plan.D;
   const int idx = blockIdx.x;  // j * (L + 1) + l
   const LevelDesc sc = plan.levels[M * (L + 1) + idx];
-  if (sc.stage_mode != kStageScreen && sc.stage_mode != kStageScreenStream) return;
+  if (sc.stage_mode < kStageScreen) return;
   const LevelDesc ds = plan.levels[idx];
   const int j = idx / (L + 1);
   const LevelDesc root = plan.levels[j * (L + 1)];

@@ -353,24 +353,36 @@ int pack_layout_shapes(int M, int D, int L, const TileShape *shapes, const uint8
       if (mode != kStageStream && mode != kStageChunked) continue;
       bool ok = true;
       int64_t sum = 0, mx = 0;
+      int maxB = 0;
       for (int j = 0; j < M && ok; ++j) {
         const LevelDesc &ds = out.levels[static_cast<size_t>(j) * (L + 1) + l];
-        if (ds.B < 2 || ds.B > kScreenMaxRows) ok = false;
+        if (ds.B < 2 || ds.B > kScreenMaxRowsChunked) ok = false;
+        maxB = ds.B > maxB ? ds.B : maxB;
         const int64_t bytes = ((kScreenHeaderFloats + TileAddrBytes<4>::body(ds.B, ds.F)) * 4 + 1023) / 1024 * 1024;
         sum += bytes;
         mx = bytes > mx ? bytes : mx;
       }
       // all M images in the pool together (no barrier between the level's steps), or one per pool half, streamed like the
       // fp64 tiles of a streamed level (a barrier per step: a wavefront that repeats a step in fp64 holds up its workgroup)
+      // or in chunks of whole row pairs through the halves (a barrier per chunk; the second pass from the screen tile in
+      // global memory)
       static const bool stream_on = [] { const char *e = std::getenv("KDEHIP_SCREEN_STREAM"); return !(e && e[0] == '0'); }();
-      const bool together = sum <= kLdsPoolBytes;
-      if (!ok || (!together && !(stream_on && mx <= kLdsPoolBytes / 2))) continue;
+      static const bool chunk_on = [] { const char *e = std::getenv("KDEHIP_SCREEN_CHUNK"); return !(e && e[0] == '0'); }();
+      const bool together = sum <= kLdsPoolBytes && maxB <= kScreenMaxRows;
+      const bool streamed = !together && stream_on && mx <= kLdsPoolBytes / 2 && maxB <= kScreenMaxRows;
+      const bool chunked = !together && !streamed && stream_on && chunk_on;
+      if (!ok || !(together || streamed || chunked)) continue;
       int64_t off = 0;
       for (int j = 0; j < M; ++j) {
         const LevelDesc &ds = out.levels[static_cast<size_t>(j) * (L + 1) + l];
         LevelDesc &sc = scr[static_cast<size_t>(j) * (L + 1) + l];
         sc.n = ds.n; sc.B = ds.B; sc.F = ds.F; sc.uniform_bw = ds.uniform_bw; sc.last_lane = ds.last_lane;
-        sc.stage_mode = together ? kStageScreen : kStageScreenStream;
+        sc.stage_mode = together ? kStageScreen : streamed ? kStageScreenStream : kStageScreenChunked;
+        if (chunked) {  // whole row pairs per chunk, an even number of them (16-byte aligned chunk starts), the header with chunk 0
+          const int64_t pair_bytes = TileAddrBytes<4>::stride(ds.F) * 4;
+          const int64_t cp = ((kLdsPoolBytes / 2 - kScreenHeaderFloats * 4) / pair_bytes) & ~int64_t(1);
+          sc.chunk_rows = static_cast<int32_t>(2 * cp);
+        }
         felem = (felem + 63) & ~int64_t(63);  // 256-byte aligned images
         sc.hdr_off = felem;
         const int64_t elems = kScreenHeaderFloats + TileAddrBytes<4>::body(ds.B, ds.F);

@@ -312,6 +312,9 @@ void bind_plan(kdehip_product *p, size_t off_lev, size_t off_count, size_t off_t
   p->dev.D = p->host.D;
   p->dev.Lt = (p->mode == kModeGeneric) ? 0 : p->host.Lt;
   p->dev.screened = (p->mode == kModeFast && !p->host.screens.empty()) ? 1 : 0;
+  if (p->dev.screened)
+    for (const LevelDesc &sc : p->host.screens)
+      if (sc.stage_mode == kStageScreenChunked) p->dev.screened = 2;  // (selects the sampler build that knows chunked screens)
 }
 
 // A plan on `device` from an image: one device allocation, one DMA transfer (hipMalloc / hipFree cost tens of

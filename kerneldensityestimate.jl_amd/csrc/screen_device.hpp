@@ -63,6 +63,7 @@ struct ScreenEval {
   float b[D];    // UNI: -c0 / c_d (the level's shared variance + leave-one-out variance); else: the leave-one-out variance
   float scale;   // UNI: rsqrt(prod_d c_d)
   float A, Bc;
+  static constexpr bool kUni = UNI;
   using TA = TileAddr<float>;
   template <typename V, typename LD>
   __device__ __forceinline__ V value(LD &&ld, V &x) const {
@@ -112,46 +113,41 @@ struct ScreenEval {
     return v;
   }
   // one entry (second pass); e = (its row, field 0, its lane)
-  __device__ __forceinline__ float one(LdsPtr<float> e) const {
+  template <typename P>
+  __device__ __forceinline__ float one(P e) const {
     float x;
     return value<float>([&](int f) { return e[f * TA::kField]; }, x);
   }
 };
 
-// The draw on a screen tile (`rows` = row 0, field 0, lane 0 in LDS): the tile position of the entry u selects, or -1 when
-// the fp32 decision cannot be certified (the caller repeats the step in fp64).
+// First pass over `npairs` row pairs from `e` (= pair 0, field 0, this lane; LDS): value sums S and error-bound sums E.
+// Two pairs per trip, the next pair's fields requested before the current pair is evaluated (ping-pong registers).
 template <int D, bool UNI>
-__device__ __forceinline__ int screen_draw(LdsPtr<float> rows, int n, int B, int F, int lane, const ScreenEval<D, UNI> &ev,
-                                           double u SSTAMP_PARAMS) {
-  using TA = TileAddr<float>;
-  const int RS = TA::stride(F);
-  SSTAMP(tq0);
-  kdehip_f2 S = {0.0f, 0.0f}, E = {0.0f, 0.0f};
-  LdsPtr<float> e = rows + lane * TA::kLane;
-  const int npairs = (B + 1) >> 1;  // (the missing second row of the last pair is padding: weight 0)
+__device__ __forceinline__ void screen_rows(LdsPtr<float> e, int npairs, int RS, const ScreenEval<D, UNI> &ev, kdehip_f2 &S,
+                                            kdehip_f2 &E) {
   using Ev = ScreenEval<D, UNI>;
-  KDEHIP_PRIO_ROWS();
-  {  // two pairs per trip, the next pair's fields requested before the current pair is evaluated (ping-pong registers)
-    typename Ev::Pair ra = Ev::load(e);
-    int p = 0;
-    for (; p + 2 <= npairs; p += 2) {
-      const typename Ev::Pair rb = Ev::load(e + RS);  // pair p + 1
-      __builtin_amdgcn_sched_barrier(0);
-      ev.pair(ra, S, E);
-      e += (p + 2 < npairs) ? 2 * RS : RS;  // pair p + 2, or pair p + 1 again (never past the tile)
-      ra = Ev::load(e);
-      __builtin_amdgcn_sched_barrier(0);
-      ev.pair(rb, S, E);
-    }
-    if (p < npairs) ev.pair(ra, S, E);
+  typename Ev::Pair ra = Ev::load(e);
+  int p = 0;
+  for (; p + 2 <= npairs; p += 2) {
+    const typename Ev::Pair rb = Ev::load(e + RS);  // pair p + 1
+    __builtin_amdgcn_sched_barrier(0);
+    ev.pair(ra, S, E);
+    e += (p + 2 < npairs) ? 2 * RS : RS;  // pair p + 2, or pair p + 1 again (never past the tile)
+    ra = Ev::load(e);
+    __builtin_amdgcn_sched_barrier(0);
+    ev.pair(rb, S, E);
   }
-  KDEHIP_PRIO_CHAIN();
-  const float s1 = S.x + S.y, e1 = E.x + E.y;
-#ifdef KDEHIP_SCREEN_STAMPS
-  asm volatile("" ::"v"(s1), "v"(e1));
-#endif
+  if (p < npairs) ev.pair(ra, S, E);
+}
+
+// The decision from the lanes' sums: the tile position of the entry u selects, or -1 when the fp32 decision cannot be
+// certified (the caller repeats the step in fp64).  `rows` = the screen tile's row 0, field 0, lane 0 -- in LDS (TWO = false:
+// at most 64 rows per lane, one second-pass round) or in global memory (TWO: at most 128 rows, two rounds).
+template <int D, bool UNI, bool TWO, typename P>
+__device__ __forceinline__ int screen_decide(P rows, int n, int B, int RS, int lane, const ScreenEval<D, UNI> &ev, double u,
+                                             float s1, float e1 SSTAMP_PARAMS) {
+  using TA = TileAddr<float>;
   SSTAMP(tq1);
-  SSTAMP_ADD(4, tq0, tq1);
   const float incl = wave_inclusive_scan(s1);
   const float einc = wave_inclusive_scan(e1);
   const float total = lane_read(incl, 63), etot = lane_read(einc, 63);
@@ -175,12 +171,46 @@ __device__ __forceinline__ int screen_draw(LdsPtr<float> rows, int n, int B, int
   const float inc3 = wave_inclusive_scan(p2);
   const double cum = static_cast<double>(base) + static_cast<double>(inc3);
   const unsigned long long hitA2 = __ballot(in && td + md <= cum), hitB2 = __ballot(in && td - md <= cum);
+  if constexpr (TWO) {
+    if (len > 64) {  // rows 64 .. len - 1 (wave-uniform branch)
+      const bool in2 = lane + 64 < len;
+      float p3 = 0.0f;
+      if (in2) p3 = ev.one(rows + lstar * TA::kLane + TA::row(lane + 64, RS));
+      const float inc4 = wave_inclusive_scan(p3);
+      const double cum2 = static_cast<double>(base) + static_cast<double>(lane_read(inc3, 63)) + static_cast<double>(inc4);
+      const unsigned long long hitA3 = __ballot(in2 && td + md <= cum2), hitB3 = __ballot(in2 && td - md <= cum2);
+      const int ia = hitA2 ? __ffsll(hitA2) - 1 : (hitA3 ? 64 + __ffsll(hitA3) - 1 : -1);
+      const int ib = hitB2 ? __ffsll(hitB2) - 1 : (hitB3 ? 64 + __ffsll(hitB3) - 1 : -1);
+      if (ia < 0 || ia != ib) return -1;
+      return ia * 64 + lstar;
+    }
+  }
   if (hitA2 == 0ull) return -1;
   const int istar = __ffsll(hitA2) - 1;
   if (__ffsll(hitB2) - 1 != istar) return -1;
   SSTAMP(tq3);
   SSTAMP_ADD(6, tq2, tq3);
   return istar * 64 + lstar;
+}
+
+// The draw on a screen tile that is whole in LDS (`rows` = row 0, field 0, lane 0).
+template <int D, bool UNI>
+__device__ __forceinline__ int screen_draw(LdsPtr<float> rows, int n, int B, int F, int lane, const ScreenEval<D, UNI> &ev,
+                                           double u SSTAMP_PARAMS) {
+  using TA = TileAddr<float>;
+  const int RS = TA::stride(F);
+  SSTAMP(tq0);
+  kdehip_f2 S = {0.0f, 0.0f}, E = {0.0f, 0.0f};
+  KDEHIP_PRIO_ROWS();
+  screen_rows<D, UNI>(rows + lane * TA::kLane, (B + 1) >> 1, RS, ev, S, E);  // (the missing second row of the last pair is padding: weight 0)
+  KDEHIP_PRIO_CHAIN();
+  const float s1 = S.x + S.y, e1 = E.x + E.y;
+#ifdef KDEHIP_SCREEN_STAMPS
+  asm volatile("" ::"v"(s1), "v"(e1));
+#endif
+  SSTAMP(tq1);
+  SSTAMP_ADD(4, tq0, tq1);
+  return screen_decide<D, UNI, false>(rows, n, B, RS, lane, ev, u, s1, e1 SSTAMP_ARGS);
 }
 
 }  // namespace kdehip

@@ -45,6 +45,10 @@ def _run_variants(plan, Np, Niter, seed, variants=(0, 5, 1)):
     (3, [1500] * 8, 96, 2, False, None),     # 8 densities: the register-resident kernel's other translation unit
     (6, [2048] * 4, 136, 3, False, None),    # levels 10 and 11: screen tiles streamed one per step
     (3, [3000, 2048, 2500], 100, 3, True, None),  # streamed screen tiles of ragged sizes, weighted
+    (6, [4096] * 4, 1100, 2, False, None),   # level 12 (4096 leaves, 64 rows per lane): screen tiles in CHUNKS, second pass from global memory
+    (6, [8000, 5000, 4096], 1100, 2, True, None),  # chunked, up to 125 rows per lane (two second-pass rounds), per-node bandwidths at level 12
+    (6, [4096] * 4, 60, 2, False, None),     # 4 chains per workgroup: that build has no chunked screens (fp64 there), the rest is screened
+    (3, [5000] * 8, 160, 2, False, None),    # BASELINE config 4's shape: levels 9-11 resident / streamed, 12-13 chunked
 ])
 def test_screened_run_is_the_fp64_run(D, Ns, Np, Niter, weighted, levels):
     g, o = _trees(4200 + D + len(Ns), D, Ns, weighted=weighted, want_oracle=(Np <= 300))
