@@ -384,8 +384,10 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
     a2 += dpp_fetch<0x112, 0xF>(a2);
     a2 += dpp_fetch<0x114, 0xF>(a2);
     const float na = __builtin_sqrtf(lane_read(a2, 7)) * (kScreenU * kScreenSqrtC0 * 1.01f);
-    const float Bc = (kScreenLn2 * 1.01f) * (na + kScreenKx * kScreenU);
-    const float A = (kScreenLn2 * 1.01f) * na + static_cast<float>(ds.B + 40) * kScreenU;
+    using SC = ScreenConst<D>;
+    const float Bc = (kScreenLn2 * 1.01f) * (na + (ds.uniform_bw ? SC::kx_uni : SC::kx_node) * kScreenU);
+    const float A = (kScreenLn2 * 1.01f) * na +
+                    (static_cast<float>(((ds.B + 1) >> 1) + 9) + (ds.uniform_bw ? SC::vc_uni : SC::vc_node)) * kScreenU;
     if (ds.uniform_bw) {
       ScreenEval<D, true> ev;
       ev.A = A; ev.Bc = Bc;
@@ -450,8 +452,10 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
         a2 += dpp_fetch<0x112, 0xF>(a2);
         a2 += dpp_fetch<0x114, 0xF>(a2);
         const float na = __builtin_sqrtf(lane_read(a2, 7)) * (kScreenU * kScreenSqrtC0 * 1.01f);
-        const float Bc = (kScreenLn2 * 1.01f) * (na + kScreenKx * kScreenU);
-        const float A = (kScreenLn2 * 1.01f) * na + static_cast<float>(ds.B + 40) * kScreenU;
+        using SC = ScreenConst<D>;
+        const float Bc = (kScreenLn2 * 1.01f) * (na + (ds.uniform_bw ? SC::kx_uni : SC::kx_node) * kScreenU);
+        const float A = (kScreenLn2 * 1.01f) * na +
+                        (static_cast<float>(((ds.B + 1) >> 1) + 9) + (ds.uniform_bw ? SC::vc_uni : SC::vc_node)) * kScreenU;
         const LdsPtr<float> rows32 = h32 + kScreenHeaderFloats;
         if (ds.uniform_bw) {
           ScreenEval<D, true> ev;
@@ -544,20 +548,20 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
       const float *grows = reinterpret_cast<const float *>(plan.data) + sc.hdr_off + kScreenHeaderFloats;
       const int pos = __builtin_amdgcn_readfirstlane(screen_eval(ds, mu0, cmin, mmax, valid, mean, cov, [&](const auto &ev, bool ok) {
         using Ev = std::decay_t<decltype(ev)>;
-        kdehip_f2 S = {0.0f, 0.0f}, E = {0.0f, 0.0f};
+        ScreenSums q;
         KDEHIP_PRIO_ROWS();
-        if (ok) screen_rows<D, Ev::kUni>(h32 + kScreenHeaderFloats + lane * TA::kLane, npairs < cp ? npairs : cp, RS, ev, S, E);
+        if (ok) screen_rows<D, Ev::kUni>(h32 + kScreenHeaderFloats + lane * TA::kLane, npairs < cp ? npairs : cp, RS, ev, q);
         ++gchunk;
         for (int p0 = cp; p0 < npairs; p0 += cp, ++gchunk) {
           staging_barrier();
           if (p0 + cp < npairs) stage_schunk(sc, p0 + cp, (gchunk + 1) & 1);
           else if (more) stage_schunk(scn, 0, (gchunk + 1) & 1);
           const int np = (npairs - p0 < cp) ? (npairs - p0) : cp;
-          if (ok) screen_rows<D, Ev::kUni>((LdsPtr<float>)(pool + (gchunk & 1) * (kLdsPoolBytes / 2)) + lane * TA::kLane, np, RS, ev, S, E);
+          if (ok) screen_rows<D, Ev::kUni>((LdsPtr<float>)(pool + (gchunk & 1) * (kLdsPoolBytes / 2)) + lane * TA::kLane, np, RS, ev, q);
         }
         KDEHIP_PRIO_CHAIN();
         if (!ok) return -1;
-        return screen_decide<D, Ev::kUni, true>(grows, ds.n, ds.B, RS, lane, ev, u, S.x + S.y, E.x + E.y SSTAMP_ARGS);
+        return screen_decide<D, Ev::kUni, true>(grows, ds.n, ds.B, RS, lane, ev, u, q.values(), q.errors() SSTAMP_ARGS);
       }));
       screen_finish(jc, ds, pos, mean, cov, u);
     }
@@ -634,6 +638,10 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
           stage_tile<W>(reinterpret_cast<const unsigned char *>(reinterpret_cast<const float *>(plan.data) + sc.hdr_off),
                         pool + half * (kLdsPoolBytes / 2), sc.stage_bytes, wave, lane);
       };
+      // (A barrier split into "arrive" and "wait" -- an LDS counter; a wavefront that must repeat its step arrives at the next
+      // barrier BEFORE the repeat, so the others go on with the next tile meanwhile -- was built and measured: config 4
+      // 3.04 -> 3.07 ms.  A late wavefront stays late, the workgroup waits for it one barrier later; only repeats that
+      // overlap in time would be hidden.  profiles/r05_experiments.md section 11.)
       staging_barrier();
       stage_screen(screen(0), 0, IC<WAVES>{});
       int t = 0;

@@ -20,13 +20,21 @@
 //     |centre'_d|, 2 |centre'_d|), moves the exponent by at most 2 c0 sum_d |t_d| u g_d / sigma_d (t_d = the scaled
 //     difference, sigma_d^2 = c_id >= cmin_d) <= 2 sqrt(c0 |x_i|) |a'| by Cauchy-Schwarz, a'_d = u g_d / sqrt(cmin_d), and
 //     2 sqrt(y) <= 1 + y gives the linear form  na (1 + |x_i|),  na = sqrt(c0) |a'|;
-//   * every other operation (the subtraction itself, squares, the sums of non-negative terms, products of variances,
-//     rsq, the rounded operands) is a relative perturbation of x_i by at most kx u, kx = 32 covering D <= 8;
-//   * front_i, exp2 and the final product add at most 24 u relative to v_i; fp32 sums of n non-negative numbers in any
-//     order are within (rows per lane + 16) u of the exact sum.
-// So |v~_i - v_i| <= v_i (A + Bc |x_i|) with the wave-uniform A = ln2 na + (B + 40) u, Bc = ln2 (na + kx u) (each with a
-// 1 % allowance for the second-order terms), every cumulative sum is within E = sum_i v~_i (A + Bc |x~_i|) of its fp64
-// value, and so is the target u * total.  A decision is certified when the boundaries on both sides of the target are
+//   * every other operation is a relative perturbation of x_i by at most kx u (ScreenConst below, each with 2 u of slack).
+//     Shared bandwidths: the difference 2 u (its rounding, the relative part of the operands'), its square 5 u; the
+//     coefficient -c0 / c_d 5 u (c_d rounded, v_rcp_f32 within 1 ulp = 2 u, the constant, the product); one rounding per
+//     fma of the D same-signed terms: kx = 10 + D.  Per-node bandwidths: the square 5 u, c_d = variance + leave-one-out
+//     variance 2 u, two roundings per level of the fraction tree (depth = ceil(log2 D)), D - 1 for the product of the
+//     variances, 4 u for the square of v_rsq_f32 (1 ulp), the two products with it and the one with -c0 (a rounded
+//     constant) 4 u: kx = 14 + 2 depth + D;
+//   * front_i, exp2 and the final product add vc u relative to v_i: the weight u, the scale rsq(prod c_d) (D + 1.5) u with
+//     shared and (1.5 D + 1.5) u with per-node bandwidths, their product u, v_exp_f32 (1 ulp) 2 u, the last product u:
+//     vc = D + 6.5 or 1.5 D + 6.5; the fp32 sums (two half sums of ceil(B / 2) rows, their sum, six scan steps; the second
+//     pass's scan is shorter) are within (ceil(B / 2) + 7) u of the exact sums of the computed values.
+// So |v~_i - v_i| <= v_i (A + Bc |x_i|) with the wave-uniform A = ln2 na + (ceil(B / 2) + 9 + vc) u, Bc = ln2 (na + kx u)
+// (each with a 1 % allowance for the second-order terms), every cumulative sum is within E = sum_i v~_i (A + Bc |x~_i|)
+// of its fp64 value, and so is the target u * total.  (Rounds 5a-5o ran with the cruder kx = 32, vc = 24, B + 16 for the
+// sums: 0.75 % of config 3's and 1.9 % of config 4's draws repeated; profiles/r05_experiments.md section 11.)  A decision is certified when the boundaries on both sides of the target are
 // more than 2.1 E away (2 E would do).  Terms that fp32 flushes to zero or holds as denormals are below 2^-126 times a
 // front that the range checks bound by 2^28 each: with total >= 2^-40 required, their sum is below 2^-40 of the margin.
 // Range checks (else the step runs in fp64): tile values (screen_build_kernel: |m'| <= 2^16, variances in [2^-7, 2^8],
@@ -54,8 +62,18 @@ constexpr float kScreenU = 5.9604645e-8f;       // 2^-24
 constexpr float kScreenC0 = 0.72134752f;        // log2(e) / 2
 constexpr float kScreenSqrtC0 = 0.84932180f;    // sqrt(c0)
 constexpr float kScreenLn2 = 0.69314718f;
-constexpr float kScreenKx = 32.0f;
+// the model's constants in units of u for D dimensions (header comment; 2 u of slack each)
+template <int D>
+struct ScreenConst {
+  static constexpr int depth = D <= 1 ? 0 : D <= 2 ? 1 : D <= 4 ? 2 : 3;  // levels of the fraction tree (fraction_sum)
+  static constexpr float kx_uni = 12 + D, kx_node = 16 + 2 * depth + D;
+  static constexpr float vc_uni = D + 9, vc_node = (3 * D + 18) / 2;
+};
+#ifdef KDEHIP_X_NO_REPEAT  // (timing experiment only: every fp32 decision accepted -- NOT the fp64 labels)
+constexpr double kScreenMargin = 0.0;
+#else
 constexpr double kScreenMargin = 2.1;  // boundaries farther than this many error sums from the target are decided (2 suffices)
+#endif
 
 template <int D, bool UNI>
 struct ScreenEval {
@@ -122,22 +140,30 @@ struct ScreenEval {
 
 // First pass over `npairs` row pairs from `e` (= pair 0, field 0, this lane; LDS): value sums S and error-bound sums E.
 // Two pairs per trip, the next pair's fields requested before the current pair is evaluated (ping-pong registers).
+// The sums of a lane: the even rows' and the odd rows' halves of one packed accumulator each (values, error bounds): a
+// chain of ceil(B / 2) additions each over all chunks, which is what the bound's summation term counts.  (Two accumulators
+// each -- even and odd PAIRS, ceil(B / 4) + 1 additions, the term 15 u smaller at 64 rows -- measured: config 4 -0.7 %,
+// config 3 +0.3 %; not kept.)
+struct ScreenSums {
+  kdehip_f2 S = {0.0f, 0.0f}, E = {0.0f, 0.0f};
+  __device__ __forceinline__ float values() const { return S.x + S.y; }
+  __device__ __forceinline__ float errors() const { return E.x + E.y; }
+};
 template <int D, bool UNI>
-__device__ __forceinline__ void screen_rows(LdsPtr<float> e, int npairs, int RS, const ScreenEval<D, UNI> &ev, kdehip_f2 &S,
-                                            kdehip_f2 &E) {
+__device__ __forceinline__ void screen_rows(LdsPtr<float> e, int npairs, int RS, const ScreenEval<D, UNI> &ev, ScreenSums &q) {
   using Ev = ScreenEval<D, UNI>;
   typename Ev::Pair ra = Ev::load(e);
   int p = 0;
   for (; p + 2 <= npairs; p += 2) {
     const typename Ev::Pair rb = Ev::load(e + RS);  // pair p + 1
     __builtin_amdgcn_sched_barrier(0);
-    ev.pair(ra, S, E);
+    ev.pair(ra, q.S, q.E);
     e += (p + 2 < npairs) ? 2 * RS : RS;  // pair p + 2, or pair p + 1 again (never past the tile)
     ra = Ev::load(e);
     __builtin_amdgcn_sched_barrier(0);
-    ev.pair(rb, S, E);
+    ev.pair(rb, q.S, q.E);
   }
-  if (p < npairs) ev.pair(ra, S, E);
+  if (p < npairs) ev.pair(ra, q.S, q.E);
 }
 
 // The decision from the lanes' sums: the tile position of the entry u selects, or -1 when the fp32 decision cannot be
@@ -200,11 +226,11 @@ __device__ __forceinline__ int screen_draw(LdsPtr<float> rows, int n, int B, int
   using TA = TileAddr<float>;
   const int RS = TA::stride(F);
   SSTAMP(tq0);
-  kdehip_f2 S = {0.0f, 0.0f}, E = {0.0f, 0.0f};
+  ScreenSums q;
   KDEHIP_PRIO_ROWS();
-  screen_rows<D, UNI>(rows + lane * TA::kLane, (B + 1) >> 1, RS, ev, S, E);  // (the missing second row of the last pair is padding: weight 0)
+  screen_rows<D, UNI>(rows + lane * TA::kLane, (B + 1) >> 1, RS, ev, q);  // (the missing second row of the last pair is padding: weight 0)
   KDEHIP_PRIO_CHAIN();
-  const float s1 = S.x + S.y, e1 = E.x + E.y;
+  const float s1 = q.values(), e1 = q.errors();
 #ifdef KDEHIP_SCREEN_STAMPS
   asm volatile("" ::"v"(s1), "v"(e1));
 #endif

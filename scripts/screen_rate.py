@@ -134,17 +134,28 @@ def delta_bound(d, fr, center, mu0, cov):
     return dx * math.log(2.0) * 1.01 + (B + 16) * U32
 
 
-def weighted_terms(d, fr, center, mu0, cov):
-    """The per-term form of the bound the kernel accumulates beside the sums: term i carries the relative error
-    A + Bc |x_i| (x_i its base-2 exponent): |dx_i| <= 2 sqrt(|x_i| / c0) |a| + kx u |x_i| <= |a| + (|a| / c0 + kx u) |x_i|."""
-    c0 = 0.7213475204444817
-    mp = np.abs(d.means[fr] - mu0).max(axis=0) * (1 + U32)
-    cmin = (d.bw[fr] + cov).min(axis=0)
-    a = (mp + np.abs(center - mu0) * (1 + U32)) / np.sqrt(cmin) * (2 * U32) * c0
-    na = float(np.sqrt((a * a).sum()))
+def weighted_terms(d, fr, center, mu0, cov, old=False):
+    """The per-term bound the kernel accumulates beside the sums (csrc/screen_device.hpp, gibbs_lean.hip step_screen): term i
+    carries the relative error A + Bc |x_i| (x_i its base-2 exponent).  old: the constants rounds 5a-5o ran with."""
+    c0 = 0.72134752
+    D = d.D
+    uniform = bool(np.all(d.bw[fr] == d.bw[fr][0]))
+    mmax = np.abs((d.means[fr] - mu0).astype(f32)).max(axis=0).astype(np.float64)
+    acen = np.abs((center - mu0).astype(f32)).astype(np.float64)
+    cf = (d.bw[fr].astype(f32).min(axis=0).astype(np.float64) + cov).astype(f32).astype(np.float64)
+    g = np.minimum(mmax + acen, 2.0 * acen)
+    na = math.sqrt(float((g * g / cf).sum())) * (U32 * math.sqrt(c0) * 1.01)
+    if os.environ.get("SCREEN_RATE_NA_SCALE"):  # (attribution experiments only)
+        na *= float(os.environ["SCREEN_RATE_NA_SCALE"])
     B = (fr.size + 63) // 64
-    A = math.log(2.0) * na * 1.01 + (B + 16) * U32
-    Bc = math.log(2.0) * (na / c0 + 24 * U32) * 1.01
+    depth = 0 if D <= 1 else 1 if D <= 2 else 2 if D <= 4 else 3
+    if old:
+        kx, const = 32.0, B + 40.0
+    else:
+        kx = (12.0 + D) if uniform else (16.0 + 2 * depth + D)
+        const = (B + 1) // 2 + 9 + ((D + 9.0) if uniform else float((3 * D + 18) // 2))
+    A = math.log(2.0) * 1.01 * na + const * U32
+    Bc = math.log(2.0) * 1.01 * (na + kx * U32)
     return A, Bc
 
 
@@ -156,6 +167,7 @@ def main():
     ap.add_argument("--from-level", type=int, default=9)
     ap.add_argument("--delta-scale", type=float, default=1.0)
     ap.add_argument("--seed", type=int, default=20260101)
+    ap.add_argument("--old-constants", action="store_true", help="the bound's constants before they were tightened (kx = 32, B + 40)")
     args = ap.parse_args()
     D, M, N, _, Niter, _, cid = bench.CONFIGS[args.config]
     pts, bws = bench.synth_inputs(kdehip, D, M, N, cid)
@@ -168,6 +180,7 @@ def main():
     mu0 = [d.means[0].copy() for d in dens]  # the root mean of every density: the centring point of its fp32 tiles
 
     steps = amb = wrong = fallback32 = 0
+    diag = {}
     amb_by_level = {}
     steps_by_level = {}
     max_rel = 0.0
@@ -225,10 +238,13 @@ def main():
                             below = b32[z32 - 1] if z32 > 0 else 0.0
                             certified = (below * kappa < t32) and (t32 * kappa <= b32[z32])
                             if args.weighted:
-                                A, Bc = weighted_terms(d, fr, center, mu0[j], cv)
+                                A, Bc = weighted_terms(d, fr, center, mu0[j], cv, args.old_constants)
                                 e = p32.astype(np.float64) * (A + Bc * np.abs(x32.astype(np.float64)))
                                 Etot = float(e.sum()) * args.delta_scale
-                                mrg = 2.5 * Etot
+                                if os.environ.get("SCREEN_RATE_DIAG"):
+                                    xa = float((p32.astype(np.float64) * np.abs(x32.astype(np.float64))).sum() / tot)
+                                    diag.setdefault(l, []).append((Etot / tot / U32, A / U32, Bc / U32, xa))
+                                mrg = 2.1 * Etot
                                 certified = (below + mrg < t32) and (t32 + mrg <= b32[z32])
                                 mr = float(np.abs(b32 - b64).max())
                                 max_ratio_w[0] = max(max_ratio_w[0], mr / Etot)
@@ -251,6 +267,10 @@ def main():
     for l in sorted(steps_by_level):
         print(f"    level {l}: {amb_by_level.get(l, 0)} / {steps_by_level[l]} = "
               f"{100.0 * amb_by_level.get(l, 0) / steps_by_level[l]:.3f} %")
+    for l in sorted(diag):
+        a = np.array(diag[l])
+        print(f"    level {l}: mean E/total {a[:, 0].mean():.0f} u (median {np.median(a[:, 0]):.0f}), A {a[:, 1].mean():.0f} u, "
+              f"Bc {a[:, 2].mean():.0f} u (median {np.median(a[:, 2]):.0f}), value-weighted |x| {a[:, 3].mean():.1f}")
     if wg_steps:
         print(f"  8-chain workgroup-steps with at least one repeat: {len(wg_amb)} / {wg_steps} = "
               f"{100.0 * len(wg_amb) / wg_steps:.3f} %")
