@@ -17,6 +17,10 @@ python scripts/chain_timing.py c3 10 2048 >> $O/chain.txt 2>&1
 python scripts/pipeline_timing.py c3 > $O/pipeline.txt 2>&1
 python scripts/loocv_timing.py 20 > $O/loocv.txt 2>&1
 python scripts/screen_rate.py --chains 64 --weighted > $O/screen_rate.txt 2>&1
+python scripts/screen_rate.py --config c4 --chains 8 --weighted >> $O/screen_rate.txt 2>&1
+( NP=1100 timeout 300 python scripts/check_screen_chunk.py 6 4 2048 4096 8000 3000
+  NP=1100 timeout 300 python scripts/check_screen_chunk.py 3 8 5000 10000 2048
+  NP=1100 timeout 300 python scripts/check_screen_chunk.py 2 3 20000 9000 ) 2>&1 | grep -v amdgpu.ids > $O/check_screen_chunk.txt
 ( KDEHIP_FUZZ_N=1500 timeout 900 python -m pytest tests/test_gpu_fuzz.py -x -q 2>&1 | tail -2
   timeout 600 python scripts/soak_threads.py 16 1500 2>&1 | tail -1
   timeout 600 python scripts/soak_multi.py 3000 --resident 2>&1 | tail -1
@@ -34,6 +38,9 @@ bash scripts/valu_mix.sh ${TAG}5 --config c5 --steps 6 > $O/mix_c5.log 2>&1
 if [ -f kerneldensityestimate.jl_amd/libkdehip_exp.so ]; then
   bash scripts/level_profile.sh kerneldensityestimate.jl_amd/libkdehip_exp.so > $O/level_insts.txt 2> $O/level_insts.err
   KDEHIP_LIB=$PWD/kerneldensityestimate.jl_amd/libkdehip_exp.so python scripts/level_timing2.py c3 0 > $O/level_timing.txt 2>&1
+fi
+if [ -f kerneldensityestimate.jl_amd/libkdehip_exp4.so ]; then
+  KDEHIP_LIB=$PWD/kerneldensityestimate.jl_amd/libkdehip_exp4.so python scripts/level_timing2.py c4 0 > $O/level_timing_c4.txt 2>&1
 fi
 python -c "
 import json
