@@ -304,7 +304,7 @@ struct Golden {
   int phase;          // 0: needs f1, 1: needs f2, 2: iterating, 3: done
   int pending;        // which of f1/f2 the evaluation in flight fills (1 or 2), 0 = none
   int nevals;
-  int pad_;
+  int spec;           // speculative rounds: the launch that evaluated `pending` also evaluated BOTH candidates of the decision after it
 };
 
 // Initial bracket of ksize (src/CrossValidation.jl:110-120) from neighborMinMax (:100-108).
@@ -317,7 +317,7 @@ __host__ __device__ inline void golden_init(Golden &s, double minm, double maxm)
   s.x0 = ax; s.x3 = cx;
   if (fabs(cx - bx) > fabs(bx - ax)) { s.x1 = bx; s.x2 = bx + C * (cx - bx); }
   else { s.x1 = bx - C * (bx - ax); s.x2 = bx; }
-  s.phase = 0; s.nevals = 0; s.pending = 0; s.alpha = 0; s.bw_eval = 0; s.f1 = s.f2 = 0; s.result = 0;
+  s.phase = 0; s.nevals = 0; s.pending = 0; s.alpha = 0; s.bw_eval = 0; s.f1 = s.f2 = 0; s.result = 0; s.spec = 0;
 }
 
 // The state machine in two halves.  book: the evaluation that was in flight has finished (its block partials of
@@ -334,21 +334,71 @@ __host__ __device__ inline void golden_book(Golden &s, const double *hpart, int 
   if (s.phase < 2) s.phase += 1;
   s.pending = 0;
 }
-__host__ __device__ inline void golden_decide(Golden &s) {
+// (the two halves of an iteration of golden, :70-90: has the bracket closed; move it to the right or to the left)
+__host__ __device__ inline bool golden_closed(const Golden &s) {
+  return !(fabs(s.x3 - s.x0) > kGoldenTol * (fabs(s.x1) + fabs(s.x2)));
+}
+__host__ __device__ inline void golden_shift(Golden &s, bool right) {
   const double C = (3.0 - sqrt(5.0)) / 2.0, R = 1.0 - C;
+  if (right) { s.x0 = s.x1; s.x1 = s.x2; s.x2 = R * s.x1 + C * s.x3; s.f1 = s.f2; s.alpha = s.x2; s.pending = 2; }
+  else { s.x3 = s.x2; s.x2 = s.x1; s.x1 = R * s.x2 + C * s.x0; s.f2 = s.f1; s.alpha = s.x1; s.pending = 1; }
+}
+__host__ __device__ inline void golden_decide(Golden &s) {
   if (s.phase == 3) return;
   if (s.phase == 0) { s.alpha = s.x1; s.pending = 1; }
   else if (s.phase == 1) { s.alpha = s.x2; s.pending = 2; }
   else {
-    if (!(fabs(s.x3 - s.x0) > kGoldenTol * (fabs(s.x1) + fabs(s.x2)))) {
+    if (golden_closed(s)) {
       s.result = (s.f1 < s.f2) ? s.x1 : s.x2;
       s.phase = 3;
       return;
     }
-    if (s.f2 < s.f1) { s.x0 = s.x1; s.x1 = s.x2; s.x2 = R * s.x1 + C * s.x3; s.f1 = s.f2; s.alpha = s.x2; s.pending = 2; }
-    else { s.x3 = s.x2; s.x2 = s.x1; s.x1 = R * s.x2 + C * s.x0; s.f2 = s.f1; s.alpha = s.x1; s.pending = 1; }
+    golden_shift(s, s.f2 < s.f1);
   }
   s.bw_eval = s.bcur * (s.alpha * s.alpha);
+}
+// SPECULATIVE rounds (loo_round_spec_kernel).  Which point golden evaluates after the one in flight depends on that
+// evaluation only through ONE comparison, so both candidates are known beforehand and a launch can evaluate three points
+// -- the one in flight's successor is then already there, whichever way the comparison goes -- and the search advances two
+// evaluations per launch.  golden_book_blind: the booking of the evaluation in flight as far as it does not need the
+// result (the drift of the leaf variance, the counter).  golden_candidate: the state as it will be when the comparison
+// comes out `right`; phase 3 = the bracket closes first, there is no such candidate.
+__host__ __device__ inline void golden_book_blind(Golden &s) {
+  const double a2 = s.alpha * s.alpha;
+  s.bcur = (s.bcur * a2) / a2;
+  s.nevals += 1;
+  if (s.phase < 2) s.phase += 1;
+  s.pending = 0;
+}
+__host__ __device__ inline Golden golden_candidate(Golden s, bool right) {
+  golden_book_blind(s);
+  if (s.phase < 2) { golden_decide(s); return s; }  // (the opening: x2 follows x1 whatever x1 gave)
+  if (golden_closed(s)) { s.phase = 3; return s; }
+  golden_shift(s, right);
+  s.bw_eval = s.bcur * (s.alpha * s.alpha);
+  return s;
+}
+// The prologue of a speculative launch: book what the previous launch evaluated -- the point in flight (shares in part[0])
+// and, when it evaluated candidates too, the one the comparison picks (part[1]: right, or the second opening probe;
+// part[2]: left) -- and decide again: `s` leaves with the next certain evaluation pending, or finished.
+__host__ __device__ inline void golden_advance_spec(Golden &s, const double *part0, const double *part1, const double *part2,
+                                                    int nfb) {
+  if (s.phase == 3) return;
+  if (s.pending) {
+    const int ph = s.phase;
+    golden_book(s, part0, nfb);
+    const bool right = s.f2 < s.f1;  // (what golden_decide is about to branch on, once the opening is over)
+    golden_decide(s);
+    if (s.phase == 3) return;
+    if (s.spec) {
+      golden_book(s, (ph < 2 || right) ? part1 : part2, nfb);
+      golden_decide(s);
+      if (s.phase == 3) return;
+    }
+  } else {
+    golden_decide(s);  // (a batch starts: nothing in flight)
+  }
+  s.spec = 1;
 }
 
 // Bounding interval (centre, half-range) of the 1-D ball-tree node that covers the sorted ranks
@@ -391,8 +441,8 @@ __global__ __launch_bounds__(kPrepThreads) void loocv_prep_kernel(const double *
                                                                  unsigned *__restrict__ arrivals, int ntiles) {
   extern __shared__ double sm[];
   const int d = blockIdx.x;
-  if (static_cast<int>(threadIdx.x) < ntiles)  // (the rounds' slot counters, both probes of the joint first launch)
-    arrivals[(d * ntiles + threadIdx.x) * kCounterStride] = arrivals[((D + d) * ntiles + threadIdx.x) * kCounterStride] = 0;
+  if (static_cast<int>(threadIdx.x) < ntiles)  // (the rounds' slot counters: up to three probes per launch)
+    for (int p = 0; p < 3; ++p) arrivals[((p * D + d) * ntiles + threadIdx.x) * kCounterStride] = 0;
   int64_t P = 1;
   while (P < N) P <<= 1;
   double *xs = sm;              // [P] sorted marginal (padded with +inf)
@@ -473,6 +523,7 @@ struct LooRound {
   double w;               // the common weight of every point (kde!(points) has none of its own)
   double sqrt_2pi;        // pow(2 pi, 1/2) as the host's libm rounds it
   int chunks_per_group, ngroups, nfb, D, round;
+  int spec;               // speculative rounds (loo_round_spec_kernel): three sets of slots / counters, shares [2][3][D][nfb]
 };
 
 // Round, first launch: advance the search of this block's dimension, then the all-pairs leave-one-out sums
@@ -703,6 +754,50 @@ __global__ __launch_bounds__(kTile *kPairWaves) void loo_round_pairs_kernel(cons
   pairs_item(r, ps, d, blockIdx.x * kPairWaves + wave, lane, sBw, sExpTab);
 }
 
+// A SPECULATIVE round (golden_advance_spec above): blockIdx.z = probe * D + dimension; probe 0 evaluates the point that is
+// certain, probes 1 and 2 the two points one of which golden will ask for next (FIRST: the opening, probes 0 and 1 = x1 and
+// x2).  Every probe has slots, counters and shares of its own; the shares are double-buffered by launch parity.  Chosen by
+// the host when three evaluations still fit the chip a few wavefronts deep (small marginals: a round is then mostly its
+// fixed ~12 us of launch, prologue and hand-over, and two evaluations per launch nearly halve the search: 6 x 1000 points
+// 0.36 -> 0.2x ms); the numbers golden sees are those of the plain rounds, bit for bit (same tiles, same order).
+template <bool FIRST>
+__global__ __launch_bounds__(kTile *kPairWaves) void loo_round_spec_kernel(const LooRound r) {
+  __shared__ double sExpTab[256];
+  __shared__ double sPart[3][kFusedMaxN / kTile];
+  __shared__ double sBw;
+  __shared__ int sPhase;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int probe = static_cast<int>(blockIdx.z) / r.D, d = static_cast<int>(blockIdx.z) - probe * r.D;
+  const int64_t plane = static_cast<int64_t>(r.D) * r.nfb;
+  PairSet ps;
+  ps.slots = r.partial + probe * (static_cast<int64_t>(r.D) * r.ngroups * r.ngroups * kTile);
+  ps.arrivals = r.arrivals + probe * (r.D * r.ngroups * kCounterStride);
+  ps.shares = r.hpart + (static_cast<int64_t>((r.round + 1) & 1) * 3 + probe) * plane + static_cast<int64_t>(d) * r.nfb;
+  if (threadIdx.x < 256) sExpTab[threadIdx.x] = kExp2Tab256[threadIdx.x];
+  if constexpr (!FIRST) {
+    if (static_cast<int>(threadIdx.x) < r.nfb)
+      for (int p = 0; p < 3; ++p)
+        sPart[p][threadIdx.x] = r.hpart[(static_cast<int64_t>(r.round & 1) * 3 + p) * plane + static_cast<int64_t>(d) * r.nfb + threadIdx.x];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    Golden s = r.state[(r.round & 1) * r.D + d];
+    if constexpr (FIRST) {
+      golden_decide(s);  // x1
+      s.spec = 1;
+    } else {
+      golden_advance_spec(s, sPart[0], sPart[1], sPart[2], r.nfb);
+    }
+    if (blockIdx.x == 0 && probe == 0) r.state[((r.round + 1) & 1) * r.D + d] = s;
+    if (probe > 0 && s.phase != 3) s = golden_candidate(s, probe == 1);
+    sBw = s.bw_eval;
+    sPhase = s.phase;
+  }
+  __syncthreads();
+  if (sPhase == 3) return;  // this dimension's search is over, or the bracket closes before this candidate
+  pairs_item(r, ps, d, blockIdx.x * kPairWaves + wave, lane, sBw, sExpTab);
+}
+
 // Round, second launch: p_q = w * (sum over groups) / norm / (1 - w); block partial of W_q * log p_q
 // (evalAvgLogL, src/DualTree01.jl:450-474; a zero likelihood that carries weight makes it -Inf, :460-463).
 template <int THREADS>
@@ -737,6 +832,27 @@ __global__ void loo_finalize_kernel(const LooRound r) {
   const int d = threadIdx.x;
   if (d >= r.D) return;
   Golden s = r.state[(r.round & 1) * r.D + d];
+  if (r.spec) {  // speculative rounds: up to two evaluations to book (golden_advance_spec, stopping short of a new evaluation)
+    const int64_t plane = static_cast<int64_t>(r.D) * r.nfb;
+    const double *part = r.hpart + static_cast<int64_t>(r.round & 1) * 3 * plane + static_cast<int64_t>(d) * r.nfb;
+    if (s.phase != 3 && s.pending) {
+      const int ph = s.phase;
+      golden_book(s, part, r.nfb);
+      const bool right = s.f2 < s.f1;
+      Golden next = s;
+      golden_decide(next);
+      if (next.phase != 3 && s.spec) {
+        s = next;
+        golden_book(s, part + ((ph < 2 || right) ? 1 : 2) * plane, r.nfb);
+        next = s;
+        golden_decide(next);
+      }
+      if (next.phase == 3) s = next;
+    }
+    s.spec = 0;
+    r.state[(r.round & 1) * r.D + d] = s;
+    return;
+  }
   golden_book(s, r.hpart + (static_cast<int64_t>(r.round & 1) * r.D + d) * r.nfb, r.nfb);
   Golden next = s;
   golden_decide(next);
@@ -787,10 +903,16 @@ int kdehip::auto_bandwidth_run(int D, int64_t N, const double *points, const dou
   const size_t off_x = al(sizeof(double) * N * D);
   const size_t off_part = al(off_x + sizeof(double) * N * D);
   r.joint = pairs ? 1 : 0;
-  const size_t off_h = al(off_part + sizeof(double) * D * r.ngroups * (pairs ? (r.joint ? 2 : 1) * int64_t(ntiles) * kTile : N));
-  const size_t off_state = al(off_h + sizeof(double) * 4 * D * r.nfb);
+  // speculative rounds (three evaluations per launch, two of them booked: loo_round_spec_kernel) while three evaluations
+  // are still only a few wavefronts per SIMD: D T (T/2 + 1) tile pairs per evaluation on 4 SIMDs per CU
+  // (KDEHIP_LOOCV_SPEC=<k>: up to k tile pairs per CU and evaluation; 0 = never; default 8)
+  static const int spec_per_cu = [] { const char *e = std::getenv("KDEHIP_LOOCV_SPEC"); return e && e[0] ? std::atoi(e) : 8; }();
+  const int pair_items = ntiles * (ntiles / 2 + 1);  // per dimension: the diagonal and the offsets 1 .. T/2 of every tile
+  r.spec = (pairs && static_cast<int64_t>(D) * pair_items <= int64_t(spec_per_cu) * device_cu_count()) ? 1 : 0;
+  const size_t off_h = al(off_part + sizeof(double) * D * r.ngroups * (pairs ? 3 * int64_t(ntiles) * kTile : N));
+  const size_t off_state = al(off_h + sizeof(double) * 6 * D * r.nfb);
   const size_t off_arr = al(off_state + sizeof(Golden) * 2 * D);
-  const size_t total = off_arr + (pairs ? sizeof(unsigned) * 2 * D * ntiles * kCounterStride : 0);
+  const size_t total = off_arr + (pairs ? sizeof(unsigned) * 3 * D * ntiles * kCounterStride : 0);
   DevBuf dev;
   KDEHIP_CHECK(dev.alloc(total));
   unsigned char *base = dev.as<unsigned char>();
@@ -846,7 +968,7 @@ int kdehip::auto_bandwidth_run(int D, int64_t N, const double *points, const dou
     for (auto &t2 : th) t2.join();
     KDEHIP_CHECK(hipMemcpyAsync(const_cast<double *>(r.x), xo.data(), sizeof(double) * D * N, hipMemcpyHostToDevice, st));
     KDEHIP_CHECK(hipMemcpyAsync(r.state, g.data(), sizeof(Golden) * D, hipMemcpyHostToDevice, st));
-    if (pairs) KDEHIP_CHECK(hipMemsetAsync(r.arrivals, 0, sizeof(unsigned) * 2 * D * ntiles * kCounterStride, st));
+    if (pairs) KDEHIP_CHECK(hipMemsetAsync(r.arrivals, 0, sizeof(unsigned) * 3 * D * ntiles * kCounterStride, st));
     KDEHIP_CHECK(hipStreamSynchronize(st));  // (xo and g are pageable and leave scope)
   }
   auto t_prep = tnow();
@@ -857,12 +979,16 @@ int kdehip::auto_bandwidth_run(int D, int64_t N, const double *points, const dou
   int rounds = 0, batches = 0;
   const dim3 gridA(static_cast<unsigned>(qblocks), static_cast<unsigned>(r.ngroups), static_cast<unsigned>(D));
   const dim3 gridB(static_cast<unsigned>(r.nfb), static_cast<unsigned>(D));
-  const int pair_items = ntiles * (ntiles / 2 + 1);  // per dimension: the diagonal and the offsets 1 .. T/2 of every tile
   const dim3 gridP(static_cast<unsigned>((pair_items + kPairWaves - 1) / kPairWaves), 1, static_cast<unsigned>(D));
   const dim3 gridP2(gridP.x, 1, static_cast<unsigned>(2 * D));  // the joint first launch
-  for (int batch = r.joint ? 19 : 20; batches < 16; batch = 8) {  // (20 evaluations: the first launch of `pairs` runs two)
+  const dim3 gridS2(gridP.x, 1, static_cast<unsigned>(2 * D)), gridS3(gridP.x, 1, static_cast<unsigned>(3 * D));
+  // (20 evaluations in the first batch: the first launch of `pairs` runs two; speculative launches book two each)
+  for (int batch = r.spec ? 10 : (r.joint ? 19 : 20); batches < 16; batch = r.spec ? 4 : 8) {
     for (int k = 0; k < batch; ++k) {
-      if (pairs) {
+      if (r.spec) {
+        if (r.round == 0) hipLaunchKernelGGL(loo_round_spec_kernel<true>, gridS2, dim3(kTile * kPairWaves), 0, st, r);
+        else hipLaunchKernelGGL(loo_round_spec_kernel<false>, gridS3, dim3(kTile * kPairWaves), 0, st, r);
+      } else if (pairs) {
         if (r.joint && r.round == 0) hipLaunchKernelGGL(loo_round_pairs_kernel<1>, gridP2, dim3(kTile * kPairWaves), 0, st, r);
         else if (r.joint && r.round == 1) hipLaunchKernelGGL(loo_round_pairs_kernel<2>, gridP, dim3(kTile * kPairWaves), 0, st, r);
         else hipLaunchKernelGGL(loo_round_pairs_kernel<0>, gridP, dim3(kTile * kPairWaves), 0, st, r);

@@ -177,17 +177,20 @@ def test_fused_loocv_rounds_equal_the_two_launch_rounds():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = []
-    for two in ("0", "1"):
-        env = dict(os.environ, KDEHIP_LOOCV_TWO_LAUNCH=two, PYTHONPATH=root)
+    # the library's choice (speculative rounds -- three evaluations per launch, csrc/evaluate.hip loo_round_spec_kernel -- for
+    # the smaller marginals, plain one-launch rounds for the larger), plain one-launch rounds everywhere, two-launch rounds
+    for extra in ({}, {"KDEHIP_LOOCV_SPEC": "0"}, {"KDEHIP_LOOCV_TWO_LAUNCH": "1"}):
+        env = dict(os.environ, PYTHONPATH=root, **extra)
         out = subprocess.run([sys.executable, "-c", _TWO_LAUNCH_SCRIPT], cwd=root, env=env, capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stdout[-1000:] + out.stderr[-3000:]
         line = [ln for ln in out.stdout.splitlines() if ln.startswith("RESULT ")][-1]
         res.append(json.loads(line[7:]))
-    assert res[0].keys() == res[1].keys()
-    for k in res[0]:
-        (b0, n0), (b1, n1) = res[0][k], res[1][k]
-        assert n0 == n1, (k, n0, n1)
-        assert np.allclose(b0, b1, rtol=1e-9, atol=0.0), (k, b0, b1)
+    for other in res[:2]:
+        assert other.keys() == res[2].keys()
+        for k in other:
+            (b0, n0), (b1, n1) = other[k], res[2][k]
+            assert n0 == n1, (k, n0, n1)
+            assert np.allclose(b0, b1, rtol=1e-9, atol=0.0), (k, b0, b1)
 
 
 def test_concurrent_searches_share_the_device():
