@@ -157,8 +157,9 @@ int kdehip_product_sample_philox_host(kdehip_product *plan, int64_t Np, int Nite
  * Negative = error code. */
 int64_t kdehip_product_fallback_count(kdehip_product *plan);
 /* Diagnostic: fp32 screening of the deep levels (fp64 plans of 2..4 or 8 densities with every dimension active): on a
- * level whose fp64 tiles are streamed through LDS one at a time, the plan also holds the level's tiles in fp32, resident in
- * LDS together; a draw step evaluates the frontier in packed fp32 with a rigorous bound on the error of its cumulative
+ * level whose fp64 tiles are streamed or chunked through LDS, the plan also holds the level's tiles in fp32 -- resident in
+ * LDS together, streamed one per step, or in chunks, whichever fits; up to 128 entries per lane --; a draw step evaluates
+ * the frontier in packed fp32 with a rigorous bound on the error of its cumulative
  * sums and keeps the fp32 decision only when the uniform draw is farther than that bound from every boundary it could
  * cross -- otherwise the step is repeated in fp64.  Labels and points are those of the fp64 arithmetic bit for bit
  * (csrc/screen_device.hpp).  levels: how many levels of the plan are screened; steps / repeats: label draws
@@ -372,7 +373,9 @@ int kdehip_evaluate(const kdehip_density *bd, const double *pos, int64_t Nq, int
 /* kdehip_auto_bandwidth: the bandwidth `kde!(points)` selects (src/KDE01.jl:3-27): per dimension,
  * `ksize` of the 1-D marginal = golden-section search (tol 1e-2) over the leave-one-out
  * log-likelihood (src/CrossValidation.jl:15-120).  points: D x N column-major; bw_out: D standard
- * deviations; nevals (optional): number of likelihood evaluations. */
+ * deviations; nevals (optional): number of likelihood evaluations -- the reference's count: for the smaller marginals
+ * the search evaluates the two possible successors of the point in flight in the same launch (csrc/evaluate.hip
+ * loo_round_spec_kernel); the ones golden does not ask for are neither booked nor counted. */
 int kdehip_auto_bandwidth(int64_t D, int64_t N, const double *points, double *bw_out, int32_t *nevals,
                           int device);
 /* `kde!(points)` in one call (src/KDE01.jl:3-27: LOOCV bandwidth per dimension, then kde!(points, bwds)): the host tree
