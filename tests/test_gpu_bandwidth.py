@@ -194,22 +194,23 @@ def test_fused_loocv_rounds_equal_the_two_launch_rounds():
 
 
 def test_concurrent_searches_share_the_device():
-    """Two host threads searching at once on their own streams (the slots, counters and search states of a call live in
+    """Three host threads searching at once on their own streams (the slots, counters and search states of a call live in
     its own device block): both must return what a lone search returns."""
     import threading
     rng = np.random.default_rng(77)
-    data = [synth_mixture(rng, 3, 1500), synth_mixture(rng, 3, 1500)]
+    # (3 x 1500: speculative rounds; 6 x 2048: plain one-launch rounds; 2 x 300: speculative, a few tiles)
+    data = [synth_mixture(rng, 3, 1500), synth_mixture(rng, 6, 2048), synth_mixture(rng, 2, 300)]
     alone = [kdehip.auto_bandwidth(x) for x in data]
-    got = [None, None]
+    got = [None] * len(data)
 
     def work(i):
         for _ in range(6):
             got[i] = kdehip.auto_bandwidth(data[i])
 
-    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(data))]
     for t in th:
         t.start()
     for t in th:
         t.join()
-    for i in range(2):
+    for i in range(len(data)):
         assert np.array_equal(got[i], alone[i]), i
