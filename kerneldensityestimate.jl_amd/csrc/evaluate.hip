@@ -290,8 +290,8 @@ constexpr double kGoldenTol = 1e-2;  // ksize, src/CrossValidation.jl:116
 constexpr int kCounterStride = 32;   // loo_round_pairs_kernel's slot counters: a 128-byte line each (neighbours in one line
                                      // make it bounce between the XCDs' L2s)
 constexpr int kPrepThreads = 1024;
-constexpr int64_t kPrepMaxN = kLoocvPrepMaxN;  // marginals up to this size are prepared on the device (LDS: 40 bytes per point
-                                               // of the next power of two: 80 KiB; 4096 points would need all 160 KiB plus the statics)
+constexpr int64_t kPrepMaxN = kLoocvPrepMaxN;  // marginals up to this size are prepared on the device (LDS: 48 bytes per point
+                                               // of the next power of two: 96 KiB; 4096 points would need more than the CU has)
 
 // State of one 1-D golden-section search (golden, src/CrossValidation.jl:44-98) + what ksize needs around it.
 struct Golden {
@@ -422,25 +422,19 @@ void interval_stats(const double *xs, int64_t low, int64_t high, int64_t leaf0, 
   if (v < min2r) min2r = v;
 }
 
-// The rank interval [low, high] (0-based ranks) of node `t` at depth `d` of the median-split tree over n ranks
-// (children of [low, high]: [low, split], [split+1, high] with split = floor((low+high)/2) on the reference's
-// 1-based leaf ids N+1..2N, :371).  Returns false if the node does not exist (an ancestor is a single leaf).
-__device__ inline bool node_interval(int64_t n, int d, int t, int64_t &low, int64_t &high) {
-  low = 0; high = n - 1;
-  for (int b = d - 1; b >= 0; --b) {
-    if (low == high) return false;
-    const int64_t split = ((low + n + 1) + (high + n + 1)) / 2 - (n + 1);  // same rounding as on the 1-based ids
-    if ((t >> b) & 1) low = split + 1; else high = split;
-  }
-  return true;
-}
-
+#ifdef KDEHIP_PREP_STAMPS  // (diagnostic builds: s_memtime at the phase boundaries of block 0, scripts/prep_stamps.py)
+__device__ unsigned long long g_prep_stamps[8];
+#define PSTAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_prep_stamps[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PSTAMP(k) do {} while (0)
+#endif
 // One block per dimension: x_d in original order to `xo`, sort in LDS, interval arithmetic, initial search state.
 __global__ __launch_bounds__(kPrepThreads) void loocv_prep_kernel(const double *__restrict__ points, int64_t N, int D,
                                                                  double *__restrict__ xo, Golden *__restrict__ state,
                                                                  unsigned *__restrict__ arrivals, int ntiles) {
   extern __shared__ double sm[];
   const int d = blockIdx.x;
+  PSTAMP(0);
   if (static_cast<int>(threadIdx.x) < ntiles)  // (the rounds' slot counters: up to three probes per launch)
     for (int p = 0; p < 3; ++p) arrivals[((p * D + d) * ntiles + threadIdx.x) * kCounterStride] = 0;
   int64_t P = 1;
@@ -448,41 +442,92 @@ __global__ __launch_bounds__(kPrepThreads) void loocv_prep_kernel(const double *
   double *xs = sm;              // [P] sorted marginal (padded with +inf)
   double *cen = sm + P;         // [2][P] centre of the nodes of two consecutive depths
   double *hal = sm + 3 * P;     // [2][P] half-range
+  // rank interval [low, high] of every node of the median-split tree, heap order (node t of depth dd at 2^dd + t; low >
+  // high: the node does not exist), laid out TOP-DOWN once -- it depends on N only -- instead of being walked down from the
+  // root by every node of every depth (node_interval: a dependent chain of up to 11 64-bit steps per node and depth, 12 of
+  // the kernel's 24 us at 1000 points; profiles/r05_experiments.md section 13)
+  unsigned short *ilo = reinterpret_cast<unsigned short *>(sm + 5 * P);  // [2P]
+  unsigned short *ihi = ilo + 2 * P;                                     // [2P]
   __shared__ double s_min[kPrepThreads / 64];
-  for (int64_t i = threadIdx.x; i < P; i += kPrepThreads) {
-    const double v = i < N ? points[i * D + d] : INFINITY;
-    xs[i] = v;
-    if (i < N) xo[static_cast<int64_t>(d) * N + i] = v;
-  }
-  __syncthreads();
-  // bitonic sort, ascending.  Compare-exchange number c of a stage works on (i, i + j), i = c with a 0 bit inserted at
-  // bit log2(j): for j <= 64 the 64 exchanges c = 64w .. 64w+63 of wavefront w stay inside elements 128w .. 128w+127,
-  // whatever j is -- consecutive stages with j <= 64 read only what the SAME wavefront wrote, and a wavefront's LDS
-  // accesses execute in order, so only the stages with j >= 128 (10 of the 66 at 2048 points) sit between barriers.
-  const int Pi = static_cast<int>(P);
-  for (int k = 2; k <= Pi; k <<= 1)
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      if (j >= 64) __syncthreads();  // (j = 64 follows a wider stage, or starts a phase whose input other wavefronts wrote)
-      for (int c = threadIdx.x; c < Pi / 2; c += kPrepThreads) {
-        const int i = ((c & ~(j - 1)) << 1) | (c & (j - 1));
-        const int l = i | j;
-        const double a = xs[i], b = xs[l];
-        const bool up = (i & k) == 0;
-        if ((a > b) == up) { xs[i] = b; xs[l] = a; }
+  // every thread keeps its element(s) of the marginal in registers: element tid, and tid + 1024 when P = 2048
+  const int Pi = static_cast<int>(P), tid = threadIdx.x;
+  const bool two = Pi > kPrepThreads;
+  const int e0 = tid, e1 = tid + kPrepThreads;
+  double v0 = INFINITY, v1 = INFINITY;  // (padding: +inf sorts to the end)
+  if (e0 < N) { v0 = points[static_cast<int64_t>(e0) * D + d]; xo[static_cast<int64_t>(d) * N + e0] = v0; }
+  if (two && e1 < N) { v1 = points[static_cast<int64_t>(e1) * D + d]; xo[static_cast<int64_t>(d) * N + e1] = v1; }
+  PSTAMP(1);
+  // Bitonic sort, ascending.  A stage pairs element i with i ^ j.  For j <= 32 the partner sits in the same wavefront, 32
+  // lanes away at most: the two exchange through the cross-lane network and each keeps the smaller or the larger (45 of
+  // the 55 stages at 1024 points; through LDS such a stage was two dependent reads and two divergent writes, ~450 cycles
+  // against ~200).  j = 1024 pairs a thread's own two elements.  The stages in between (j = 64 .. 512) go through LDS, one
+  // thread per pair, one barrier each.
+  auto lane_stage = [&](double &v, int e, int k, int j) {
+    const double p = __shfl_xor(v, j);
+    const bool up = (e & k) == 0, lower = (e & j) == 0;
+    v = (up == lower) ? fmin(v, p) : fmax(v, p);
+  };
+  for (int k = 2; k <= Pi; k <<= 1) {
+    if (k > 64) {
+      if (k > kPrepThreads) {  // j = 1024 (the last phase of 2048 elements: ascending everywhere)
+        const double lo = fmin(v0, v1), hi = fmax(v0, v1);
+        v0 = lo; v1 = hi;
       }
-      __builtin_amdgcn_wave_barrier();
+      if (e0 < Pi) xs[e0] = v0;
+      if (two) xs[e1] = v1;
+      for (int j = (k >> 1) < 512 ? (k >> 1) : 512; j >= 64; j >>= 1) {
+        __syncthreads();
+        for (int c = tid; c < Pi / 2; c += kPrepThreads) {
+          const int i = ((c & ~(j - 1)) << 1) | (c & (j - 1));
+          const int l = i | j;
+          const double a = xs[i], b = xs[l];
+          const bool up = (i & k) == 0;
+          if ((a > b) == up) { xs[i] = b; xs[l] = a; }
+        }
+      }
+      __syncthreads();
+      if (e0 < Pi) v0 = xs[e0];
+      if (two) v1 = xs[e1];
     }
+    for (int j = (k >> 1) < 32 ? (k >> 1) : 32; j >= 1; j >>= 1) {
+      lane_stage(v0, e0, k, j);
+      if (two) lane_stage(v1, e1, k, j);
+    }
+  }
+  if (e0 < Pi) xs[e0] = v0;
+  if (two) xs[e1] = v1;
   __syncthreads();
+  PSTAMP(2);
   int depth = 0;
   while ((int64_t(1) << depth) < N) ++depth;  // the deepest level that can hold a node
+  {
+    const int n = static_cast<int>(N);
+    if (threadIdx.x == 0) { ilo[1] = 0; ihi[1] = static_cast<unsigned short>(n - 1); }
+    __syncthreads();
+    for (int dd = 0; dd < depth; ++dd) {
+      const int cnt = 1 << dd;
+      for (int t = threadIdx.x; t < cnt; t += kPrepThreads) {
+        const int low = ilo[cnt + t], high = ihi[cnt + t];
+        const int c = 2 * (cnt + t);
+        if (low >= high) {  // a leaf, or no node: no children
+          ilo[c] = ilo[c + 1] = 1; ihi[c] = ihi[c + 1] = 0;
+        } else {
+          const int split = ((low + n + 1) + (high + n + 1)) / 2 - (n + 1);  // same rounding as on the 1-based ids (:371)
+          ilo[c] = static_cast<unsigned short>(low); ihi[c] = static_cast<unsigned short>(split);
+          ilo[c + 1] = static_cast<unsigned short>(split + 1); ihi[c + 1] = static_cast<unsigned short>(high);
+        }
+      }
+      __syncthreads();
+    }
+  }
   double vmin = INFINITY;
   for (int dd = depth; dd >= 0; --dd) {
     double *c0 = cen + (dd & 1) * P, *h0 = hal + (dd & 1) * P;
     const double *c1 = cen + ((dd + 1) & 1) * P, *h1 = hal + ((dd + 1) & 1) * P;
-    const int64_t cnt = int64_t(1) << dd;
-    for (int64_t t = threadIdx.x; t < cnt && t < P; t += kPrepThreads) {
-      int64_t low, high;
-      if (!node_interval(N, dd, static_cast<int>(t), low, high)) continue;
+    const int cnt = 1 << dd;
+    for (int t = threadIdx.x; t < cnt && t < P; t += kPrepThreads) {
+      const int low = ilo[cnt + t], high = ihi[cnt + t];
+      if (low > high) continue;  // no such node (an ancestor is a single leaf)
       if (low == high) { c0[t] = xs[low]; h0[t] = 0.0; continue; }
       const double cL = c1[2 * t], rL = h1[2 * t], cR = c1[2 * t + 1], rR = h1[2 * t + 1];
       const double upA = cL + rL, upB = cR + rR, dnA = cL - rL, dnB = cR - rR;
@@ -495,6 +540,7 @@ __global__ __launch_bounds__(kPrepThreads) void loocv_prep_kernel(const double *
     }
     __syncthreads();
   }
+  PSTAMP(3);
   for (int off = 32; off > 0; off >>= 1) vmin = fmin(vmin, __shfl_down(vmin, off));
   if ((threadIdx.x & 63) == 0) s_min[threadIdx.x >> 6] = vmin;
   __syncthreads();
@@ -506,6 +552,7 @@ __global__ __launch_bounds__(kPrepThreads) void loocv_prep_kernel(const double *
     golden_init(g, m, sqrt((2.0 * half_root) * (2.0 * half_root)));
     state[d] = g;
   }
+  PSTAMP(4);
 }
 
 constexpr int kLooThreads = 256;  // queries per block
@@ -946,8 +993,8 @@ int kdehip::auto_bandwidth_run(int D, int64_t N, const double *points, const dou
     int64_t P = 1;
     while (P < N) P <<= 1;
     KDEHIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(loocv_prep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     static_cast<int>(sizeof(double) * 5 * P)));  // up to 80 KiB; per call = per device
-    hipLaunchKernelGGL(loocv_prep_kernel, dim3(D), dim3(kPrepThreads), sizeof(double) * 5 * P, st, d_points ? d_points : d_pts, N, D,
+                                     static_cast<int>(sizeof(double) * 6 * P)));  // up to 96 KiB; per call = per device
+    hipLaunchKernelGGL(loocv_prep_kernel, dim3(D), dim3(kPrepThreads), sizeof(double) * 6 * P, st, d_points ? d_points : d_pts, N, D,
                        const_cast<double *>(r.x), r.state, r.arrivals, ntiles);
     KDEHIP_CHECK(hipGetLastError());
   } else {
@@ -1066,3 +1113,9 @@ extern "C" int kdehip_make_density_auto(int64_t D, int64_t N, const double *poin
   return kdehip_density_set_bandwidth(D, N, bw_out, D, weights, left_child, right_child, means, bandwidth, bandwidthMin,
                                       bandwidthMax);
 }
+
+#ifdef KDEHIP_PREP_STAMPS
+extern "C" int kdehip_debug_prep_stamps(unsigned long long *out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prep_stamps), sizeof(unsigned long long) * 8) == hipSuccess ? 0 : -5;
+}
+#endif
