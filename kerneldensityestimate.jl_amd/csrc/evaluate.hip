@@ -517,8 +517,10 @@ __global__ __launch_bounds__(kPrepThreads) void loocv_prep_kernel(const double *
           ilo[c + 1] = static_cast<unsigned short>(split + 1); ihi[c + 1] = static_cast<unsigned short>(high);
         }
       }
-      __syncthreads();
+      // (up to 64 children: written and read by wavefront 0 alone, whose LDS accesses execute in order -- no block barrier)
+      if (2 * cnt > 64) __syncthreads(); else __builtin_amdgcn_wave_barrier();
     }
+    __syncthreads();
   }
   double vmin = INFINITY;
   for (int dd = depth; dd >= 0; --dd) {
@@ -538,7 +540,7 @@ __global__ __launch_bounds__(kPrepThreads) void loocv_prep_kernel(const double *
       const double v = sqrt((2.0 * half) * (2.0 * half));
       if (v < vmin) vmin = v;
     }
-    __syncthreads();
+    if (cnt > 64) __syncthreads(); else __builtin_amdgcn_wave_barrier();  // (as above: the levels of wavefront 0 alone)
   }
   PSTAMP(3);
   for (int off = 32; off > 0; off >>= 1) vmin = fmin(vmin, __shfl_down(vmin, off));
