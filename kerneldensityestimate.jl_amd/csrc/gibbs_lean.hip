@@ -872,14 +872,17 @@ template <typename T, int D, int M, int WAVES>
 static void launch_lean_waves(const PlanDev &plan, const RunArgs &args, hipStream_t stream) {
   const int64_t blocks = (args.Np + WAVES - 1) / WAVES;
   if constexpr (sizeof(T) == 8 && WAVES >= 8) {  // (4 chains per workgroup: small runs; chunked screen levels run in fp64 there)
-    if (plan.screened == 2 && args.use_screen) {
+    // 8 densities: the chunked-screen build is the only one (BASELINE config 4 needs it; a second build of these, the largest
+    // kernels of the library, would be another 1.6 minutes of build time for plans of 8 small densities)
+    if (M == 8 || (plan.screened == 2 && args.use_screen)) {
       hipLaunchKernelGGL((gibbs_lean_kernel<T, D, M, WAVES, false, true>), dim3(static_cast<unsigned>(blocks)), dim3(WAVES * 64),
                          0, stream, plan, args);
       return;
     }
   }
-  hipLaunchKernelGGL((gibbs_lean_kernel<T, D, M, WAVES>), dim3(static_cast<unsigned>(blocks)), dim3(WAVES * 64), 0,
-                     stream, plan, args);
+  if constexpr (!(sizeof(T) == 8 && WAVES >= 8 && M == 8))
+    hipLaunchKernelGGL((gibbs_lean_kernel<T, D, M, WAVES>), dim3(static_cast<unsigned>(blocks)), dim3(WAVES * 64), 0,
+                       stream, plan, args);
 }
 
 // wavefronts (= chains) per workgroup of this run
