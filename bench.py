@@ -322,6 +322,17 @@ def main():
             valu_floor = {"ms": floor_ms, "frac": floor_ms / kern_ms, "clock_ghz": vf["clock_ghz"],
                           "valu_cycles_per_chain": vf["cycles_per_chain"], "mix_per_chain": vf["mix_per_chain"],
                           "issue_cost_cycles": vf["issue_cost_cycles"], "source": vf["source"]}
+        # Occupancy of the vector pipe by the counters of the same committed profile: SQ_ACTIVE_INST_VALU of one wavefront x
+        # the wavefronts a SIMD holds (chains per workgroup / 4, one workgroup per CU: the LDS pool) / SQ_WAVE_CYCLES.
+        vb = prof.get("valu_busy")
+        valu_busy = None
+        if vb and vb.get("chains_profiled") == hi - lo:  # (the counters of another chain count are another occupancy)
+            geo = plan.launch_geometry(hi - lo)
+            wps = geo.get("waves", 0) / 4.0 if isinstance(geo, dict) else 0.0
+            if wps > 0:
+                valu_busy = {"frac": vb["active_inst_valu_quads_per_chain"] * wps / vb["wave_quads_per_chain"],
+                             "wavefronts_per_simd": wps, "source": vb["source"],
+                             "what": "SQ_ACTIVE_INST_VALU x wavefronts per SIMD / SQ_WAVE_CYCLES (replayed from the committed profile)"}
         out = {
             "metric": "gibbs_product_samples_per_sec",
             "value": Np_total * args.steps / elapsed,
@@ -359,6 +370,7 @@ def main():
                          # wavefronts issued per chain against the 4-cycle issue slots of their lifetime
                          "issue": prof.get("issue"),
                          "valu_floor": valu_floor,
+                         "valu_busy": valu_busy,
                          # traffic / issue / valu_floor above are REPLAYED from a committed rocprofv3 --pmc profile of this
                          # workload (counters cannot be collected inside a timed run); kernel_ms and frac are live
                          "profile_replayed_from": ({"file": prof.get("_file"), "tag": prof.get("tag"), "commit": prof.get("commit"),

@@ -85,6 +85,12 @@ for name in [f"traffic_{wl}.json"] + (["traffic_latest.json"] if wl == "c3" else
             t["valu_floor"] = {"cycles_per_chain": cycles_per_chain, "clock_ghz": ghz, "simds": simds,
                                "mix_per_chain": out["mix_per_chain"], "issue_cost_cycles": COST,
                                "source": f"profiles/{tag}_valu_mix.json + profiles/r02_valu_rates.txt"}
+            # what the counters say the vector pipe was doing: quads (4 cycles) in which a wavefront's vector instruction
+            # executed, against the quads the wavefront was resident (bench.py: x wavefronts per SIMD = occupancy of the pipe)
+            if per.get("SQ_ACTIVE_INST_VALU") and per.get("SQ_WAVE_CYCLES"):
+                t["valu_busy"] = {"active_inst_valu_quads_per_chain": per["SQ_ACTIVE_INST_VALU"],
+                                  "wave_quads_per_chain": per["SQ_WAVE_CYCLES"], "chains_profiled": nchains,
+                                  "source": f"profiles/{tag}_valu_mix.json"}
             json.dump(t, open(tl, "w"), indent=1)
     except (OSError, ValueError, KeyError):
         pass
