@@ -711,62 +711,14 @@ __device__ __forceinline__ void pairs_arrive(const LooRound &r, const PairSet &p
 
 // One tile pair (I, I + k mod T) of dimension d by one wavefront: the 64 x 64 kernel values, each computed once and added to
 // a row sum (own point) and a column sum (visiting point), left in the (tile, source tile) slots; then the arrival.
-// The own tile (I, I) with every pair of its points computed ONCE as well (the speculative rounds): the visiting copy at
-// distance s = 1 .. 31 adds the value to the row sum of the point at home and to a column sum that travels with the visitor,
-// distance 32 is its own mirror image (both lanes of a pair compute it, each for its own row), and the column sums are 32
-// lanes from home at the end -- 32 kernel values per lane instead of 63; the self term is never formed (:141).
-__device__ __forceinline__ double pairs_own_tile(const LooRound &r, int d, int I, int lane, double nhib, const double *sExpTab) {
-  const double *x = r.x + static_cast<int64_t>(d) * r.N;
-  const int64_t q = static_cast<int64_t>(I) * kTile + lane;
-  const double xi = q < r.N ? x[q] : INFINITY;
-  double xj = wave_rotate(q < r.N ? x[q] : -INFINITY);  // (a point at infinity contributes exp(-inf) = 0; opposite signs: no inf - inf)
-  double row = 0.0, col = 0.0;
-#pragma unroll 4
-  for (int s = 1; s < kTile / 2; ++s) {
-    const double dlt = xi - xj;
-    const double v = exp256_nonpos((dlt * dlt) * nhib, sExpTab);
-    row += v;
-    col = wave_rotate(col + v);
-    xj = wave_rotate(xj);
-  }
-  const double dlt = xi - xj;  // distance 32
-  row += exp256_nonpos((dlt * dlt) * nhib, sExpTab);
-  return row + __shfl_xor(col, kTile / 2);
-}
-
-// PAIRED: the item numbering of the speculative rounds -- the own tiles two to an item (pairs_own_tile: as much arithmetic
-// as one pair of different tiles), then the offsets 1 .. T/2 of every tile: (T + 1) / 2 + T (T / 2) items per dimension
-// instead of T (T / 2 + 1).  With three evaluations a launch the fewer, evener items are worth 15-18 % of a search at 1300-2000
-// points; the plain rounds of the larger marginals keep the own tile as an item of its own -- with the paired numbering a
-// round at 6 x 2048 took 22.4 us instead of 18.4 (profiles/r05_experiments.md section 15).
-template <bool PAIRED = false>
 __device__ __forceinline__ void pairs_item(const LooRound &r, const PairSet &ps, int d, int e, int lane, double bw_eval,
                                            const double *sExpTab) {
   const int T = r.ngroups, K = T / 2;
-  const double nhib = -0.5 / bw_eval;
-  int I, k;
-  if constexpr (PAIRED) {
-    const int nd = (T + 1) / 2;
-    if (e < nd) {
-      const int I0 = 2 * e, I2 = (2 * e + 1 < T) ? 2 * e + 1 : -1;
-      slot_store(ps.slots + ((static_cast<int64_t>(d) * T + I0) * T + I0) * kTile + lane, pairs_own_tile(r, d, I0, lane, nhib, sExpTab));
-      if (I2 >= 0)
-        slot_store(ps.slots + ((static_cast<int64_t>(d) * T + I2) * T + I2) * kTile + lane, pairs_own_tile(r, d, I2, lane, nhib, sExpTab));
-      slots_delivered();
-      pairs_arrive(r, ps, d, I0, I2, lane, bw_eval);
-      return;
-    }
-    if (K == 0) return;
-    const int ef = e - nd;
-    I = ef / K;
-    k = 1 + ef - I * K;
-  } else {
-    I = e / (K + 1);
-    k = e - I * (K + 1);
-  }
+  const int I = e / (K + 1), k = e - I * (K + 1);
   if (I >= T) return;
   if (2 * k == T && I >= K) return;  // even T, offset T/2: the partner tile holds this pair
   const int J = I + k < T ? I + k : I + k - T;
+  const double nhib = -0.5 / bw_eval;
   const double *x = r.x + static_cast<int64_t>(d) * r.N;
   const int64_t qi = static_cast<int64_t>(I) * kTile + lane, qj = static_cast<int64_t>(J) * kTile + lane;
   const double xi = qi < r.N ? x[qi] : INFINITY;
@@ -857,10 +809,8 @@ __global__ __launch_bounds__(kTile *kPairWaves) void loo_round_pairs_kernel(cons
 // the host when three evaluations still fit the chip a few wavefronts deep (small marginals: a round is then mostly its
 // fixed ~12 us of launch, prologue and hand-over, and two evaluations per launch nearly halve the search: 6 x 1000 points
 // 0.36 -> 0.2x ms); the numbers golden sees are those of the plain rounds, bit for bit (same tiles, same order).
-constexpr int kSpecWaves = 12;  // wavefronts (= items) per workgroup of the speculative rounds: three per SIMD (16: the gains of
-                                // the paired numbering stay away -- 6 x 1300: 0.361 against 0.308 ms, section 15 of the experiments)
 template <bool FIRST>
-__global__ __launch_bounds__(kTile *kSpecWaves) void loo_round_spec_kernel(const LooRound r) {
+__global__ __launch_bounds__(kTile *kPairWaves) void loo_round_spec_kernel(const LooRound r) {
   __shared__ double sExpTab[256];
   __shared__ double sPart[3][kFusedMaxN / kTile];
   __shared__ double sBw;
@@ -894,7 +844,7 @@ __global__ __launch_bounds__(kTile *kSpecWaves) void loo_round_spec_kernel(const
   }
   __syncthreads();
   if (sPhase == 3) return;  // this dimension's search is over, or the bracket closes before this candidate
-  pairs_item<true>(r, ps, d, blockIdx.x * kSpecWaves + wave, lane, sBw, sExpTab);
+  pairs_item(r, ps, d, blockIdx.x * kPairWaves + wave, lane, sBw, sExpTab);
 }
 
 // Round, second launch: p_q = w * (sum over groups) / norm / (1 - w); block partial of W_q * log p_q
@@ -1007,8 +957,7 @@ int kdehip::auto_bandwidth_run(int D, int64_t N, const double *points, const dou
   // (KDEHIP_LOOCV_SPEC=<k>: up to k tile pairs per CU and evaluation; 0 = never; default 8)
   static const int spec_per_cu = [] { const char *e = std::getenv("KDEHIP_LOOCV_SPEC"); return e && e[0] ? std::atoi(e) : 8; }();
   const int pair_items = ntiles * (ntiles / 2 + 1);  // per dimension: the diagonal and the offsets 1 .. T/2 of every tile
-  const int paired_items = (ntiles + 1) / 2 + ntiles * (ntiles / 2);  // ... with the own tiles two to an item (speculative rounds)
-  r.spec = (pairs && static_cast<int64_t>(D) * paired_items <= int64_t(spec_per_cu) * device_cu_count()) ? 1 : 0;
+  r.spec = (pairs && static_cast<int64_t>(D) * pair_items <= int64_t(spec_per_cu) * device_cu_count()) ? 1 : 0;
   const size_t off_h = al(off_part + sizeof(double) * D * r.ngroups * (pairs ? 3 * int64_t(ntiles) * kTile : N));
   const size_t off_state = al(off_h + sizeof(double) * 6 * D * r.nfb);
   const size_t off_arr = al(off_state + sizeof(Golden) * 2 * D);
@@ -1081,14 +1030,13 @@ int kdehip::auto_bandwidth_run(int D, int64_t N, const double *points, const dou
   const dim3 gridB(static_cast<unsigned>(r.nfb), static_cast<unsigned>(D));
   const dim3 gridP(static_cast<unsigned>((pair_items + kPairWaves - 1) / kPairWaves), 1, static_cast<unsigned>(D));
   const dim3 gridP2(gridP.x, 1, static_cast<unsigned>(2 * D));  // the joint first launch
-  const unsigned gsx = static_cast<unsigned>((paired_items + kSpecWaves - 1) / kSpecWaves);
-  const dim3 gridS2(gsx, 1, static_cast<unsigned>(2 * D)), gridS3(gsx, 1, static_cast<unsigned>(3 * D));
+  const dim3 gridS2(gridP.x, 1, static_cast<unsigned>(2 * D)), gridS3(gridP.x, 1, static_cast<unsigned>(3 * D));
   // (20 evaluations in the first batch: the first launch of `pairs` runs two; speculative launches book two each)
   for (int batch = r.spec ? 10 : (r.joint ? 19 : 20); batches < 16; batch = r.spec ? 4 : 8) {
     for (int k = 0; k < batch; ++k) {
       if (r.spec) {
-        if (r.round == 0) hipLaunchKernelGGL(loo_round_spec_kernel<true>, gridS2, dim3(kTile * kSpecWaves), 0, st, r);
-        else hipLaunchKernelGGL(loo_round_spec_kernel<false>, gridS3, dim3(kTile * kSpecWaves), 0, st, r);
+        if (r.round == 0) hipLaunchKernelGGL(loo_round_spec_kernel<true>, gridS2, dim3(kTile * kPairWaves), 0, st, r);
+        else hipLaunchKernelGGL(loo_round_spec_kernel<false>, gridS3, dim3(kTile * kPairWaves), 0, st, r);
       } else if (pairs) {
         if (r.joint && r.round == 0) hipLaunchKernelGGL(loo_round_pairs_kernel<1>, gridP2, dim3(kTile * kPairWaves), 0, st, r);
         else if (r.joint && r.round == 1) hipLaunchKernelGGL(loo_round_pairs_kernel<2>, gridP, dim3(kTile * kPairWaves), 0, st, r);
