@@ -313,6 +313,16 @@ int kdehip_profile_sampler_read(int device, void *stream, double *total_ms, int6
  * entries): a straggling device or link shows up as skew, a slow kernel as duration. */
 int kdehip_product_multi_timing(kdehip_product_multi *mp, double *kernel_ms, double *done_ms);
 
+/* The fp32 screen of the deep levels (csrc/screen_device.hpp) certifies its decisions with an error bound whose premise is
+ * that the hardware's v_rcp_f32, v_rsq_f32 and v_exp_f32 are within 1 ulp (a relative error of at most 2 u, u = 2^-24).
+ * This entry MEASURES that on `device`: over the `count` fp32 bit patterns from `first_bits` on it returns the largest
+ * error of instruction `which` against fp64 formed on the device -- 0: v_rcp_f32, 1: v_rsq_f32, 2: v_exp_f32 (2^x), each
+ * relative, in units of u; 3: |v_exp_f32(x) - 2^x| in units of 2^-126 (for x < -126, where the bound only needs "off by
+ * less than the smallest normal").  worst_bits / worst_result_bits (optional): the input with the largest error and the
+ * hardware's result for it.  tests/test_gpu_ulp.py sweeps the screen's whole input ranges with it.  Blocking. */
+int kdehip_selftest_fp32(int which, uint32_t first_bits, uint64_t count, int device, double *max_err,
+                         uint32_t *worst_bits, uint32_t *worst_result_bits);
+
 /* ---- (3) host twin of the device RNG ----------------------------------------------------------
  * Fills the arrays a caller would pass as randU / randN so that a streams-run (or the Julia
  * reference, via its randU=/randN= keywords, src/MSGibbs01.jl:661-662) consumes exactly the

@@ -106,6 +106,8 @@ SIGNATURES = {
                                      [C.POINTER(C.c_void_p)] * 13 + [C.c_int]),
     "kdehip_density_set_bandwidth": (C.c_int, [C.c_int64, C.c_int64, f64p, C.c_int64, f64p, i64p, i64p, f64p, f64p, f64p, f64p]),
     "kdehip_profile_sampler": (None, [C.c_int]),
+    "kdehip_selftest_fp32": (C.c_int, [C.c_int, C.c_uint32, C.c_uint64, C.c_int, f64p, C.POINTER(C.c_uint32),
+                                      C.POINTER(C.c_uint32)]),
     "kdehip_profile_sampler_read": (C.c_int, [C.c_int, C.c_void_p, f64p, i64p]),
     "kdehip_product_multi_timing": (C.c_int, [C.c_void_p, f64p, f64p]),
     "kdehip_density_from_device_points": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_int64, C.c_int64, C.c_int,

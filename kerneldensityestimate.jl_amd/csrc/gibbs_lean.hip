@@ -377,13 +377,14 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
     const float cf = static_cast<float>(cmin + cov), covf = static_cast<float>(cov);
     const float acen = fabsf(cen);
     const bool inr = (acen <= kScreenMaxAbsMean) && (covf <= static_cast<float>(kScreenMaxVar));  // (false for a NaN)
-    const bool ok = valid != 0.0f && __ballot(lane < D && !inr) == 0ull;
+    const bool ok0 = valid != 0.0f && __ballot(lane < D && !inr) == 0ull;
     const float t = fminf(mmax + acen, 2.0f * acen);
     float a2 = lane < D ? t * t * __builtin_amdgcn_rcpf(cf) : 0.0f;
     a2 += dpp_fetch<0x111, 0xF>(a2);  // row_shr:1, 2, 4: lane 7 holds the sum over the (at most 8) dimension lanes
     a2 += dpp_fetch<0x112, 0xF>(a2);
     a2 += dpp_fetch<0x114, 0xF>(a2);
     const float na = __builtin_sqrtf(lane_read(a2, 7)) * (kScreenU * kScreenSqrtC0 * 1.01f);
+    const bool ok = ok0 && na <= kScreenMaxNa;  // (the bound is linearised in na (1 + |x|): screen_device.hpp; false for a NaN)
     using SC = ScreenConst<D>;
     const float Bc = (kScreenLn2 * 1.01f) * (na + (ds.uniform_bw ? SC::kx_uni : SC::kx_node) * kScreenU);
     const float A = (kScreenLn2 * 1.01f) * na +
@@ -457,7 +458,9 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
         const float A = (kScreenLn2 * 1.01f) * na +
                         (static_cast<float>(((ds.B + 1) >> 1) + 9) + (ds.uniform_bw ? SC::vc_uni : SC::vc_node)) * kScreenU;
         const LdsPtr<float> rows32 = h32 + kScreenHeaderFloats;
-        if (ds.uniform_bw) {
+        if (!(na <= kScreenMaxNa)) {
+          // outside the regime the bound is linearised for (screen_device.hpp "Range checks"): the step runs in fp64
+        } else if (ds.uniform_bw) {
           ScreenEval<D, true> ev;
           ev.A = A; ev.Bc = Bc;
           const float ninv = -kScreenC0 * __builtin_amdgcn_rcpf(cf);

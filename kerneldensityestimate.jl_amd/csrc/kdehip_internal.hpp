@@ -144,6 +144,10 @@ constexpr int kScreenMaxRows = 64;           // rows per lane up to which a leve
 constexpr int kScreenMaxRowsChunked = 128;   // ... when its screen tiles are chunked (second pass from global memory, two rounds)
 constexpr float kScreenMaxAbsMean = 65536.0f;  // |m'_d|, |centre'_d| <= 2^16
 constexpr double kScreenMinVar = 1.0 / 128.0, kScreenMaxVar = 256.0;  // variances (tile, leave-one-out) in [2^-7, 2^8]
+// The bound's centring term is linear in na (1 + |x|) with a 1 % allowance for the second-order part and the margin's 5 %
+// (2.1 E against 2 E): exp(d) - 1 <= 1.06 d needs d = ln2 na (1 + |x|) <= 0.11, and |x| < 127 wherever a value is not
+// flushed to zero -- so na <= 2^-11 (d <= 0.044) keeps it rigorous; typical data have na ~ 2^-19.
+constexpr float kScreenMaxNa = 0x1p-11f;
 
 // Conditional table of density j on level l (see gibbs_kernel.hip "conditional tables"): rows of n+1
 // values (inclusive scan over the n frontier nodes, then the total).  Only levels whose frontier sizes

@@ -9,9 +9,10 @@
 #
 # or, to route every existing caller (`*`, IncrementalInference, ...) through the GPU:
 #
-#   KernelDensityEstimateHIP.enable!()      # overrides KernelDensityEstimate.prodAppxMSGibbsS, .gibbs1, kde!(points),
-#                                           # kde!(points, ks[, weights]) and evaluateDualTree: the WHOLE `*` -- product,
-#                                           # bandwidth search AND tree construction -- runs in libkdehip.so
+#   KernelDensityEstimateHIP.enable!()      # overrides KernelDensityEstimate.prodAppxMSGibbsS and .gibbs1 (the hot path)
+#   KernelDensityEstimateHIP.enable!(kde=true, trees=true, evaluate=true)
+#                                           # opt-in: also kde!(points), kde!(points, ks[, weights]) and evaluateDualTree,
+#                                           # i.e. the WHOLE `*` -- product, bandwidth search AND tree construction
 #
 # After enable!() a call of the reference's `prodAppxMSGibbsS` WITHOUT `randU=`/`randN=` (what `*` and every
 # JuliaRobotics caller does) no longer draws `rand(Np*Ndens*(Niter+2)*Nlevels)` / `randn(...)` on the host
@@ -315,8 +316,11 @@ builds_here(points, ks, addop, diffop) =
 
 `kde!(points, ks, weights)` / `kde!(points, ks)` (src/KDE01.jl:34-76 -> makeBallTreeDensity, src/BallTreeDensity01.jl:192-231
 -> buildTree!, src/BallTree01.jl:415-434) built by the library's pooled host builder (`kdehip_make_density`): the same
-twelve arrays as the reference's single-threaded quick-select gives, bit for bit (same split rule, swap order, node
-numbering and moment matching; pinned by the reference's own golden files).
+twelve arrays as the reference's single-threaded quick-select gives (same split rule, swap order, node numbering and
+moment matching; pinned by the reference's own golden files) -- bit for bit with unit weights (`kde!(points, ks)`).  With
+other weights the normalisation `weights ./ sum(weights)` (src/KDE01.jl:46) is a sequential sum in the library and a
+pairwise `@simd` sum in Julia: the total, hence every weight and moment-matched node, may differ in the last bit (which
+is why the override `enable!(trees=true)` installs hands only unit weights to the library).
 """
 function kde!(points::AbstractMatrix{<:Real}, ks::Vector{Float64}, weights::Union{Nothing,Vector{Float64}}=nothing)
   D, N = size(points)
@@ -415,7 +419,7 @@ function auto_bandwidth(points::AbstractMatrix{Float64}; device::Int=0)
 end
 
 """
-    enable!(; kde=true, trees=true, evaluate=true)
+    enable!(; kde=false, trees=false, evaluate=false)
 
 Route `KernelDensityEstimate.prodAppxMSGibbsS` and `KernelDensityEstimate.gibbs1` -- and with them `*` and every
 downstream caller -- through libkdehip.so (method overwrites).  A product called without `randU`/`randN`
@@ -424,13 +428,15 @@ explicit streams are consumed in the reference's order by the `gibbs1` override.
 stay reachable for non-Euclidean manifolds and for shapes beyond the compiled limits: they are invoked in the
 world age in which they were defined.
 
-The callers either side of the product are switched by keyword (all on by default): `kde` = `kde!(points)` (LOOCV
+The callers either side of the product are OPT-IN by keyword (all off by default: none of this file has been executed
+yet -- no Julia in the build image -- so the default keeps the blast radius at the two hot-path methods; switch them on
+once `oracle/julia_crosscheck.jl --shim` has passed on your installation): `kde` = `kde!(points)` (LOOCV
 bandwidth + tree in one library call), `trees` = `kde!(points, ks)` and `kde!(points, ks, weights)` (every tree of every
 caller built by the library's pooled builder instead of the reference's single-threaded quick-select), `evaluate` = both
 forms of `evaluateDualTree`.  An override whose reference method cannot be found by its signature (another version of
 KernelDensityEstimate.jl) is skipped with a warning: the reference method stays in place.
 """
-function enable!(; kde::Bool=true, trees::Bool=true, evaluate::Bool=true)
+function enable!(; kde::Bool=false, trees::Bool=false, evaluate::Bool=false)
   devicecount() > 0 || error("libkdehip: no MI355X visible; refusing to enable (no CPU fallback in the library)")
   ORIGINAL_GIBBS1[] === nothing || return nothing   # already enabled
   orig = KDE.gibbs1
@@ -513,8 +519,9 @@ function enable!(; kde::Bool=true, trees::Bool=true, evaluate::Bool=true)
   end
   kde_bww === nothing || @eval KDE function kde!(points::AbstractArray{<:Real,2}, ks::Array{Float64,1}, weights::Array{Float64,1},
                                                  addop=(+,), diffop=(-,))
-    if $(builds_here)(points, ks, addop, diffop) && length(weights) == size(points, 2)
-      return $(kde!)(points, ks, weights)
+    # (unit weights only -- what kde!(points, ks) passes: there `weights ./ sum(weights)` is exact in any summation order)
+    if $(builds_here)(points, ks, addop, diffop) && length(weights) == size(points, 2) && all(isone, weights)
+      return $(kde!)(points, ks, nothing)
     end
     return $(reference_kde_bww)(points, ks, weights, addop, diffop)
   end
@@ -541,9 +548,9 @@ end
 """
     overridden_methods()
 
-What `enable!()` replaces in `KernelDensityEstimate` (pinned by tests/test_julia_shim_syntax.py): after it, an unchanged
-caller of `*` runs product, bandwidth search, tree construction and evaluation in libkdehip.so -- no stage of `*` is left
-on the reference's single-threaded Julia path.
+What `enable!(kde=true, trees=true, evaluate=true)` replaces in `KernelDensityEstimate` (pinned by
+tests/test_julia_shim_syntax.py; plain `enable!()` replaces the first two): with all of them, an unchanged caller of `*`
+runs product, bandwidth search, tree construction and evaluation in libkdehip.so.
 """
 overridden_methods() = ["gibbs1", "prodAppxMSGibbsS", "kde!(points)", "kde!(points, ks)", "kde!(points, ks, weights)",
                         "evaluateDualTree(bd, pos::Array{Float64,2})", "evaluateDualTree(bd, pos::BallTreeDensity)"]

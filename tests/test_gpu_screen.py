@@ -130,6 +130,32 @@ def test_screen_range_rules(shift, scale, why):
     assert np.array_equal(res[0][1], oi) and np.array_equal(res[0][2], ol)
 
 
+def test_screen_linearisation_guard():
+    """Clusters thousands of bandwidths apart (coordinates ~ +-4000, sigma 0.2): the tiles pass the range checks (|m'| <=
+    2^16, variances >= 2^-7) but the centring term na = sqrt(c0) u |g / sigma| is ~4e-3, where the bound's linearised
+    exp(d) - 1 ~ d no longer holds.  The step must run in fp64 there (kScreenMaxNa): every screened step
+    of such a level is a repeat, and the results are the unscreened run's and the oracle's."""
+    D, Ns, Np, Niter = 6, [1000, 900, 1000], 192, 3
+    rng = np.random.default_rng(4242)
+    g, o = [], []
+    for N in Ns:
+        pts = synth_mixture(rng, D, N) + rng.choice([-4000.0, 4000.0], size=(D, 1)) * (rng.uniform(size=(D, N)) < 0.5)
+        g.append(kdehip.kde(pts, [0.2]))
+        o.append(oracle.OracleDensity(pts, [0.2]))
+    with kdehip.ProductPlan(g) as plan:
+        res = _run_variants(plan, Np, Niter, 29)
+        st = plan.screen_stats()
+        K, R = plan.randu_per_sample(Niter), plan.randn_per_sample()
+    for v in (5, 1):
+        for a, b in zip(res[0], res[v]):
+            assert np.array_equal(a, b), v
+    assert st["levels"] >= 1 and st["steps"] > 0, st
+    assert st["repeats"] == st["steps"], st
+    u, n = kdehip.philox_streams(29, 0, Np, K, R)
+    op, oi, ol = oracle.gibbs1(o, Np, Niter, u, n, want_labels=True)
+    assert np.array_equal(res[0][1], oi) and np.array_equal(res[0][2], ol)
+
+
 def test_screen_through_every_entry_point():
     """One-shot calls, caller streams, resident densities and the batched entry give the screened plan's result."""
     D, Ns, Np, Niter, seed = 6, [1000] * 4, 160, 4, 321
