@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define KDEHIP_VERSION 500 /* 0.5.0 */
+#define KDEHIP_VERSION 600 /* 0.6.0 */
 
 enum {
   KDEHIP_OK = 0,
@@ -202,7 +202,10 @@ const char *kdehip_product_kernel_name(const kdehip_product *plan, int64_t Np);
  * create).  Arrays from a stream-ordered pool (hipMallocAsync) or from virtual-memory mappings are reachable from a
  * peer only if the pool / mapping grants that device access (hipMemPoolSetAccess / hipMemSetAccess); the call looks at
  * every destination once per product and takes the copy path for anything it cannot show reachable
- * (KDEHIP_PEER_STORES=0 forces the copy path, =1 skips the look-up). */
+ * (KDEHIP_PEER_STORES=0 forces the copy path, =1 skips the look-up).  The verdicts are remembered per plan, keyed by the
+ * array's ADDRESS and the writing device: an array that is freed and re-allocated at the same address from another kind
+ * of allocator keeps its old verdict until kdehip_clear_cache() is called (which forgets all of them) -- a caller that
+ * switches allocators under a live plan calls it, or sets KDEHIP_PEER_STORES. */
 typedef struct kdehip_product_multi kdehip_product_multi;
 int kdehip_product_multi_create(kdehip_product_multi **out, int Ndens, const kdehip_density *trees, int ndims,
                                 const uint8_t *partialDimMask, int precision, int first_device, int ngpus);
@@ -267,6 +270,26 @@ int kdehip_density_from_device_points(kdehip_device_density **out, const double 
  * kdehip_prod_philox(seed) followed by kdehip_make_density_auto on the host. */
 int kdehip_mul_device(kdehip_device_density **out, int Ndens, kdehip_device_density *const *trees, uint64_t seed,
                       int addEntropy, double *bw_out, int32_t *nevals);
+/* `*` for MANY products in one call -- the reference's serving shape: a belief-propagation sweep calls `*`
+ * (src/MSGibbs01.jl:707-726) dozens of times on densities of 100-300 points (test/runtests.jl:189-201), and one at a time
+ * each is a blocking call of >= 10 dependent small launches.  Here every product is sampled by the batched sampler
+ * (kdehip_prod_philox_batch), the LOOCV bandwidth searches (src/KDE01.jl:3-27, src/CrossValidation.jl:44-120) of all
+ * outputs of one size advance in the SAME launches, the ball trees (src/BallTree01.jl:415-434) are built by the pooled
+ * host builder under the searches from ONE copy of all matrices, and the nprod resulting densities share one device block.
+ * out[i] (nprod handles, each freed with kdehip_density_free; the shared block goes with the last of them) is bit for
+ * bit the density kdehip_mul_device(items[i]) returns: same product (Philox keyed by items[i].seed), same bandwidth
+ * search evaluations, same tree.  bw_out (optional): nprod rows of KDEHIP_MAX_DIMS doubles, row i = the D bandwidths of
+ * result i; nevals (optional): nprod counts.  An item with one density and addEntropy = 0 is the reference's shortcut
+ * (:713-716); results of fewer than 2 or more than 2048 points are built by a call of their own inside this one.
+ * All densities on one device.  Blocking, on the calling thread's stream.  On an error no handle is returned. */
+typedef struct kdehip_mul_item {
+  int32_t Ndens;
+  int32_t addEntropy;
+  kdehip_device_density *const *trees; /* Ndens handles */
+  uint64_t seed;
+} kdehip_mul_item;
+int kdehip_mul_device_batch(int nprod, const kdehip_mul_item *items, kdehip_device_density **out, double *bw_out,
+                            int32_t *nevals);
 /* The reference's arrays of a density the library built (the two entries above), shaped as in kdehip_make_density; any
  * pointer may be NULL; bw_out: its D LOOCV bandwidths (standard deviations).  A density that came from
  * kdehip_density_upload has no such mirror (KDEHIP_ERR_UNSUPPORTED): its arrays are the caller's. */
@@ -313,6 +336,13 @@ int kdehip_profile_sampler_read(int device, void *stream, double *total_ms, int6
  * entries): a straggling device or link shows up as skew, a slow kernel as duration. */
 int kdehip_product_multi_timing(kdehip_product_multi *mp, double *kernel_ms, double *done_ms);
 
+/* The callers either side of the product (section 5, 2d) are blocking entries on the calling thread's own stream: their
+ * device work cannot be bracketed from outside.  With kdehip_profile_sampler(1), the LOOCV bandwidth search (which = 0:
+ * preparation + every round of a search, per batch of rounds), kdehip_evaluate (which = 1: the partial and finish
+ * kernels) and the GPU tree builder (which = 2: kdehip_make_densities_device's kernel) bracket their launches with a pair
+ * of timing events; this returns the sum of those durations and the number of bracketed phases since the last read, and
+ * resets both (process-wide sums).  bench.py --frow reports them as kernel time. */
+int kdehip_profile_phase_read(int which, double *total_ms, int64_t *count);
 /* The fp32 screen of the deep levels (csrc/screen_device.hpp) certifies its decisions with an error bound whose premise is
  * that the hardware's v_rcp_f32, v_rsq_f32 and v_exp_f32 are within 1 ulp (a relative error of at most 2 u, u = 2^-24).
  * This entry MEASURES that on `device`: over the `count` fp32 bit patterns from `first_bits` on it returns the largest

@@ -9,7 +9,7 @@ from ._lib import KdeHipError, LIB_PATH, lib as _clib  # noqa: F401  (import fai
 from .density import (BallTree, BallTreeDensity, Ndim, Npts, density_from_arrays, getBW, getPoints,  # noqa: F401
                       getWeights, kde, kde_b, kde_batch)
 from .bandwidth import auto_bandwidth, evaluateDualTree, kde_auto  # noqa: F401
-from .product import (DeviceDensity, GbGlb, MultiProductPlan, ProductBatch, ProductPlan, gibbs1, makeEmptyGbGlb, mul, mul_device,  # noqa: F401
+from .product import (DeviceDensity, GbGlb, MultiProductPlan, ProductBatch, ProductPlan, gibbs1, makeEmptyGbGlb, mul, mul_device, mul_device_batch,  # noqa: F401
                       nlevels, philox_streams, prodAppxMSGibbsS, prodAppxMSGibbsS_batch, prodAppxMSGibbsS_device,
                       prodAppxMSGibbsS_resident)
 

@@ -39,6 +39,11 @@ class CBatchItem(C.Structure):
     ]
 
 
+class CMulItem(C.Structure):
+    """struct kdehip_mul_item"""
+    _fields_ = [("Ndens", C.c_int32), ("addEntropy", C.c_int32), ("trees", C.POINTER(C.c_void_p)), ("seed", C.c_uint64)]
+
+
 class CProductInfo(C.Structure):
     """struct kdehip_product_info_t"""
     _fields_ = [
@@ -106,6 +111,7 @@ SIGNATURES = {
                                      [C.POINTER(C.c_void_p)] * 13 + [C.c_int]),
     "kdehip_density_set_bandwidth": (C.c_int, [C.c_int64, C.c_int64, f64p, C.c_int64, f64p, i64p, i64p, f64p, f64p, f64p, f64p]),
     "kdehip_profile_sampler": (None, [C.c_int]),
+    "kdehip_profile_phase_read": (C.c_int, [C.c_int, f64p, i64p]),
     "kdehip_selftest_fp32": (C.c_int, [C.c_int, C.c_uint32, C.c_uint64, C.c_int, f64p, C.POINTER(C.c_uint32),
                                       C.POINTER(C.c_uint32)]),
     "kdehip_profile_sampler_read": (C.c_int, [C.c_int, C.c_void_p, f64p, i64p]),
@@ -113,6 +119,7 @@ SIGNATURES = {
     "kdehip_density_from_device_points": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_int64, C.c_int64, C.c_int,
                                                     C.c_void_p, f64p, i32p]),
     "kdehip_mul_device": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p), C.c_uint64, C.c_int, f64p, i32p]),
+    "kdehip_mul_device_batch": (C.c_int, [C.c_int, C.POINTER(CMulItem), C.POINTER(C.c_void_p), f64p, i32p]),
     "kdehip_density_download": (C.c_int, [C.c_void_p, f64p, f64p, f64p, i64p, i64p, i64p, i64p, i64p, f64p, f64p, f64p,
                                           f64p, f64p]),
     "kdehip_prod_philox_batch": (C.c_int, [C.c_int, C.POINTER(CBatchItem), C.c_int, C.c_void_p]),

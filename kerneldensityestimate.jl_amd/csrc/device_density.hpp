@@ -1,6 +1,7 @@
 // device_density.hpp -- densities that live in HBM (pack_device.hip) and what the packers share.
 #pragma once
 
+#include <atomic>
 #include <cstdint>
 #include <vector>
 
@@ -68,6 +69,19 @@ int children_first_order(int64_t N, const int64_t *left_child, const int64_t *ri
 
 }  // namespace kdehip
 
+namespace kdehip {
+// The densities a batched call builds (kdehip_mul_device_batch) live in ONE device block and ONE pinned mirror -- one
+// allocation, two uploads for the whole batch instead of three small transfers per density --, released when the last of
+// them is freed.
+struct SharedBlock {
+  std::atomic<int> refs{0};
+  void *d_blob = nullptr;
+  size_t blob_bytes = 0;
+  void *mirror = nullptr;
+  size_t mirror_bytes = 0;
+};
+}  // namespace kdehip
+
 // A BallTreeDensity resident on one device (include/kdehip.h "densities in HBM").
 struct kdehip_device_density {
   int device = 0;
@@ -95,6 +109,7 @@ struct kdehip_device_density {
     int64_t *left = nullptr, *right = nullptr, *lowest = nullptr, *highest = nullptr, *perm = nullptr;
   } m;
   double bw[KDEHIP_MAX_DIMS] = {};  // its LOOCV bandwidth (standard deviations)
+  kdehip::SharedBlock *shared = nullptr;  // set: d_blob / mirror above are null, the arrays live in the batch's blocks
 };
 
 namespace kdehip {

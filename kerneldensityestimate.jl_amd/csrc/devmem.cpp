@@ -8,6 +8,7 @@
 // into the cache has synchronised its stream / finished its blocking copies before doing so.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstddef>
 #include <cstdlib>
 #include <mutex>
@@ -15,6 +16,7 @@
 #include <vector>
 
 #include "kdehip_internal.hpp"
+#include "phase_timer.hpp"
 
 namespace kdehip {
 namespace {
@@ -126,8 +128,40 @@ void cached_host_free(void *p, size_t bytes) {
 }  // namespace kdehip
 
 
+namespace kdehip {
+// kdehip_profile_phase_read (phase_timer.hpp)
+namespace {
+std::atomic<int> g_phases_on{0};
+std::mutex g_phase_mu;
+double g_phase_ms[kPhaseCount] = {};
+int64_t g_phase_n[kPhaseCount] = {};
+}  // namespace
+bool profile_phases_on() { return g_phases_on.load(std::memory_order_relaxed) != 0; }
+void profile_phases_set(bool on) { g_phases_on.store(on ? 1 : 0, std::memory_order_relaxed); }
+void profile_phase_add(int which, double ms) {
+  if (which < 0 || which >= kPhaseCount) return;
+  std::lock_guard<std::mutex> lock(g_phase_mu);
+  g_phase_ms[which] += ms;
+  g_phase_n[which] += 1;
+}
+}  // namespace kdehip
+
+extern "C" int kdehip_profile_phase_read(int which, double *total_ms, int64_t *count) {
+  using namespace kdehip;
+  if (which < 0 || which >= kPhaseCount) return set_error(KDEHIP_ERR_ARG, "kdehip_profile_phase_read: which in 0..2");
+  std::lock_guard<std::mutex> lock(g_phase_mu);
+  if (total_ms) *total_ms = g_phase_ms[which];
+  if (count) *count = g_phase_n[which];
+  g_phase_ms[which] = 0.0;
+  g_phase_n[which] = 0;
+  return KDEHIP_OK;
+}
+
+namespace kdehip { std::atomic<unsigned> g_peer_epoch{0}; }  // product.hip: the multi-GPU plans' peer-store verdicts
+
 extern "C" void kdehip_clear_cache(void) {
   using namespace kdehip;
+  g_peer_epoch.fetch_add(1, std::memory_order_relaxed);  // verdicts cached per raw pointer do not survive a cache reset
   kdehip::drain_pending();  // product.hip: plans of enqueue-only device products still waiting for their work
   int cur = 0;
   const bool have_cur = hipGetDevice(&cur) == hipSuccess;

@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cmath>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -23,6 +24,8 @@
 #include "fastexp.hpp"
 #include "host_pool.hpp"
 #include "kdehip_internal.hpp"
+#include "loocv_search.hpp"
+#include "phase_timer.hpp"
 
 namespace kdehip {
 namespace {
@@ -262,15 +265,18 @@ extern "C" int kdehip_evaluate(const kdehip_density *bd, const double *pos, int6
   fp.partial = d_part.as<double>(); fp.w = d_w;
   fp.out_idx = leave_one_out ? reinterpret_cast<const int64_t *>(du + o_q) : nullptr;
   fp.out = d_out.as<double>(); fp.inv_norm = 1.0 / gauss_norm(bw, D); fp.Nq = Nq; fp.nchunks = nchunks;
+  PhaseTimer timer(kPhaseEvaluate, st);
   rc = launch_partial_dims(D, eb, 1, Nq, gs.ngroups, leave_one_out ? 1 : 0, st);
   if (rc != KDEHIP_OK) { (void)hipStreamSynchronize(st); return rc; }
   hipLaunchKernelGGL(eval_finish_kernel, dim3(static_cast<unsigned>((Nq + 255) / 256), 1), dim3(256), 0, st,
                      fb, leave_one_out ? 1 : 0);
   hipError_t le = hipGetLastError();
+  timer.stop();
   if (le == hipSuccess) le = hipMemcpyAsync(h + o_out, d_out.p, sizeof(double) * Nq, hipMemcpyDeviceToHost, st);
   const hipError_t se = hipStreamSynchronize(st);  // (also before the scratch goes back to the cache on an error)
   KDEHIP_CHECK(le);
   KDEHIP_CHECK(se);
+  timer.collect();
   std::memcpy(p_out, h + o_out, sizeof(double) * Nq);
   return KDEHIP_OK;
 }
@@ -391,7 +397,9 @@ __host__ __device__ inline void golden_advance_spec(Golden &s, const double *par
     golden_decide(s);
     if (s.phase == 3) return;
     if (s.spec) {
-      golden_book(s, (ph < 2 || right) ? part1 : part2, nfb);
+      // (ph == 0: the opening, x2 follows x1 whatever x1 gave -- part1; from then on the candidate the comparison picks.  A
+      // launch that evaluates candidates with x2 in flight (ph == 1) books by `right` like any other: ADVICE round 5)
+      golden_book(s, (ph == 0 || right) ? part1 : part2, nfb);
       golden_decide(s);
       if (s.phase == 3) return;
     }
@@ -428,15 +436,19 @@ __device__ unsigned long long g_prep_stamps[8];
 #else
 #define PSTAMP(k) do {} while (0)
 #endif
-// One block per dimension: x_d in original order to `xo`, sort in LDS, interval arithmetic, initial search state.
-__global__ __launch_bounds__(kPrepThreads) void loocv_prep_kernel(const double *__restrict__ points, int64_t N, int D,
+// One block per marginal: x_d in original order to `xo`, sort in LDS, interval arithmetic, initial search state.  `points`
+// = nm / D matrices of D x N (column-major, one behind the other): block m prepares dimension m % D of matrix m / D -- the
+// D searches of one kde!(points), or those of a whole batch of them (kdehip_mul_device_batch) in the same launch.
+__global__ __launch_bounds__(kPrepThreads) void loocv_prep_kernel(const double *__restrict__ points, int64_t N, int D, int nm,
                                                                  double *__restrict__ xo, Golden *__restrict__ state,
                                                                  unsigned *__restrict__ arrivals, int ntiles) {
   extern __shared__ double sm[];
-  const int d = blockIdx.x;
+  const int m = blockIdx.x, mat = m / D, d = m - mat * D;
+  points += static_cast<int64_t>(mat) * N * D;
+  xo += static_cast<int64_t>(m - d) * N;  // (xo[d * N + e] below: marginal m at xo[m * N])
   PSTAMP(0);
   if (static_cast<int>(threadIdx.x) < ntiles)  // (the rounds' slot counters: up to three probes per launch)
-    for (int p = 0; p < 3; ++p) arrivals[((p * D + d) * ntiles + threadIdx.x) * kCounterStride] = 0;
+    for (int p = 0; p < 3; ++p) arrivals[((p * nm + m) * ntiles + threadIdx.x) * kCounterStride] = 0;
   int64_t P = 1;
   while (P < N) P <<= 1;
   double *xs = sm;              // [P] sorted marginal (padded with +inf)
@@ -547,12 +559,12 @@ __global__ __launch_bounds__(kPrepThreads) void loocv_prep_kernel(const double *
   if ((threadIdx.x & 63) == 0) s_min[threadIdx.x >> 6] = vmin;
   __syncthreads();
   if (threadIdx.x == 0) {
-    double m = s_min[0];
-    for (int i = 1; i < kPrepThreads / 64; ++i) m = fmin(m, s_min[i]);
+    double mn = s_min[0];
+    for (int i = 1; i < kPrepThreads / 64; ++i) mn = fmin(mn, s_min[i]);
     const double half_root = hal[0];
     Golden g;
-    golden_init(g, m, sqrt((2.0 * half_root) * (2.0 * half_root)));
-    state[d] = g;
+    golden_init(g, mn, sqrt((2.0 * half_root) * (2.0 * half_root)));
+    state[blockIdx.x] = g;
   }
   PSTAMP(4);
 }
@@ -878,7 +890,7 @@ __global__ __launch_bounds__(THREADS) void loo_round_entropy_kernel(const LooRou
 // After the last round of a batch: book its evaluation; a search that thereby converges is finished here, one that
 // goes on keeps the booked state (no evaluation pending) and decides again in the next batch's first round.
 __global__ void loo_finalize_kernel(const LooRound r) {
-  const int d = threadIdx.x;
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
   if (d >= r.D) return;
   Golden s = r.state[(r.round & 1) * r.D + d];
   if (r.spec) {  // speculative rounds: up to two evaluations to book (golden_advance_spec, stopping short of a new evaluation)
@@ -892,7 +904,7 @@ __global__ void loo_finalize_kernel(const LooRound r) {
       golden_decide(next);
       if (next.phase != 3 && s.spec) {
         s = next;
-        golden_book(s, part + ((ph < 2 || right) ? 1 : 2) * plane, r.nfb);
+        golden_book(s, part + ((ph == 0 || right) ? 1 : 2) * plane, r.nfb);
         next = s;
         golden_decide(next);
       }
@@ -910,17 +922,49 @@ __global__ void loo_finalize_kernel(const LooRound r) {
 
 }  // namespace
 
-// The search itself, on stream `st` of the current device (the caller holds the DeviceGuard).  `points` are the host's
-// copy of the D x N matrix, `d_points` (optional) the same matrix already in HBM -- the product a resident chain has just
-// sampled (kdehip_density_from_device_points): the marginals are then prepared straight from it, nothing is uploaded.
-// Marginals beyond kPrepMaxN points are prepared on the host and need `points`.
-int kdehip::auto_bandwidth_run(int D, int64_t N, const double *points, const double *d_points, void *stream,
-                               double *bw_out, int32_t *nevals_out, const std::function<void()> *overlap) {
-  hipStream_t st = static_cast<hipStream_t>(stream);
+// The search itself, on stream `st` of the current device (the caller holds the DeviceGuard), for `nb` matrices of D x N
+// at once: nm = nb * D one-dimensional searches advance in the SAME launches (a launch indexes marginals, not dimensions:
+// blockIdx.z, the state, the shares and the counters are all per marginal, and every marginal's tiles and summation order
+// depend on N only -- so each search is, bit for bit, the one a call of its own would run).  `points` is the host's copy
+// of the (single) matrix, `d_points` the matrices already in HBM, one behind the other -- the product(s) a resident chain
+// has just sampled (kdehip_density_from_device_points, kdehip_mul_device_batch): the marginals are then prepared straight
+// from them, nothing is uploaded.  Marginals beyond kPrepMaxN points are prepared on the host and need `points` (nb = 1).
+// Protocol: begin (everything up to the first batch of rounds enqueued) -> the caller synchronises `st` -> poll (done, or
+// the next batch enqueued) -> ... -> finish (bandwidths).  Several searches (different N) can be in flight on one stream.
+class kdehip::LoocvSearch {
+ public:
+  int begin(int nb, int D, int64_t N, const double *points, const double *d_points, hipStream_t st);
+  int poll(bool *done);
+  int finish(double *bw_out, int32_t *nevals_out);  // bw_out: nb * D standard deviations; nevals_out: nb counts
+  int rounds() const { return rounds_; }
+  int batches() const { return batches_; }
+  ~LoocvSearch() {
+    // an early error return waits for whatever has been enqueued before the device block and the pinned block go back
+    // to the caches (where another thread may be handed them at once); on the regular path the stream is already idle
+    if (armed_) (void)hipStreamSynchronize(st_);
+    if (pin_) cached_host_free(pin_, pin_bytes_);
+  }
+
+ private:
+  int enqueue_batch(int batch);
+  LooRound r_{};
+  DevBuf dev_;
+  void *pin_ = nullptr;
+  size_t pin_bytes_ = 0;
+  Golden *h_state_ = nullptr;
+  hipStream_t st_ = nullptr;
+  bool armed_ = false, pairs_ = false;
+  std::unique_ptr<PhaseTimer> timer_;  // kdehip_profile_phase_read(0): the batch of rounds in flight
+  int nb_ = 0, D_ = 0, nm_ = 0, rounds_ = 0, batches_ = 0, pair_items_ = 0;
+  int64_t qblocks_ = 0;
+};
+
+int kdehip::LoocvSearch::begin(int nb, int D, int64_t N, const double *points, const double *d_points, hipStream_t st) {
+  st_ = st; nb_ = nb; D_ = D;
+  const int nm = nm_ = nb * D;
+  if (nb < 1 || nm > 21000) return set_error(KDEHIP_ERR_UNSUPPORTED, "bandwidth search: too many marginals for one launch");
   if (!points && !(d_points && N <= kPrepMaxN)) return set_error(KDEHIP_ERR_ARG, "auto_bandwidth_run: no host copy of the points");
-  const bool timing = std::getenv("KDEHIP_TIMING") != nullptr;
-  auto tnow = [] { return std::chrono::steady_clock::now(); };
-  auto t_begin = tnow();
+  if (nb > 1 && !(d_points && N <= kPrepMaxN)) return set_error(KDEHIP_ERR_ARG, "bandwidth search: a batch needs device matrices of at most 2048 points");
 
   // weights: ones -> /N (kde!(points,[1.0])) -> renormalised by the marginal's kde! (src/KDE01.jl:46,152): every
   // point ends up with the same weight w1
@@ -930,74 +974,63 @@ int kdehip::auto_bandwidth_run(int D, int64_t N, const double *points, const dou
   const double w1 = w0 / t;
 
   const int64_t nchunks = (N + kLooChunk - 1) / kLooChunk;
-  const int64_t qblocks = (N + kLooThreads - 1) / kLooThreads;
-  int64_t want = (int64_t(8) * device_cu_count() + qblocks * D - 1) / (qblocks * D);  // ~8 blocks per CU
+  const int64_t qblocks = qblocks_ = (N + kLooThreads - 1) / kLooThreads;
+  int64_t want = (int64_t(8) * device_cu_count() + qblocks * nm - 1) / (qblocks * nm);  // ~8 blocks per CU
   if (want < 1) want = 1;
   if (want > kEvalMaxGroups) want = kEvalMaxGroups;
   if (want > nchunks) want = nchunks;
-  LooRound r{};
+  LooRound &r = r_;
   // one fused launch per round (KDEHIP_LOOCV_TWO_LAUNCH=1: the two-launch rounds at every size -- what the tests pin the
   // fused hand-over against)
   static const bool two_launch = [] { const char *e = std::getenv("KDEHIP_LOOCV_TWO_LAUNCH"); return e && e[0] == '1'; }();
-  const bool pairs = N <= kFusedMaxN && !two_launch;
+  const bool pairs = pairs_ = N <= kFusedMaxN && !two_launch;
   const int ntiles = static_cast<int>((N + kTile - 1) / kTile);
   r.chunks_per_group = static_cast<int>((nchunks + want - 1) / want);
   r.ngroups = pairs ? ntiles : static_cast<int>((nchunks + r.chunks_per_group - 1) / r.chunks_per_group);
   r.nfb = pairs ? ntiles : static_cast<int>(qblocks);  // blocks of the log-likelihood reduction (64 / 256 queries each)
-  r.N = N; r.D = D; r.w = w1; r.round = 0;
+  r.N = N; r.D = nm; r.w = w1; r.round = 0;
   r.sqrt_2pi = std::pow(2.0 * M_PI, 1 / 2.0);
 
-  // one device block: [points N*D | xo D*N | partial D*ngroups*N | hpart D*nfb | state 2*D]
+  // one device block: [points N*D | xo nm*N | partial nm*ngroups*N | hpart nm*nfb | state 2*nm]
   auto al = [](size_t x) { return (x + 255) & ~static_cast<size_t>(255); };
-  const size_t off_x = al(sizeof(double) * N * D);
-  const size_t off_part = al(off_x + sizeof(double) * N * D);
+  const size_t off_x = al(d_points ? 0 : sizeof(double) * N * D);
+  const size_t off_part = al(off_x + sizeof(double) * N * nm);
   r.joint = pairs ? 1 : 0;
   // speculative rounds (three evaluations per launch, two of them booked: loo_round_spec_kernel) while three evaluations
-  // are still only a few wavefronts per SIMD: D T (T/2 + 1) tile pairs per evaluation on 4 SIMDs per CU
+  // are still only a few wavefronts per SIMD: nm T (T/2 + 1) tile pairs per evaluation on 4 SIMDs per CU
   // (KDEHIP_LOOCV_SPEC=<k>: up to k tile pairs per CU and evaluation; 0 = never; default 8)
   static const int spec_per_cu = [] { const char *e = std::getenv("KDEHIP_LOOCV_SPEC"); return e && e[0] ? std::atoi(e) : 8; }();
-  const int pair_items = ntiles * (ntiles / 2 + 1);  // per dimension: the diagonal and the offsets 1 .. T/2 of every tile
-  r.spec = (pairs && static_cast<int64_t>(D) * pair_items <= int64_t(spec_per_cu) * device_cu_count()) ? 1 : 0;
-  const size_t off_h = al(off_part + sizeof(double) * D * r.ngroups * (pairs ? 3 * int64_t(ntiles) * kTile : N));
-  const size_t off_state = al(off_h + sizeof(double) * 6 * D * r.nfb);
-  const size_t off_arr = al(off_state + sizeof(Golden) * 2 * D);
-  const size_t total = off_arr + (pairs ? sizeof(unsigned) * 3 * D * ntiles * kCounterStride : 0);
-  DevBuf dev;
-  KDEHIP_CHECK(dev.alloc(total));
-  unsigned char *base = dev.as<unsigned char>();
+  const int pair_items = pair_items_ = ntiles * (ntiles / 2 + 1);  // per marginal: the diagonal and the offsets 1 .. T/2 of every tile
+  r.spec = (pairs && static_cast<int64_t>(nm) * pair_items <= int64_t(spec_per_cu) * device_cu_count()) ? 1 : 0;
+  const size_t off_h = al(off_part + sizeof(double) * nm * r.ngroups * (pairs ? 3 * int64_t(ntiles) * kTile : N));
+  const size_t off_state = al(off_h + sizeof(double) * 6 * nm * r.nfb);
+  const size_t off_arr = al(off_state + sizeof(Golden) * 2 * nm);
+  const size_t total = off_arr + (pairs ? sizeof(unsigned) * 3 * nm * ntiles * kCounterStride : 0);
+  KDEHIP_CHECK(dev_.alloc(total));
+  unsigned char *base = dev_.as<unsigned char>();
   double *d_pts = reinterpret_cast<double *>(base);
   r.x = reinterpret_cast<double *>(base + off_x);
   r.partial = reinterpret_cast<double *>(base + off_part);
   r.hpart = reinterpret_cast<double *>(base + off_h);
   r.state = reinterpret_cast<Golden *>(base + off_state);
   r.arrivals = reinterpret_cast<unsigned *>(base + off_arr);
-  struct Pinned {
-    void *p = nullptr;
-    size_t n = 0;
-    ~Pinned() { if (p) cached_host_free(p, n); }
-  } pin;
-  pin.n = std::max(sizeof(double) * N * D, sizeof(Golden) * 2 * D);
-  KDEHIP_CHECK(cached_host_malloc(&pin.p, pin.n));
-  Golden *h_state = static_cast<Golden *>(pin.p);
-  // Declared after the two blocks, i.e. destroyed before them: an early error return below waits for whatever has
-  // been enqueued before the device block and the pinned block go back to the caches (where another thread may be
-  // handed them at once).  On the regular path the stream is already idle.
-  struct DrainOnExit {
-    hipStream_t st;
-    ~DrainOnExit() { (void)hipStreamSynchronize(st); }
-  } drain_on_exit{st};
+  pin_bytes_ = std::max(d_points ? size_t(0) : sizeof(double) * N * D, sizeof(Golden) * 2 * nm);
+  KDEHIP_CHECK(cached_host_malloc(&pin_, pin_bytes_));
+  h_state_ = static_cast<Golden *>(pin_);
+  armed_ = true;
+  timer_.reset(new PhaseTimer(kPhaseLoocv, st));
 
   if (N <= kPrepMaxN) {
     if (!d_points) {
-      std::memcpy(pin.p, points, sizeof(double) * N * D);
-      KDEHIP_CHECK(hipMemcpyAsync(d_pts, pin.p, sizeof(double) * N * D, hipMemcpyHostToDevice, st));
+      std::memcpy(pin_, points, sizeof(double) * N * D);
+      KDEHIP_CHECK(hipMemcpyAsync(d_pts, pin_, sizeof(double) * N * D, hipMemcpyHostToDevice, st));
     }
     int64_t P = 1;
     while (P < N) P <<= 1;
     KDEHIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(loocv_prep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      static_cast<int>(sizeof(double) * 6 * P)));  // up to 96 KiB; per call = per device
-    hipLaunchKernelGGL(loocv_prep_kernel, dim3(D), dim3(kPrepThreads), sizeof(double) * 6 * P, st, d_points ? d_points : d_pts, N, D,
-                       const_cast<double *>(r.x), r.state, r.arrivals, ntiles);
+    hipLaunchKernelGGL(loocv_prep_kernel, dim3(nm), dim3(kPrepThreads), sizeof(double) * 6 * P, st, d_points ? d_points : d_pts, N, D,
+                       nm, const_cast<double *>(r.x), r.state, r.arrivals, ntiles);
     KDEHIP_CHECK(hipGetLastError());
   } else {
     // large marginals: sort and interval arithmetic on the host (one thread per dimension), same state afterwards
@@ -1020,56 +1053,102 @@ int kdehip::auto_bandwidth_run(int D, int64_t N, const double *points, const dou
     if (pairs) KDEHIP_CHECK(hipMemsetAsync(r.arrivals, 0, sizeof(unsigned) * 3 * D * ntiles * kCounterStride, st));
     KDEHIP_CHECK(hipStreamSynchronize(st));  // (xo and g are pageable and leave scope)
   }
-  auto t_prep = tnow();
-
-  // (Round 5 built the whole search as ONE persistent launch -- workgroups that stay, a tile counter per dimension between
-  // the rounds: bit-identical and SLOWER, 457 against 410 us at 6 x 2048: noticing a counter from another XCD and fetching
-  // the shares behind it cost more than the 3.5 us launch gap they replace.  Removed; profiles/r05_experiments.md section 8.)
-  int rounds = 0, batches = 0;
-  const dim3 gridA(static_cast<unsigned>(qblocks), static_cast<unsigned>(r.ngroups), static_cast<unsigned>(D));
-  const dim3 gridB(static_cast<unsigned>(r.nfb), static_cast<unsigned>(D));
-  const dim3 gridP(static_cast<unsigned>((pair_items + kPairWaves - 1) / kPairWaves), 1, static_cast<unsigned>(D));
-  const dim3 gridP2(gridP.x, 1, static_cast<unsigned>(2 * D));  // the joint first launch
-  const dim3 gridS2(gridP.x, 1, static_cast<unsigned>(2 * D)), gridS3(gridP.x, 1, static_cast<unsigned>(3 * D));
   // (20 evaluations in the first batch: the first launch of `pairs` runs two; speculative launches book two each)
-  for (int batch = r.spec ? 10 : (r.joint ? 19 : 20); batches < 16; batch = r.spec ? 4 : 8) {
-    for (int k = 0; k < batch; ++k) {
-      if (r.spec) {
-        if (r.round == 0) hipLaunchKernelGGL(loo_round_spec_kernel<true>, gridS2, dim3(kTile * kPairWaves), 0, st, r);
-        else hipLaunchKernelGGL(loo_round_spec_kernel<false>, gridS3, dim3(kTile * kPairWaves), 0, st, r);
-      } else if (pairs) {
-        if (r.joint && r.round == 0) hipLaunchKernelGGL(loo_round_pairs_kernel<1>, gridP2, dim3(kTile * kPairWaves), 0, st, r);
-        else if (r.joint && r.round == 1) hipLaunchKernelGGL(loo_round_pairs_kernel<2>, gridP, dim3(kTile * kPairWaves), 0, st, r);
-        else hipLaunchKernelGGL(loo_round_pairs_kernel<0>, gridP, dim3(kTile * kPairWaves), 0, st, r);
-      } else {
-        hipLaunchKernelGGL(loo_round_partial_kernel, gridA, dim3(kLooThreads), 0, st, r);
-        hipLaunchKernelGGL(loo_round_entropy_kernel<kLooThreads>, gridB, dim3(kLooThreads), 0, st, r);
-      }
-      ++r.round;
-      ++rounds;
+  return enqueue_batch(r.spec ? 10 : (r.joint ? 19 : 20));
+}
+
+// (Round 5 built the whole search as ONE persistent launch -- workgroups that stay, a tile counter per dimension between
+// the rounds: bit-identical and SLOWER, 457 against 410 us at 6 x 2048: noticing a counter from another XCD and fetching
+// the shares behind it cost more than the 3.5 us launch gap they replace.  Removed; profiles/r05_experiments.md section 8.)
+int kdehip::LoocvSearch::enqueue_batch(int batch) {
+  LooRound &r = r_;
+  hipStream_t st = st_;
+  const unsigned nm = static_cast<unsigned>(nm_);
+  const dim3 gridA(static_cast<unsigned>(qblocks_), static_cast<unsigned>(r.ngroups), nm);
+  const dim3 gridB(static_cast<unsigned>(r.nfb), nm);
+  const dim3 gridP(static_cast<unsigned>((pair_items_ + kPairWaves - 1) / kPairWaves), 1, nm);
+  const dim3 gridP2(gridP.x, 1, 2 * nm);  // the joint first launch
+  const dim3 gridS2(gridP.x, 1, 2 * nm), gridS3(gridP.x, 1, 3 * nm);
+  for (int k = 0; k < batch; ++k) {
+    if (r.spec) {
+      if (r.round == 0) hipLaunchKernelGGL(loo_round_spec_kernel<true>, gridS2, dim3(kTile * kPairWaves), 0, st, r);
+      else hipLaunchKernelGGL(loo_round_spec_kernel<false>, gridS3, dim3(kTile * kPairWaves), 0, st, r);
+    } else if (pairs_) {
+      if (r.joint && r.round == 0) hipLaunchKernelGGL(loo_round_pairs_kernel<1>, gridP2, dim3(kTile * kPairWaves), 0, st, r);
+      else if (r.joint && r.round == 1) hipLaunchKernelGGL(loo_round_pairs_kernel<2>, gridP, dim3(kTile * kPairWaves), 0, st, r);
+      else hipLaunchKernelGGL(loo_round_pairs_kernel<0>, gridP, dim3(kTile * kPairWaves), 0, st, r);
+    } else {
+      hipLaunchKernelGGL(loo_round_partial_kernel, gridA, dim3(kLooThreads), 0, st, r);
+      hipLaunchKernelGGL(loo_round_entropy_kernel<kLooThreads>, gridB, dim3(kLooThreads), 0, st, r);
     }
-    hipLaunchKernelGGL(loo_finalize_kernel, dim3(1), dim3(64), 0, st, r);
-    KDEHIP_CHECK(hipGetLastError());
-    KDEHIP_CHECK(hipMemcpyAsync(h_state, r.state + (r.round & 1) * D, sizeof(Golden) * D, hipMemcpyDeviceToHost, st));
-    if (overlap && batches == 0) (*overlap)();  // (the first batch is in flight: the caller's host work runs under it)
+    ++r.round;
+    ++rounds_;
+  }
+  hipLaunchKernelGGL(loo_finalize_kernel, dim3((nm + 63) / 64), dim3(64), 0, st, r);
+  KDEHIP_CHECK(hipGetLastError());
+  if (timer_) timer_->stop();
+  KDEHIP_CHECK(hipMemcpyAsync(h_state_, r.state + (r.round & 1) * nm_, sizeof(Golden) * nm_, hipMemcpyDeviceToHost, st));
+  return KDEHIP_OK;
+}
+
+// After the caller has synchronised the stream: have all searches converged?  If not, the next batch of rounds is enqueued.
+int kdehip::LoocvSearch::poll(bool *done) {
+  ++batches_;
+  if (timer_) { timer_->collect(); timer_.reset(); }
+  bool all = true;
+  for (int m = 0; m < nm_; ++m) all = all && h_state_[m].phase == 3;
+  *done = all;
+  if (all) { armed_ = false; return KDEHIP_OK; }
+  if (batches_ >= 16) return set_error(KDEHIP_ERR_HIP, "bandwidth search did not converge");
+  timer_.reset(new PhaseTimer(kPhaseLoocv, st_));
+  return enqueue_batch(r_.spec ? 4 : 8);
+}
+
+int kdehip::LoocvSearch::finish(double *bw_out, int32_t *nevals_out) {
+  for (int b = 0; b < nb_; ++b) {
+    int total_evals = 0;
+    for (int d = 0; d < D_; ++d) {
+      const Golden &g = h_state_[b * D_ + d];
+      if (g.phase != 3) return set_error(KDEHIP_ERR_HIP, "bandwidth search did not converge");
+      const double ks = g.result * (g.minm + g.maxm) / 2.0;  // ksize, src/CrossValidation.jl:117
+      bw_out[b * D_ + d] = std::sqrt(ks * ks);               // getBW of kde!(.., [ks]) (src/KDE01.jl:45,118)
+      total_evals += g.nevals;
+    }
+    if (nevals_out) nevals_out[b] = total_evals;
+  }
+  return KDEHIP_OK;
+}
+
+kdehip::LoocvSearch *kdehip::loocv_new() { return new (std::nothrow) LoocvSearch(); }
+void kdehip::loocv_delete(LoocvSearch *s) { delete s; }
+int kdehip::loocv_begin(LoocvSearch *s, int nb, int D, int64_t N, const double *d_points, void *stream) {
+  return s->begin(nb, D, N, nullptr, d_points, static_cast<hipStream_t>(stream));
+}
+int kdehip::loocv_poll(LoocvSearch *s, bool *done) { return s->poll(done); }
+int kdehip::loocv_finish(LoocvSearch *s, double *bw_out, int32_t *nevals_out) { return s->finish(bw_out, nevals_out); }
+
+int kdehip::auto_bandwidth_run(int D, int64_t N, const double *points, const double *d_points, void *stream,
+                               double *bw_out, int32_t *nevals_out, const std::function<void()> *overlap) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const bool timing = std::getenv("KDEHIP_TIMING") != nullptr;
+  auto tnow = [] { return std::chrono::steady_clock::now(); };
+  auto t_begin = tnow();
+  LoocvSearch search;
+  int rc = search.begin(1, D, N, points, d_points, st);
+  if (rc != KDEHIP_OK) return rc;
+  auto t_prep = tnow();
+  if (overlap) (*overlap)();  // (the first batch is in flight: the caller's host work runs under it)
+  for (bool done = false; !done;) {
     KDEHIP_CHECK(hipStreamSynchronize(st));
-    ++batches;
-    bool done = true;
-    for (int d = 0; d < D; ++d) done = done && h_state[d].phase == 3;
-    if (done) break;
+    rc = search.poll(&done);
+    if (rc != KDEHIP_OK) return rc;
   }
-  int total_evals = 0;
-  for (int d = 0; d < D; ++d) {
-    if (h_state[d].phase != 3) return set_error(KDEHIP_ERR_HIP, "bandwidth search did not converge");
-    const double ks = h_state[d].result * (h_state[d].minm + h_state[d].maxm) / 2.0;  // ksize, src/CrossValidation.jl:117
-    bw_out[d] = std::sqrt(ks * ks);                                                    // getBW of kde!(.., [ks]) (src/KDE01.jl:45,118)
-    total_evals += h_state[d].nevals;
-  }
-  if (nevals_out) *nevals_out = total_evals;
+  rc = search.finish(bw_out, nevals_out);
+  if (rc != KDEHIP_OK) return rc;
   if (timing) {
     auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
-    std::fprintf(stderr, "kdehip_auto_bandwidth D=%d N=%lld: upload + prep enqueue %.0f us, %d rounds in %d batches %.0f us\n", D,
-                 static_cast<long long>(N), us(t_begin, t_prep), rounds, batches, us(t_prep, tnow()));
+    std::fprintf(stderr, "kdehip_auto_bandwidth D=%d N=%lld: upload + prep + first batch enqueue %.0f us, %d rounds in %d batches %.0f us\n", D,
+                 static_cast<long long>(N), us(t_begin, t_prep), search.rounds(), search.batches(), us(t_prep, tnow()));
   }
   return KDEHIP_OK;
 }

@@ -28,6 +28,7 @@
 #include "device_density.hpp"
 #include "host_pool.hpp"
 #include "kdehip_internal.hpp"
+#include "loocv_search.hpp"
 
 using namespace kdehip;
 
@@ -412,7 +413,7 @@ extern "C" int kdehip_density_from_device_points(kdehip_device_density **out, co
   // what needs the host but not the bandwidth: the tree (topology, bounding boxes, weights, means), the frontier ids,
   // the device block and the upload of everything in it but the variances
   std::vector<int64_t> order;
-  auto host_side = [&]() {
+  auto host_side_body = [&]() {
     if (hipStreamSynchronize(xs) != hipSuccess) { side_rc = KDEHIP_ERR_HIP; side_msg = "the copy of the points failed"; return; }
     tree_rc = kdehip_make_density(D, N, pts, &one, 1, nullptr, centers, ranges, weights, left, right, lowest, highest, perm,
                                   means, bandwidth, bwmin, bwmax);
@@ -437,9 +438,19 @@ extern "C" int kdehip_density_from_device_points(kdehip_device_density **out, co
     if (e != hipSuccess) { side_rc = KDEHIP_ERR_HIP; side_msg = std::string("density block: ") + hipGetErrorString(e); }
     us_side = us();
   };
+  // (nothing may throw out of an extern "C" entry point, nor through the search's stack: vector growth in the frontier
+  // expansion is reported like any other failure of the host side -- ADVICE round 5)
+  auto host_side = [&]() {
+    try { host_side_body(); }
+    catch (const std::exception &e) { side_rc = KDEHIP_ERR_ALLOC; side_msg = e.what(); }
+  };
   if (under) {
-    const std::function<void()> fn = host_side;
-    rc = auto_bandwidth_run(static_cast<int>(D), N, nullptr, d_points, cs, bw, nevals, &fn);
+    try {
+      const std::function<void()> fn = host_side;
+      rc = auto_bandwidth_run(static_cast<int>(D), N, nullptr, d_points, cs, bw, nevals, &fn);
+    } catch (const std::exception &e) {
+      return set_error(KDEHIP_ERR_ALLOC, std::string("kdehip_density_from_device_points: ") + e.what());
+    }
     if (rc != KDEHIP_OK) return rc;
   } else {
     // (larger marginals are prepared on the host: the search needs the copy first; the tree still builds under it)
@@ -539,6 +550,305 @@ extern "C" int kdehip_mul_device(kdehip_device_density **out, int Ndens, kdehip_
   return kdehip_density_from_device_points(out, d_pts, D, Np, device, cs, bw_out, nevals);
 }
 
+// ---- `*` for MANY products in one call ----------------------------------------------------------------------------
+// The reference's `*` (src/MSGibbs01.jl:707-726) is what a belief-propagation host calls dozens of times per sweep, on
+// densities of 100-300 points (test/runtests.jl:189-201): product, then kde!(pGM) = LOOCV bandwidth per dimension
+// (src/KDE01.jl:3-27, src/CrossValidation.jl:44-120) + ball tree (src/BallTree01.jl:415-434).  One at a time each is a
+// blocking call of >= 10 dependent launches that fill a fraction of the device.  Here ALL products are sampled by the batched
+// sampler (kdehip_prod_philox_batch: one launch per (dimension count, density count) group) into one scratch block; the
+// bandwidth searches of ALL outputs of one size advance in the SAME launches (LoocvSearch: a launch indexes marginals, a
+// batch of nb products of D dimensions is nb * D of them); the matrices come down in ONE copy and the nb trees are built by
+// the pooled host builder UNDER the searches; the densities share one device block and one pinned mirror (two uploads for
+// the batch).  Every result is, bit for bit, what kdehip_mul_device returns for the same item.
+namespace {
+
+struct MulPlan {   // what one item of the batch becomes
+  int D = 0, M = 0;
+  int64_t N = 0;          // points of the result (Np of the product, or the density's own count for the shortcut)
+  bool shortcut = false, loose = false;  // loose: outside the batched path (fewer than 2 or more than 2048 points): a call of its own
+  int group = -1, slot = 0;              // its (D, N) group and position in it
+  size_t pts_off = 0, ind_off = 0;       // in the scratch block (bytes)
+  size_t a_off = 0, b_off = 0, x_off = 0;  // in the shared block: region A (means, weights, permutation, ids), B (variances); mirror extras
+  size_t front_cap = 0;
+  kdehip_device_density *h = nullptr;
+  std::vector<int64_t> order;
+  int rc = KDEHIP_OK;
+  std::string msg;
+};
+struct MulGroup { int D; int64_t N; std::vector<int> members; size_t pts_off = 0; LoocvSearch *search = nullptr; };
+
+}  // namespace
+
+extern "C" int kdehip_mul_device_batch(int nprod, const kdehip_mul_item *items, kdehip_device_density **out, double *bw_out,
+                                       int32_t *nevals) {
+  if (nprod < 0 || (nprod > 0 && (!items || !out))) return set_error(KDEHIP_ERR_ARG, "kdehip_mul_device_batch: bad item list");
+  for (int i = 0; i < nprod; ++i) out[i] = nullptr;
+  if (nprod == 0) return KDEHIP_OK;
+  std::vector<MulPlan> mp(static_cast<size_t>(nprod));
+  int device = -1;
+  for (int i = 0; i < nprod; ++i) {
+    const kdehip_mul_item &it = items[i];
+    if (it.Ndens < 1 || !it.trees) return set_error(KDEHIP_ERR_ARG, "need at least one density");
+    for (int j = 0; j < it.Ndens; ++j) {
+      if (!it.trees[j]) return set_error(KDEHIP_ERR_ARG, "null density");
+      if (it.trees[j]->D != it.trees[0]->D) return set_error(KDEHIP_ERR_DIM_MISMATCH, "kdes must have same dimension");
+      if (device < 0) device = it.trees[j]->device;
+      if (it.trees[j]->device != device) return set_error(KDEHIP_ERR_ARG, "densities on different devices");
+    }
+    MulPlan &m = mp[i];
+    m.D = it.trees[0]->D; m.M = it.Ndens;
+    m.shortcut = it.Ndens == 1 && !it.addEntropy;  // the "hack fix for #70" (:713-716)
+    if (m.shortcut) m.N = it.trees[0]->N;
+    else {
+      double sum = 0.0;  // numpts = round(Int, mean(Npts.(trees))): halves to even, like nearbyint
+      for (int j = 0; j < it.Ndens; ++j) sum += static_cast<double>(it.trees[j]->N);
+      m.N = static_cast<int64_t>(std::nearbyint(sum / static_cast<double>(it.Ndens)));
+    }
+  }
+  DeviceGuard guard;
+  int rc = guard.enter(device);
+  if (rc != KDEHIP_OK) return rc;
+  hipStream_t cs = hipStreamPerThread, xs = side_stream(device);
+  auto al = [](size_t x) { return (x + 255) & ~static_cast<size_t>(255); };
+
+  // groups of equal (D, N): their searches share launches and their matrices sit one behind the other
+  std::vector<MulGroup> groups;
+  for (int i = 0; i < nprod; ++i) {
+    MulPlan &m = mp[i];
+    m.loose = xs == nullptr || m.N < 2 || m.N > kLoocvPrepMaxN;
+    if (m.loose) continue;
+    int g = -1;
+    for (size_t k = 0; k < groups.size(); ++k) if (groups[k].D == m.D && groups[k].N == m.N) g = static_cast<int>(k);
+    if (g < 0) { groups.push_back(MulGroup{m.D, m.N, {}}); g = static_cast<int>(groups.size()) - 1; }
+    m.group = g; m.slot = static_cast<int>(groups[g].members.size());
+    groups[g].members.push_back(i);
+  }
+  size_t pts_bytes = 0, ind_bytes = 0, a_bytes = 0, b_bytes = 0, x_bytes = 0;
+  for (MulGroup &g : groups) {
+    g.pts_off = pts_bytes;
+    for (int i : g.members) {
+      MulPlan &m = mp[i];
+      m.pts_off = pts_bytes; pts_bytes += sizeof(double) * m.N * m.D;  // (no padding inside a group: LoocvSearch strides by N * D)
+    }
+    pts_bytes = al(pts_bytes);
+  }
+  int nbatched = 0;
+  for (int i = 0; i < nprod; ++i) {
+    MulPlan &m = mp[i];
+    if (m.loose) continue;
+    ++nbatched;
+    if (!m.shortcut) { m.ind_off = ind_bytes; ind_bytes = al(ind_bytes + sizeof(int64_t) * m.N * m.M); }
+    const size_t nd = sizeof(double) * 2 * m.N * m.D, n2 = sizeof(double) * 2 * m.N;
+    m.front_cap = static_cast<size_t>(nlevels_for(m.N) + 1) * static_cast<size_t>(m.N) + 64;
+    m.a_off = a_bytes; a_bytes = al(a_bytes + al(nd) + al(n2) + al(n2) + sizeof(int32_t) * m.front_cap);
+    m.b_off = b_bytes; b_bytes = al(b_bytes + nd);
+    m.x_off = x_bytes; x_bytes = al(x_bytes + nd * 3 + sizeof(int64_t) * 4 * 2 * m.N);  // centers, ranges, bwmin + bwmax, left .. highest
+  }
+
+  // everything the error paths have to take back
+  struct Cleanup {
+    std::vector<MulPlan> *mp; std::vector<MulGroup> *groups;
+    hipStream_t cs, xs;
+    void *scratch = nullptr; size_t scratch_bytes = 0;
+    void *pin = nullptr; size_t pin_bytes = 0;
+    SharedBlock *sb = nullptr;
+    bool keep = false;
+    ~Cleanup() {
+      for (MulGroup &g : *groups) if (g.search) loocv_delete(g.search);  // (an abandoned search waits for its stream)
+      (void)hipStreamSynchronize(cs);
+      if (xs) (void)hipStreamSynchronize(xs);
+      if (scratch) cached_free(scratch, scratch_bytes);
+      if (pin) cached_host_free(pin, pin_bytes);
+      if (keep) return;
+      for (MulPlan &m : *mp) { delete m.h; m.h = nullptr; }
+      if (sb) {
+        if (sb->d_blob) cached_free(sb->d_blob, sb->blob_bytes);
+        if (sb->mirror) cached_host_free(sb->mirror, sb->mirror_bytes);
+        delete sb;
+      }
+    }
+  } cl{&mp, &groups, cs, xs};
+
+  if (nbatched > 0) {
+    cl.scratch_bytes = al(pts_bytes) + ind_bytes + 256;
+    KDEHIP_CHECK(cached_malloc(&cl.scratch, cl.scratch_bytes));
+    unsigned char *sc = static_cast<unsigned char *>(cl.scratch);
+    // (1) the products: one batched call (its own groups by (D, M)); the shortcut items un-permute their own leaves
+    std::vector<kdehip_batch_item> prod;
+    for (int i = 0; i < nprod; ++i) {
+      MulPlan &m = mp[i];
+      if (m.loose) continue;
+      double *d_pts = reinterpret_cast<double *>(sc + m.pts_off);
+      if (m.shortcut) {
+        const kdehip_device_density *t = items[i].trees[0];
+        const int64_t n = m.N * m.D;
+        hipLaunchKernelGGL(unpermute_points_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, cs, t->means, t->perm,
+                           m.N, m.D, d_pts);
+        KDEHIP_CHECK(hipGetLastError());
+        continue;
+      }
+      kdehip_batch_item b{};
+      b.Ndens = m.M; b.Niter = 5; b.trees = items[i].trees; b.Np = m.N; b.seed = items[i].seed; b.sample_offset = 0;
+      b.addEntropy = items[i].addEntropy; b.partialDimMask = nullptr; b.d_points = d_pts;
+      b.d_indices = reinterpret_cast<int64_t *>(sc + al(pts_bytes) + m.ind_off); b.d_labels = nullptr;
+      prod.push_back(b);
+    }
+    if (!prod.empty()) {
+      rc = kdehip_prod_philox_batch(static_cast<int>(prod.size()), prod.data(), 64, cs);
+      if (rc != KDEHIP_OK) return rc;
+    }
+    // (2) the matrices come down in one copy on the side stream, behind the products
+    cl.pin_bytes = pts_bytes;
+    KDEHIP_CHECK(cached_host_malloc(&cl.pin, cl.pin_bytes));
+    {
+      hipEvent_t ev = nullptr;
+      KDEHIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      hipError_t e = hipEventRecord(ev, cs);
+      if (e == hipSuccess) e = hipStreamWaitEvent(xs, ev, 0);
+      (void)hipEventDestroy(ev);
+      if (e != hipSuccess) return set_error(KDEHIP_ERR_HIP, std::string("kdehip_mul_device_batch: ") + hipGetErrorString(e));
+      KDEHIP_CHECK(hipMemcpyAsync(cl.pin, sc, pts_bytes, hipMemcpyDeviceToHost, xs));
+    }
+    // (3) the bandwidth searches: one per group, all of its marginals in the same launches, nothing needs the host
+    for (MulGroup &g : groups) {
+      g.search = loocv_new();
+      if (!g.search) return set_error(KDEHIP_ERR_ALLOC, "out of host memory");
+      rc = loocv_begin(g.search, static_cast<int>(g.members.size()), g.D, g.N, reinterpret_cast<const double *>(sc + g.pts_off), cs);
+      if (rc != KDEHIP_OK) return rc;
+    }
+    // (4) UNDER the searches: handles, the shared blocks, and -- once the copy is down -- the trees (one pool task each)
+    cl.sb = new (std::nothrow) SharedBlock();
+    if (!cl.sb) return set_error(KDEHIP_ERR_ALLOC, "out of host memory");
+    cl.sb->blob_bytes = a_bytes + b_bytes;
+    cl.sb->mirror_bytes = a_bytes + b_bytes + x_bytes;
+    KDEHIP_CHECK(cached_malloc(&cl.sb->d_blob, cl.sb->blob_bytes));
+    KDEHIP_CHECK(cached_host_malloc(&cl.sb->mirror, cl.sb->mirror_bytes));
+    unsigned char *mb = static_cast<unsigned char *>(cl.sb->mirror), *db = static_cast<unsigned char *>(cl.sb->d_blob);
+    for (int i = 0; i < nprod; ++i) {
+      MulPlan &m = mp[i];
+      if (m.loose) continue;
+      kdehip_device_density *h = m.h = new (std::nothrow) kdehip_device_density();
+      if (!h) return set_error(KDEHIP_ERR_ALLOC, "out of host memory");
+      h->device = device; h->N = m.N; h->D = m.D; h->Lown = nlevels_for(m.N);
+      const size_t nd = sizeof(double) * 2 * m.N * m.D, n2 = sizeof(double) * 2 * m.N;
+      const size_t o_w = al(nd), o_perm = o_w + al(n2), o_front = o_perm + al(n2);
+      unsigned char *a = mb + m.a_off, *x = mb + a_bytes + b_bytes + m.x_off;
+      kdehip_device_density::Mirror &q = h->m;
+      q.means = reinterpret_cast<double *>(a); q.weights = reinterpret_cast<double *>(a + o_w);
+      q.perm = reinterpret_cast<int64_t *>(a + o_perm);
+      q.bandwidth = reinterpret_cast<double *>(mb + a_bytes + m.b_off);
+      q.centers = reinterpret_cast<double *>(x); q.ranges = q.centers + nd / 8; q.bwmin = q.ranges + nd / 8; q.bwmax = q.bwmin + nd / 16;
+      q.left = reinterpret_cast<int64_t *>(q.bwmax + nd / 16); q.right = q.left + 2 * m.N; q.lowest = q.right + 2 * m.N;
+      q.highest = q.lowest + 2 * m.N;
+      h->means = reinterpret_cast<const double *>(db + m.a_off);
+      h->weights = reinterpret_cast<const double *>(db + m.a_off + o_w);
+      h->perm = reinterpret_cast<const int64_t *>(db + m.a_off + o_perm);
+      h->front = reinterpret_cast<const int32_t *>(db + m.a_off + o_front);
+      h->bandwidth = reinterpret_cast<const double *>(db + a_bytes + m.b_off);
+    }
+    KDEHIP_CHECK(hipStreamSynchronize(xs));  // the matrices are down
+    const unsigned char *pin = static_cast<const unsigned char *>(cl.pin);
+    const double one = 1.0;  // (placeholder: only `bandwidth`, bandwidthMin/Max depend on the bandwidth)
+    try {
+      TaskGroup trees(HostPool::get());
+      for (int i = 0; i < nprod; ++i) {
+        MulPlan *m = &mp[i];
+        if (m->loose) continue;
+        trees.run([m, pin, mb, al, &one] {
+          kdehip_device_density *h = m->h;
+          kdehip_device_density::Mirror &q = h->m;
+          m->rc = kdehip_make_density(m->D, m->N, reinterpret_cast<const double *>(pin + m->pts_off), &one, 1, nullptr, q.centers, q.ranges,
+                                      q.weights, q.left, q.right, q.lowest, q.highest, q.perm, q.means, q.bandwidth, q.bwmin, q.bwmax);
+          const kdehip_density host{m->N, m->D, q.means, q.bandwidth, q.weights, q.left, q.right, q.perm};
+          if (m->rc == KDEHIP_OK) m->rc = expand_frontier_ids(host, h->D, h->Lown, h->fr);
+          if (m->rc == KDEHIP_OK) m->rc = children_first_order(m->N, q.left, q.right, m->order);
+          if (m->rc != KDEHIP_OK) { m->msg = kdehip_last_error(); return; }
+          if (h->fr.ids.size() > m->front_cap) { m->rc = KDEHIP_ERR_ARG; m->msg = "more frontier ids than a tree of N leaves has"; return; }
+          const size_t nd = sizeof(double) * 2 * m->N * m->D, n2 = sizeof(double) * 2 * m->N;
+          std::memcpy(mb + m->a_off + al(nd) + 2 * al(n2), h->fr.ids.data(), sizeof(int32_t) * h->fr.ids.size());
+        });
+      }
+      trees.wait();
+    } catch (const std::exception &e) {
+      return set_error(KDEHIP_ERR_ALLOC, std::string("kdehip_mul_device_batch: ") + e.what());
+    }
+    for (const MulPlan &m : mp) if (!m.loose && m.rc != KDEHIP_OK) return set_error(m.rc, "kdehip_mul_device_batch: " + m.msg);
+    KDEHIP_CHECK(hipMemcpyAsync(db, mb, a_bytes, hipMemcpyHostToDevice, xs));  // everything but the variances, ONE transfer
+    // (5) the searches: wait, look, go on where one needs more rounds
+    for (bool all = false; !all;) {
+      KDEHIP_CHECK(hipStreamSynchronize(cs));
+      all = true;
+      for (MulGroup &g : groups) {
+        if (!g.search) continue;
+        bool done = false;
+        rc = loocv_poll(g.search, &done);
+        if (rc != KDEHIP_OK) return rc;
+        if (!done) { all = false; continue; }
+        std::vector<double> bw(g.members.size() * g.D);
+        std::vector<int32_t> ne(g.members.size());
+        rc = loocv_finish(g.search, bw.data(), ne.data());
+        loocv_delete(g.search);
+        g.search = nullptr;
+        if (rc != KDEHIP_OK) return rc;
+        for (size_t k = 0; k < g.members.size(); ++k) {
+          const int i = g.members[k];
+          for (int d = 0; d < g.D; ++d) {
+            mp[i].h->bw[d] = bw[k * g.D + d];
+            if (bw_out) bw_out[static_cast<size_t>(i) * KDEHIP_MAX_DIMS + d] = bw[k * g.D + d];
+          }
+          if (nevals) nevals[i] = ne[k];
+        }
+      }
+    }
+    // (6) the bandwidth-dependent rest: variances (+ the packers' examination of the nodes), one upload, per-level flags
+    try {
+      TaskGroup rest(HostPool::get());
+      for (int i = 0; i < nprod; ++i) {
+        MulPlan *m = &mp[i];
+        if (m->loose) continue;
+        rest.run([m] {
+          kdehip_device_density *h = m->h;
+          kdehip_device_density::Mirror &q = h->m;
+          NodeStats stats{};
+          m->rc = set_bandwidth_examined(m->D, m->N, h->bw, m->D, q.weights, q.left, q.right, q.means, q.bandwidth, q.bwmin, q.bwmax,
+                                         &stats, &m->order);
+          if (m->rc != KDEHIP_OK) { m->msg = kdehip_last_error(); return; }
+          const kdehip_density host{m->N, m->D, q.means, q.bandwidth, q.weights, q.left, q.right, q.perm};
+          examine_frontiers(host, h->D, h->Lown, /*look=*/false, h->fr);
+          h->fr.bad = stats.bad;
+          for (int k = 0; k < KDEHIP_MAX_DIMS; ++k) { h->fr.lo[k] = stats.lo[k]; h->fr.hi[k] = stats.hi[k]; }
+          std::vector<int32_t>().swap(h->fr.ids);  // (the ids live on the device now; sizes, offsets and flags stay)
+          std::vector<uint8_t>().swap(h->fr.fresh);
+        });
+      }
+      rest.wait();
+    } catch (const std::exception &e) {
+      return set_error(KDEHIP_ERR_ALLOC, std::string("kdehip_mul_device_batch: ") + e.what());
+    }
+    for (const MulPlan &m : mp) if (!m.loose && m.rc != KDEHIP_OK) return set_error(m.rc, "kdehip_mul_device_batch: " + m.msg);
+    KDEHIP_CHECK(hipMemcpyAsync(db + a_bytes, mb + a_bytes, b_bytes, hipMemcpyHostToDevice, xs));
+    KDEHIP_CHECK(hipStreamSynchronize(xs));
+  }
+  // items outside the batched path: a call of their own each
+  for (int i = 0; i < nprod; ++i) {
+    if (!mp[i].loose) continue;
+    rc = kdehip_mul_device(&mp[i].h, items[i].Ndens, items[i].trees, items[i].seed, items[i].addEntropy,
+                           bw_out ? bw_out + static_cast<size_t>(i) * KDEHIP_MAX_DIMS : nullptr, nevals ? nevals + i : nullptr);
+    if (rc != KDEHIP_OK) {
+      for (MulPlan &m : mp) if (m.loose && m.h) { kdehip_density_free(m.h); m.h = nullptr; }
+      return rc;
+    }
+  }
+  for (int i = 0; i < nprod; ++i) {
+    MulPlan &m = mp[i];
+    if (!m.loose) { m.h->built = true; m.h->shared = cl.sb; cl.sb->refs.fetch_add(1, std::memory_order_relaxed); }
+    out[i] = m.h;
+  }
+  if (cl.sb && nbatched == 0) { delete cl.sb; cl.sb = nullptr; }
+  cl.keep = true;
+  return KDEHIP_OK;
+}
+
 // The arrays of a density the library built (kdehip_density_from_device_points / kdehip_mul_device), shaped as in
 // kdehip_make_density; any pointer may be NULL.  A density that came from kdehip_density_upload has no mirror: its
 // arrays are the caller's.
@@ -562,12 +872,21 @@ extern "C" int kdehip_density_download(const kdehip_device_density *h, double *c
 extern "C" void kdehip_density_free(kdehip_device_density *h) {
   if (!h) return;
   DeviceGuard guard;
+  SharedBlock *sb = h->shared;
+  const bool last = sb && sb->refs.fetch_sub(1, std::memory_order_acq_rel) == 1;  // (a batch's blocks go with its last density)
   if (guard.enter(h->device) == KDEHIP_OK) {
     (void)hipDeviceSynchronize();  // products enqueued on caller streams may still read the block
     if (h->d_blob) cached_free(h->d_blob, h->blob_bytes);
     if (h->mirror) cached_host_free(h->mirror, h->mirror_bytes);
+    if (last) {
+      if (sb->d_blob) cached_free(sb->d_blob, sb->blob_bytes);
+      if (sb->mirror) cached_host_free(sb->mirror, sb->mirror_bytes);
+    }
+  } else {  // (no device to enter: hand the pinned block back to the driver)
+    if (h->mirror) (void)hipHostFree(h->mirror);
+    if (last && sb->mirror) (void)hipHostFree(sb->mirror);
   }
-  else if (h->mirror) (void)hipHostFree(h->mirror);  // (no device to enter: hand the pinned block back to the driver)
+  if (last) delete sb;
   delete h;
 }
 

@@ -17,6 +17,9 @@
 
 #include "device_density.hpp"
 #include "kdehip_internal.hpp"
+#include "phase_timer.hpp"
+
+namespace kdehip { extern std::atomic<unsigned> g_peer_epoch; }  // devmem.cpp: bumped by kdehip_clear_cache
 #include "philox.hpp"
 
 using namespace kdehip;
@@ -1216,6 +1219,7 @@ void kdehip_profile_sampler(int enable) {
   std::lock_guard<std::mutex> lock(g_profile_mu);
   for (int d = 0; d < kMaxDevices; ++d) g_profile[d].clear();
   g_profile_sampler.store(enable ? 1 : 0, std::memory_order_relaxed);
+  profile_phases_set(enable != 0);  // (phase_timer.hpp: LOOCV search, evaluation, GPU tree build)
 }
 int kdehip_profile_sampler_read(int device, void *stream, double *total_ms, int64_t *launches) {
   if (device < 0 || device >= kMaxDevices) return set_error(KDEHIP_ERR_ARG, "device ordinal outside 0..63");
@@ -1280,8 +1284,12 @@ struct kdehip_product_multi {
   std::vector<char> timed_dev;    // ... and device g had chains in it (an empty slice records no events)
   // verdicts of peer_can_store per (array, writing device): a caller passes the same arrays product after product, and
   // a look-up is up to three driver queries (112 look-ups per product at 8 GPUs)
+  // The verdicts are keyed by raw pointer: an array freed and re-allocated at the same address from ANOTHER allocator would
+  // keep a stale one.  kdehip_clear_cache() invalidates them in every plan (peer_epoch against g_peer_epoch); a caller that
+  // changes allocators without it sets KDEHIP_PEER_STORES (include/kdehip.h section 2b).
   struct PeerVerdict { const void *p; int writer; bool ok; };
   std::vector<PeerVerdict> peer_cache;
+  unsigned peer_epoch = 0;
 };
 
 namespace {
@@ -1399,6 +1407,10 @@ int kdehip_product_multi_sample_philox(kdehip_product_multi *mp, int64_t Np, int
   // that device access, one made of virtual-memory mappings only if hipMemSetAccess did.  Looked at per call (the
   // caller may pass other arrays every time); anything that cannot be shown reachable takes the copy path.
   bool peer_stores = mp->peer_stores;
+  if (const unsigned ep = g_peer_epoch.load(std::memory_order_relaxed); ep != mp->peer_epoch) {
+    mp->peer_cache.clear();  // kdehip_clear_cache() has run since the verdicts were formed
+    mp->peer_epoch = ep;
+  }
   for (int h = 0; h < G && peer_stores && G > 1; ++h)
     for (int g = 0; g < G && peer_stores; ++g) {
       // (KDEHIP_PEER_CHECK_ALIASED=1: tests on one GPU run the look-up on aliased devices too)

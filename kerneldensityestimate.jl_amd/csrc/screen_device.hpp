@@ -38,7 +38,14 @@
 // more than 2.1 E away (2 E would do).  Terms that fp32 flushes to zero or holds as denormals are below 2^-126 times a
 // front that the range checks bound by 2^28 each: with total >= 2^-40 required, their sum is below 2^-40 of the margin.
 // Range checks (else the step runs in fp64): tile values (screen_build_kernel: |m'| <= 2^16, variances in [2^-7, 2^8],
-// weights in [0, 2]) and per step |centre'_d| <= 2^16, leave-one-out variance <= 2^8.
+// weights in [0, 2]) and per step |centre'_d| <= 2^16, leave-one-out variance <= 2^8, and na <= 2^-11 (kScreenMaxNa: the
+// linear form na (1 + |x|) stands for exp(d) - 1 with d = ln2 na (1 + |x|); the 1 % allowance and the margin's 5 % cover it
+// up to d ~ 0.11, and |x| < 127 wherever the value is not flushed -- clusters thousands of bandwidths apart exceed it).
+//
+// THE HARDWARE PREMISE, MEASURED (csrc/selftest.hip, tests/test_gpu_ulp.py: every fp32 input swept on the device against
+// fp64; MI355X, round 6): largest relative error of v_rcp_f32 1.535 u (all inputs with a normal reciprocal, both signs),
+// v_rsq_f32 1.577 u (all positive normals), v_exp_f32 1.423 u on [-126, -0] and 1.395 u on [0, 127]; for x < -126 the
+// result is flushed to zero (off by < 2^-126).  The constants above charge each of them 2 u.
 #pragma once
 #include "gibbs_device.hpp"
 

@@ -29,6 +29,7 @@
 #include <vector>
 
 #include "kdehip_internal.hpp"
+#include "phase_timer.hpp"
 
 namespace kdehip {
 namespace {
@@ -496,10 +497,13 @@ extern "C" int kdehip_make_densities_device(int nb, int64_t D, const int64_t *Ns
   // (per call: the attribute belongs to the function ON THE CURRENT DEVICE, and concurrent host threads get here)
   KDEHIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(tree_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    static_cast<int>(kTreeLdsLimit)));
+  PhaseTimer timer(kPhaseTreeBuild, hipStreamPerThread);  // (kdehip_profile_phase_read(2): the kernel alone)
   hipLaunchKernelGGL(tree_build_kernel, dim3(nb), dim3(kTB), L.total, hipStreamPerThread, batch, L);
   KDEHIP_CHECK(hipGetLastError());
+  timer.stop();
   KDEHIP_CHECK(hipMemcpyAsync(hb + out_begin, db + out_begin, out_end - out_begin, hipMemcpyDeviceToHost, hipStreamPerThread));
   KDEHIP_CHECK(hipStreamSynchronize(hipStreamPerThread));
+  timer.collect();
   for (int j = 0; j < nb; ++j) {
     const int64_t N = Ns[j];
     const size_t nd = sizeof(double) * 2 * N * D, n2 = sizeof(double) * 2 * N;

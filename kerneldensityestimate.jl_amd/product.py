@@ -296,6 +296,37 @@ def mul_device(trees, *, addEntropy=True, seed=None) -> DeviceDensity:
     return out
 
 
+def mul_device_batch(products, *, addEntropy=True, seeds=None):
+    """Many `*` in ONE call (kdehip_mul_device_batch): `products` = a list of lists of `DeviceDensity`; returns one
+    `DeviceDensity` per product, each bit for bit what `mul_device(products[i], addEntropy=..., seed=seeds[i])` returns --
+    batched sampler, the LOOCV searches of all results of one size in shared launches, trees built under them.
+    `addEntropy`: one flag or one per product."""
+    products = [list(p) for p in products]
+    n = len(products)
+    if n == 0:
+        return []
+    if seeds is None:
+        seeds = [int.from_bytes(os.urandom(8), "little") for _ in range(n)]
+    flags = [bool(addEntropy)] * n if isinstance(addEntropy, (bool, int)) else [bool(f) for f in addEntropy]
+    items = (_lib.CMulItem * n)()
+    keep = []
+    for k, trees in enumerate(products):
+        arr = (C.c_void_p * len(trees))(*[t._h for t in trees])
+        keep.append(arr)
+        items[k].Ndens, items[k].addEntropy, items[k].trees = len(trees), int(flags[k]), arr
+        items[k].seed = int(seeds[k]) & (2 ** 64 - 1)
+    out = (C.c_void_p * n)()
+    bw = np.zeros((n, _lib.MAX_DIMS))
+    ne = np.zeros(n, dtype=np.int32)
+    _lib.check(_lib.lib.kdehip_mul_device_batch(n, items, out, ptr(bw, f64p), ptr(ne, _lib.i32p)))
+    res = []
+    for k in range(n):
+        d = DeviceDensity(device=products[k][0].device, _handle=C.c_void_p(out[k]))
+        d.bw, d.nevals = bw[k, :d.dims].copy(), int(ne[k])
+        res.append(d)
+    return res
+
+
 class ProductBatch:
     """The argument block of one `kdehip_prod_philox_batch` call, built once: a host that issues the same set of products
     sweep after sweep (only seeds / sample offsets change) does not pay the Python-side marshalling per call."""

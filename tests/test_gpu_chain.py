@@ -108,3 +108,81 @@ def test_ten_deep_chain_on_resident_densities():
     for x in made + dd:
         x.close()
     kdehip._clib.kdehip_clear_cache()
+
+
+def _same_as_singles(products, flags, seeds):
+    """mul_device_batch(products) against one mul_device per product: every array of every density, the LOOCV bandwidths
+    and the evaluation counts, bit for bit; then the batch's densities must WORK as inputs (a product of two of them)."""
+    outs = kdehip.mul_device_batch(products, addEntropy=flags, seeds=seeds)
+    assert len(outs) == len(products)
+    for k, (trees, out) in enumerate(zip(products, outs)):
+        with kdehip.mul_device(trees, addEntropy=flags[k], seed=seeds[k]) as ref:
+            assert out.num_points == ref.num_points and out.dims == ref.dims, k
+            assert np.array_equal(out.bw, ref.bw), (k, out.bw, ref.bw)
+            assert out.nevals == ref.nevals, k
+            assert_same_density(out.download(), ref.download(), f"product {k}")
+    return outs
+
+
+def test_mul_device_batch_of_config2_shapes_equals_singles():
+    """64 products of the reference's own serving shape (BASELINE config 2: 2-D, 3 x 200 points, Np = 200, Niter = 5;
+    src/MSGibbs01.jl:707-726 with test/runtests.jl:189-201's sizes) in ONE call."""
+    D, B = 2, 64
+    pool = [kdehip.DeviceDensity(t) for t in _trees(321, D, [200] * 12)]
+    rng = np.random.default_rng(5)
+    products = [[pool[j] for j in rng.choice(len(pool), size=3, replace=False)] for _ in range(B)]
+    seeds = [9000 + k for k in range(B)]
+    outs = _same_as_singles(products, [True] * B, seeds)
+    # the results are ordinary resident densities: a product of two of them == the product of the same two built singly
+    with kdehip.mul_device(products[0], seed=seeds[0]) as a, kdehip.mul_device(products[1], seed=seeds[1]) as b:
+        with kdehip.mul_device([a, b], seed=1) as ref, kdehip.mul_device([outs[0], outs[1]], seed=1) as got:
+            assert_same_density(got.download(), ref.download(), "product of two batch results")
+    # freeing in any order: the batch's shared block goes with the last handle
+    for o in outs[::2] + outs[1::2]:
+        o.close()
+    for d in pool:
+        d.close()
+    kdehip._clib.kdehip_clear_cache()
+
+
+def test_mul_device_batch_ragged_sizes_shortcut_and_loose_items():
+    """Mixed in one call: results of different sizes and dimension counts (one bandwidth search per (D, N) group), 1 to 5
+    densities per product, addEntropy on and off, the one-density shortcut (src/MSGibbs01.jl:713-716), and a result
+    beyond 2048 points (built by a call of its own inside the batch)."""
+    t2 = [kdehip.DeviceDensity(t) for t in _trees(11, 2, [200, 200, 150, 151, 64])]
+    t6 = [kdehip.DeviceDensity(t) for t in _trees(12, 6, [300, 300, 1000, 1000])]
+    t3 = [kdehip.DeviceDensity(t) for t in _trees(13, 3, [2500, 2500])]
+    t1 = [kdehip.DeviceDensity(t) for t in _trees(14, 1, [100, 100, 37])]
+    products = [
+        [t2[0], t2[1]],                 # 2-D, Np 200
+        [t2[0], t2[1], t2[2]],          # mean 183.33 -> 183
+        [t2[2], t2[3]],                 # mean 150.5 -> 150 (halves to even)
+        [t2[1], t2[0]],                 # Np 200 again: same group as product 0
+        [t2[4]],                        # one density, entropy on: a real product of one
+        [t2[4]],                        # one density, no entropy: the shortcut
+        [t6[0], t6[1]],                 # 6-D, Np 300
+        [t6[2], t6[3], t6[0]],          # 6-D, mean 766.67 -> 767
+        [t3[0], t3[1]],                 # Np 2500 > 2048: outside the batched path
+        [t1[0], t1[1]],                 # 1-D
+        [t1[0], t1[1], t1[2], t1[0], t1[1]],  # five densities: the general sampler inside the batch
+        [t6[0], t6[1]],                 # 6-D, Np 300 again, other seed
+    ]
+    flags = [True, False, True, True, True, False, True, False, True, True, True, False]
+    seeds = [500 + 7 * k for k in range(len(products))]
+    outs = _same_as_singles(products, flags, seeds)
+    for o in outs:
+        o.close()
+    for d in t2 + t6 + t3 + t1:
+        d.close()
+    kdehip._clib.kdehip_clear_cache()
+
+
+def test_mul_device_batch_argument_errors():
+    a = kdehip.DeviceDensity(_trees(1, 2, [50])[0])
+    b = kdehip.DeviceDensity(_trees(2, 3, [50])[0])
+    assert kdehip.mul_device_batch([]) == []
+    with pytest.raises(ValueError, match="same dimension"):
+        kdehip.mul_device_batch([[a, a], [a, b]], seeds=[1, 2])
+    with pytest.raises(kdehip.KdeHipError):
+        kdehip.mul_device_batch([[a, a], []], seeds=[1, 2])
+    a.close(); b.close()

@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol():
     from importlib import import_module
     bound = set(import_module("kdehip._lib").SIGNATURES)
     assert declared == bound, declared ^ bound
-    assert kdehip.version() == 500
+    assert kdehip.version() == 600
 
 
 def test_ctypes_signatures_match_the_header():
@@ -50,7 +50,7 @@ def test_ctypes_signatures_match_the_header():
     from importlib import import_module
     from tests.test_julia_shim_syntax import header_params
     sigs = import_module("kdehip._lib").SIGNATURES
-    ints = {"int": C.c_int, "int64_t": C.c_int64, "uint64_t": C.c_uint64, "int32_t": C.c_int32}
+    ints = {"int": C.c_int, "int64_t": C.c_int64, "uint64_t": C.c_uint64, "int32_t": C.c_int32, "uint32_t": C.c_uint32}
     for name, params in header_params().items():
         res, args = sigs[name]
         assert len(args) == len(params), f"{name}: ctypes binds {len(args)} arguments, the header declares {len(params)}"
