@@ -26,6 +26,7 @@ kept as `normalised_hbm` (a throughput normalisation, not a roofline: it exceeds
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -120,7 +121,14 @@ def main():
                     help="with --batch B: a step = B complete `*` (product + kde!(pGM): LOOCV bandwidth + tree; reference "
                          "src/MSGibbs01.jl:707-726, Np = round(mean Npts), Niter = 5) in ONE kdehip_mul_device_batch call, "
                          "with the same B `*` as B kdehip_mul_device calls beside it")
+    ap.add_argument("--frow", choices=["loocv", "evaluate", "tree"], default=None,
+                    help="the callers either side of the product (SURVEY.md 8f) at the measurement bar: loocv = kde!(points)'s "
+                         "bandwidth search on the product's output shape (D x Nout of --config), evaluate = evaluateDualTree(bd, pos) "
+                         "of one density of --config at 65,536 positions, tree = kde!(points, ks) of D x Nout points, host builder "
+                         "beside the GPU builder; each with roofline (kernel time by HIP events inside the library) and cpu_baseline")
     args = ap.parse_args()
+    if args.frow:
+        return frow_mode(args)
     if args.inproc_gpus > 0:
         return inproc_multi(args)
     if args.batch > 0 and args.mul:
@@ -578,6 +586,167 @@ def batch_mode(args):
     for dd in dds:
         for d in dd:
             d.close()
+    print(json.dumps(out), flush=True)
+
+
+def frow_mode(args):
+    """SURVEY.md 8(f) rows 1-3 to the same measurement bar as the product: a step = one blocking library call with host
+    buffers in and out (what the reference's caller has); kernel time = HIP events around the launches INSIDE the library
+    (kdehip_profile_phase_read: the entries run on the calling thread's own stream); roofline against the fp64 vector peak
+    with the REFERENCE's flop count per kernel value (evalDirect, src/DualTree01.jl:130-162: per dimension subtract,
+    square, divide, add; then exp, scale, weight = 4 D + 3); cpu_baseline = the oracle's restatement of the same function
+    on one host core (a bounded sample for evaluate)."""
+    import ctypes as C
+    import torch
+    import kdehip
+    from oracle import oracle
+    D, M, N, Nout, Niter, prec, cid = CONFIGS[args.config]
+    if args.nout > 0:
+        Nout = args.nout
+    torch.cuda.set_device(0)
+    steps, warmup = min(args.steps, 100), min(args.warmup, 10)
+    clib = kdehip._clib
+    peak_tf = VALU_PEAK_TFLOPS[64]
+
+    def phase(which):
+        ms, n = C.c_double(0.0), C.c_int64(0)
+        clib.kdehip_profile_phase_read(which, C.byref(ms), C.byref(n))
+        return ms.value, n.value
+
+    def timed(f):
+        for _ in range(warmup):
+            f()
+        ts = []
+        for _ in range(steps):
+            t0 = time.perf_counter()
+            f()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        return float(np.mean(ts)), float(np.median(ts))
+
+    def timed_kernel(f, which):
+        clib.kdehip_profile_sampler(1)
+        phase(which)
+        for _ in range(steps):
+            f()
+        ms, n = phase(which)
+        clib.kdehip_profile_sampler(0)
+        return ms / steps, n / steps
+
+    base = {"n_gpus": 1, "steps": steps, "warmup": warmup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic"}
+    if args.frow == "loocv":
+        # the matrix kde!(pGM) sees after a product of --config: D x Nout points of a mixture (SURVEY 8d's generator)
+        pts = synth_inputs(kdehip, D, 1, Nout, 100 * cid + 7)[0][0]
+        bw, ne = kdehip.auto_bandwidth(pts, return_evals=True)
+        obw, one = oracle.auto_bandwidth(pts) if Nout <= 4096 else (None, None)
+        mean_ms, med_ms = timed(lambda: kdehip.auto_bandwidth(pts))
+        k_ms, k_n = timed_kernel(lambda: kdehip.auto_bandwidth(pts), 0)
+        values = float(ne) * Nout * Nout                    # the reference evaluates every marginal at N x N pairs per likelihood
+        flops = values * (4 * 1 + 3)
+        ach = flops / (k_ms * 1e-3) / 1e12
+        cpu = None
+        if not args.no_cpu_baseline and Nout <= 4096:
+            t0 = time.perf_counter()
+            oracle.auto_bandwidth(pts)
+            tc = time.perf_counter() - t0
+            cpu = {"value": 1.0 / tc, "unit": "searches/s", "cores": 1, "kind": "port", "ms": tc * 1e3,
+                   "sample": f"one complete search of the same {D} x {Nout} matrix by oracle/kde_oracle.c (okde_auto_bandwidth)"}
+        out = dict(base, metric="loocv_bandwidth_searches_per_sec", value=1e3 / mean_ms, unit="searches/s", ms_per_step=mean_ms,
+                   ms_per_step_median=med_ms,
+                   value_is="one blocking kdehip_auto_bandwidth call (kde!(points)'s per-dimension golden-section LOOCV search, "
+                            "src/KDE01.jl:3-27, src/CrossValidation.jl:15-120), host matrix in, D bandwidths out",
+                   config={"workload": f"loocv: {D} x {Nout} points (the output shape of a {args.config} product)", "ndims": D,
+                           "npts": Nout, "likelihood_evaluations": int(ne), "pair_values_per_evaluation": Nout * Nout,
+                           "flops_per_value": 7},
+                   roofline={"bound": "valu", "achieved": ach, "peak": peak_tf, "unit": "TFLOP/s", "frac": ach / peak_tf,
+                             "traffic": None, "kernel": "loocv_prep_kernel + loo_round_*_kernel rounds + loo_finalize_kernel",
+                             "kernel_ms": k_ms, "phases_per_search": k_n,
+                             "kernel_ms_is": "HIP events on the search's stream around preparation + every batch of rounds, inside the "
+                                             "library (kdehip_profile_phase_read(0)); includes the ~3.5 us gaps between the dependent launches",
+                             "algorithmic_flops_per_launch": flops,
+                             "note": "values counted as the reference computes them (N x N per evaluation); the kernels form each unordered "
+                                     "pair ONCE (half the exps). A round of a search is latency: ~12 us fixed of ~18 us"},
+                   parity={"bandwidths_equal_oracle_1e-9": (bool(np.allclose(bw, obw, rtol=1e-9, atol=0)) if obw is not None else None),
+                           "evaluation_counts_equal": (int(ne) == int(one) if one is not None else None)},
+                   cpu_baseline=cpu)
+    elif args.frow == "evaluate":
+        pts, bws = synth_inputs(kdehip, D, 1, N, 100 * cid + 8)
+        bd = kdehip.kde(pts[0], bws[0])
+        Nq = 65536
+        pos = synth_inputs(kdehip, D, 1, Nq, 100 * cid + 9)[0][0]
+        p = kdehip.evaluateDualTree(bd, pos)
+        mean_ms, med_ms = timed(lambda: kdehip.evaluateDualTree(bd, pos))
+        k_ms, _ = timed_kernel(lambda: kdehip.evaluateDualTree(bd, pos), 1)
+        values = float(N) * Nq
+        flops = values * (4 * D + 3)
+        ach = flops / (k_ms * 1e-3) / 1e12
+        cpu, par = None, None
+        nqc = min(Nq, max(64, int(2.0e8 / N)))             # ~2e8 kernel values: a few seconds on one core
+        od = oracle.OracleDensity(pts[0], bws[0])
+        t0 = time.perf_counter()
+        po = oracle.eval_direct(od, pos[:, :nqc])
+        tc = time.perf_counter() - t0
+        par = {"max_rel_err_vs_oracle": float(np.max(np.abs(p[:nqc] - po) / np.maximum(np.abs(po), 1e-300))), "queries_compared": nqc}
+        if not args.no_cpu_baseline:
+            cpu = {"value": N * nqc / tc, "unit": "kernel values/s", "cores": 1, "kind": "port",
+                   "sample": f"okde_eval_direct of the same density at the first {nqc} of the {Nq} positions ({tc:.2f} s)"}
+        out = dict(base, metric="kde_evaluation_kernel_values_per_sec", value=values / (mean_ms * 1e-3), unit="kernel values/s",
+                   ms_per_step=mean_ms, ms_per_step_median=med_ms,
+                   value_is="one blocking kdehip_evaluate call (evaluateDualTree(bd, pos) with FORCE_EVAL_DIRECT, "
+                            "src/DualTree01.jl:130-162,303-346,370-446), host buffers in and out (PCIe both ways inside)",
+                   config={"workload": f"evaluate: {D}-D density of {N} points at {Nq} positions", "ndims": D, "npts": N, "nq": Nq,
+                           "flops_per_value": 4 * D + 3},
+                   roofline={"bound": "valu", "achieved": ach, "peak": peak_tf, "unit": "TFLOP/s", "frac": ach / peak_tf, "traffic": None,
+                             "kernel": f"eval_partial_kernel<{D}> + eval_finish_kernel", "kernel_ms": k_ms,
+                             "kernel_ms_is": "HIP events around the two launches inside the library (kdehip_profile_phase_read(1))",
+                             "kernel_values_per_sec": values / (k_ms * 1e-3), "algorithmic_flops_per_launch": flops},
+                   parity=par, cpu_baseline=cpu)
+    else:
+        pts, bws = synth_inputs(kdehip, D, 1, Nout, 100 * cid + 7)
+        x, ks = pts[0], bws[0]
+        bd = kdehip.kde(x, ks)
+        L = int(math.floor(math.log(Nout) / math.log(2.0))) + 1
+        mean_ms, med_ms = timed(lambda: kdehip.kde(x, ks))
+        gpu_ok = bool(clib.kdehip_make_density_device_supported(D, Nout))
+        g1 = g16 = gk1 = gk16 = None
+        same = None
+        if gpu_ok:
+            g = kdehip.kde_batch([(x, ks)])[0]
+            same = all(np.array_equal(getattr(g.bt, a), getattr(bd.bt, a)) for a in
+                       ("centers", "ranges", "weights", "left_child", "right_child", "lowest_leaf", "highest_leaf", "permutation")) and \
+                all(np.array_equal(getattr(g, a), getattr(bd, a)) for a in ("means", "bandwidth"))
+            g1, _ = timed(lambda: kdehip.kde_batch([(x, ks)]))
+            gk1, _ = timed_kernel(lambda: kdehip.kde_batch([(x, ks)]), 2)
+            many = [(synth_inputs(kdehip, D, 1, Nout, 100 * cid + 20 + b)[0][0], ks) for b in range(16)]
+            g16, _ = timed(lambda: kdehip.kde_batch(many))
+            gk16, _ = timed_kernel(lambda: kdehip.kde_batch(many), 2)
+        cpu = None
+        if not args.no_cpu_baseline:
+            t0 = time.perf_counter()
+            for _ in range(5):
+                oracle.OracleDensity(x, ks)
+            tc = (time.perf_counter() - t0) / 5
+            cpu = {"value": 1.0 / tc, "unit": "trees/s", "cores": 1, "kind": "port", "ms": tc * 1e3,
+                   "sample": "5 builds of the same density by oracle/kde_oracle.c (okde_build: the reference's sequential quick-select)"}
+        # every level's quick-select passes read and swap whole points: ~2 passes x (D + 2) doubles x N per level
+        alg_bytes = 2.0 * L * Nout * (D + 2) * 8
+        best_ms = mean_ms
+        out = dict(base, metric="kde_tree_builds_per_sec", value=1e3 / mean_ms, unit="trees/s", ms_per_step=mean_ms, ms_per_step_median=med_ms,
+                   value_is="one kdehip_make_density call (kde!(points, ks): buildTree! + calcStats, src/BallTree01.jl:223-463, "
+                            "src/BallTreeDensity01.jl:141-231) on the library's pooled HOST builder -- the builder every `*` path uses",
+                   config={"workload": f"tree: {D} x {Nout} points", "ndims": D, "npts": Nout, "levels": L,
+                           "host_threads": os.environ.get("KDEHIP_HOST_THREADS", "default (<= 15 workers)")},
+                   roofline={"bound": "hbm", "achieved": alg_bytes / (best_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": alg_bytes / (best_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                             "kernel": "host: balltree.cpp (pooled); GPU: tree_build_kernel (one workgroup per density)",
+                             "kernel_ms": gk1,
+                             "note": "a tree build is a chain of L dependent selections per subtree: latency, not bandwidth -- which is why "
+                                     "ONE density builds faster on the host pool than in one workgroup of the GPU; the GPU builder pays "
+                                     "when many densities are built at once (gpu_builder.batch16)"},
+                   gpu_builder=({"supported": True, "one_density_call_ms": g1, "one_density_kernel_ms": gk1,
+                                 "batch16_call_ms": g16, "batch16_kernel_ms": gk16, "batch16_ms_per_density": g16 / 16.0,
+                                 "arrays_identical_to_host_builder": bool(same)} if gpu_ok else {"supported": False}),
+                   cpu_baseline=cpu)
     print(json.dumps(out), flush=True)
 
 

@@ -555,6 +555,36 @@ __device__ __forceinline__ void lane_rows_all(P rows, int nrows, int RS, int lan
   }
 }
 
+// The same sums of a tile in GLOBAL memory with FOUR rows requested ahead (the fp64 repeat of a screened step reads its
+// fp64 tile through the L2: with lane_rows_all's one row ahead every row waits out most of a ~2,000-cycle round trip, 60,000
+// cycles for 64 rows; with the next trip's four rows in flight behind the current four the loads overlap ~200 fp64
+// instructions).  Same values, same association: a[k] takes its rows r = k (mod 4) in increasing order.  Rows beyond the
+// tile are re-reads of its last row whose values are never added.  Measured (interleaved A/B, profiles/r06_experiments.md):
+// config 4 3.04 -> 2.99 ms, config 3 -0.1 %; EIGHT rows ahead spill (256 VGPRs + scratch) and lose: 3.01 ms.
+template <typename T, typename Eval>
+__device__ __forceinline__ void lane_rows_all_deep(const T *rows, int nrows, int RS, int lane, const Eval &ev, LaneAcc<T> &acc) {
+  using TA = TileAddr<T>;
+  using Row = typename Eval::Row;
+  const T *e = rows + lane * TA::kLane;
+  auto at = [&](int r) { return e + TA::row(r < nrows ? r : nrows - 1, RS); };
+  Row a0 = ev.load(at(0)), a1 = ev.load(at(1)), a2 = ev.load(at(2)), a3 = ev.load(at(3));
+  int i = 0;
+  for (; i + 4 <= nrows; i += 4) {
+    const Row b0 = ev.load(at(i + 4)), b1 = ev.load(at(i + 5)), b2 = ev.load(at(i + 6)), b3 = ev.load(at(i + 7));
+    __builtin_amdgcn_sched_barrier(0);  // keep the requests above the arithmetic
+    const typename Eval::Mid m0 = ev.arg(a0), m1 = ev.arg(a1);
+    const typename Eval::Mid m2 = ev.arg(a2), m3 = ev.arg(a3);
+    acc.a[0] += ev.fin(m0);
+    acc.a[1] += ev.fin(m1);
+    acc.a[2] += ev.fin(m2);
+    acc.a[3] += ev.fin(m3);
+    a0 = b0; a1 = b1; a2 = b2; a3 = b3;
+  }
+  if (i < nrows) acc.a[0] += ev(a0);
+  if (i + 1 < nrows) acc.a[1] += ev(a1);
+  if (i + 2 < nrows) acc.a[2] += ev(a2);
+}
+
 // the canonical lane sum of a whole tile
 template <typename T, typename P, typename Eval, bool PREFETCH = true>
 __device__ __forceinline__ T lane_sum_rows(P rows, int nrows, int RS, int lane, const Eval &ev) {

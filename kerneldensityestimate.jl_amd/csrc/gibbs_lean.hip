@@ -264,6 +264,23 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
     return draw_label<T, P, kPrefetchRows, kKeptRows>(rows, ds, lane, ev, u, fb);
   };
 
+  // the fp64 REPEAT of a screened step on the plan's fp64 tile in global memory: the canonical lane sums with four rows
+  // requested ahead where the registers allow it (up to 7 fields per row: every shared-bandwidth tile, per-node tiles up to
+  // D = 3), then the unchanged selection
+  auto draw_rows_repeat = [&](const auto &ds, const T *rows, const auto &ev, double u) -> int {
+    using Ev = std::decay_t<decltype(ev)>;
+#ifndef KDEHIP_X_NO_DEEP
+    if constexpr (kScreen && sizeof(typename Ev::Row) <= 7 * sizeof(T) && WAVES <= 8) {
+      LaneAcc<T> acc;
+      KDEHIP_PRIO_ROWS();
+      lane_rows_all_deep<T, Ev>(rows, ds.B, TileAddr<T>::stride(ds.F), lane, ev, acc);
+      KDEHIP_PRIO_CHAIN();
+      return select_or_raise<T, const T *>(acc.total(), rows, ds, lane, ev, u, fb);
+    }
+#endif
+    return draw_rows(ds, rows, ev, u);
+  };
+
   // a step on an LDS tile with per-node bandwidths and at most 8 rows per lane whose first row `row` has been requested
   // already: broadcasts, the kept-rows draw (or the single-row one), adoption
 #ifdef KDEHIP_SCREEN_STAMPS
@@ -376,15 +393,15 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
     const float cen = static_cast<float>(mean - mu0);
     const float cf = static_cast<float>(cmin + cov), covf = static_cast<float>(cov);
     const float acen = fabsf(cen);
-    const bool inr = (acen <= kScreenMaxAbsMean) && (covf <= static_cast<float>(kScreenMaxVar));  // (false for a NaN)
-    const bool ok0 = valid != 0.0f && __ballot(lane < D && !inr) == 0ull;
     const float t = fminf(mmax + acen, 2.0f * acen);
     float a2 = lane < D ? t * t * __builtin_amdgcn_rcpf(cf) : 0.0f;
+    // (a2 <= kScreenMaxA2 in every dimension keeps na <= 2^-11, the regime the bound is linearised for: screen_device.hpp)
+    const bool inr = (acen <= kScreenMaxAbsMean) && (covf <= static_cast<float>(kScreenMaxVar)) && (a2 <= kScreenMaxA2);  // (false for a NaN)
+    const bool ok = valid != 0.0f && __ballot(lane < D && !inr) == 0ull;
     a2 += dpp_fetch<0x111, 0xF>(a2);  // row_shr:1, 2, 4: lane 7 holds the sum over the (at most 8) dimension lanes
     a2 += dpp_fetch<0x112, 0xF>(a2);
     a2 += dpp_fetch<0x114, 0xF>(a2);
     const float na = __builtin_sqrtf(lane_read(a2, 7)) * (kScreenU * kScreenSqrtC0 * 1.01f);
-    const bool ok = ok0 && na <= kScreenMaxNa;  // (the bound is linearised in na (1 + |x|): screen_device.hpp; false for a NaN)
     using SC = ScreenConst<D>;
     const float Bc = (kScreenLn2 * 1.01f) * (na + (ds.uniform_bw ? SC::kx_uni : SC::kx_node) * kScreenU);
     const float A = (kScreenLn2 * 1.01f) * na +
@@ -421,7 +438,7 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
     if (pos < 0) {
       ++n_repeated;
       pos = __builtin_amdgcn_readfirstlane(draw(ds, hdrg, mean, cov, [&](const auto &ev) {
-        return draw_rows(ds, hdrg + kTileHeader, ev, u);
+        return draw_rows_repeat(ds, hdrg + kTileHeader, ev, u);
       }));
     }
     adopt(jc, ds, hdrg, pos);
@@ -443,12 +460,17 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
       const float cen = static_cast<float>(mean - mu0);
       const float cf = static_cast<float>(cmin + cov), covf = static_cast<float>(cov);
       const float acen = fabsf(cen);
-      const bool inr = (acen <= kScreenMaxAbsMean) && (covf <= static_cast<float>(kScreenMaxVar));  // (false for a NaN)
+      const float t = fminf(mmax + acen, 2.0f * acen);
+      float a2 = lane < D ? t * t * __builtin_amdgcn_rcpf(cf) : 0.0f;
+      // (a2 <= kScreenMaxA2 in every dimension keeps na <= 2^-11, the regime the bound is linearised for: screen_device.hpp)
+#ifndef KDEHIP_X_NO_NA_GUARD
+      const bool inr = (acen <= kScreenMaxAbsMean) && (covf <= static_cast<float>(kScreenMaxVar)) && (a2 <= kScreenMaxA2);  // (false for a NaN)
+#else
+      const bool inr = (acen <= kScreenMaxAbsMean) && (covf <= static_cast<float>(kScreenMaxVar));
+#endif
       int pos = -1;
       const T *hdrg = data + ds.hdr_off();
       if (valid != 0.0f && __ballot(lane < D && !inr) == 0ull) {
-        const float t = fminf(mmax + acen, 2.0f * acen);
-        float a2 = lane < D ? t * t * __builtin_amdgcn_rcpf(cf) : 0.0f;
         a2 += dpp_fetch<0x111, 0xF>(a2);  // row_shr:1, 2, 4: lane 7 holds the sum over the (at most 8) dimension lanes
         a2 += dpp_fetch<0x112, 0xF>(a2);
         a2 += dpp_fetch<0x114, 0xF>(a2);
@@ -458,9 +480,7 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
         const float A = (kScreenLn2 * 1.01f) * na +
                         (static_cast<float>(((ds.B + 1) >> 1) + 9) + (ds.uniform_bw ? SC::vc_uni : SC::vc_node)) * kScreenU;
         const LdsPtr<float> rows32 = h32 + kScreenHeaderFloats;
-        if (!(na <= kScreenMaxNa)) {
-          // outside the regime the bound is linearised for (screen_device.hpp "Range checks"): the step runs in fp64
-        } else if (ds.uniform_bw) {
+        if (ds.uniform_bw) {
           ScreenEval<D, true> ev;
           ev.A = A; ev.Bc = Bc;
           const float ninv = -kScreenC0 * __builtin_amdgcn_rcpf(cf);
@@ -491,7 +511,7 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
       if (pos < 0) {  // not certified (or out of the screen's range): the fp64 draw on the fp64 tile
         ++n_repeated;
         pos = __builtin_amdgcn_readfirstlane(draw(ds, hdrg, mean, cov, [&](const auto &ev) {
-          return draw_rows(ds, hdrg + kTileHeader, ev, u);
+          return draw_rows_repeat(ds, hdrg + kTileHeader, ev, u);
         }));
       }
       SSTAMP(ts3);

@@ -148,6 +148,10 @@ constexpr double kScreenMinVar = 1.0 / 128.0, kScreenMaxVar = 256.0;  // varianc
 // (2.1 E against 2 E): exp(d) - 1 <= 1.06 d needs d = ln2 na (1 + |x|) <= 0.11, and |x| < 127 wherever a value is not
 // flushed to zero -- so na <= 2^-11 (d <= 0.044) keeps it rigorous; typical data have na ~ 2^-19.
 constexpr float kScreenMaxNa = 0x1p-11f;
+// ... enforced per dimension, with the step's other range checks: na = 1.01 u sqrt(c0) sqrt(sum_d a2_d), a2_d = (g_d / sigma_d)^2,
+// so a2_d <= (kScreenMaxNa / (1.01 u sqrt(c0)))^2 / 8 = 1.14e7 in each of the (at most 8) dimensions is sufficient
+// (g / sigma <= 3376 per dimension; typical data: < 100)
+constexpr float kScreenMaxA2 = 1.14e7f;
 
 // Conditional table of density j on level l (see gibbs_kernel.hip "conditional tables"): rows of n+1
 // values (inclusive scan over the n frontier nodes, then the total).  Only levels whose frontier sizes
