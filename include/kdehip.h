@@ -99,6 +99,30 @@ int kdehip_gibbs1_multi(int Ndens, const kdehip_density *trees, int64_t Np, int 
                         int addEntropy, int ndims, const uint8_t *partialDimMask, int device, int ngpus,
                         int32_t *labels);
 
+/* ---- manifolds: the operator tuples addop / diffop / getMu / getLambda as an ENUM ------------------------------------
+ * The reference takes its on-manifold operators as per-dimension Julia FUNCTIONS (src/MSGibbs01.jl:650-653, broadcast at
+ * :672-675) and applies them at three hook points: diffop inside every kernel evaluation (:290), getLambda / getMu in the
+ * Gaussian product (:183-184, applied :210-213), addop where a sample is composed with its noise (:456).  Functions
+ * cannot cross a C ABI, and the reference itself defines only the Euclidean set (its callers bring the others): this
+ * entry takes, per dimension, KDEHIP_MANIFOLD_EUCLIDEAN (the reference's defaults) or KDEHIP_MANIFOLD_CIRCULAR with THIS
+ * library's stated semantic -- nothing in the reference pins it:
+ *     wrap(t)        = t - 2 pi floor((t + pi) / (2 pi))            in [-pi, pi)
+ *     diffop(a, b)   = wrap(a - b)         addop(a, b) = wrap(a + b)         getLambda(lambdas) = sum(lambdas)
+ *     getMu(mus, lambdas, scale) = addop(ref, scale * sum_j lambdas_j diffop(mus_j, ref)),  ref = mus of the first j with
+ *                      lambdas_j > 0   (the information-weighted mean in the tangent space at ref; the Euclidean formula
+ *                      whenever no difference wraps)
+ * The densities are the caller's arrays as built (the reference's tree construction has hooks of its own,
+ * src/BallTree01.jl:315, which are the caller's business).  Runs the general sampler's generic arithmetic (the
+ * reference's divide + log accumulation); caller streams in the reference's order, as kdehip_gibbs1_trace.  manifold == NULL
+ * = all Euclidean = kdehip_gibbs1_trace.  oracle/kde_oracle.c okde_gibbs1_manifold is the same enum on the CPU; the Julia
+ * shim maps NOTHING to it automatically (a caller's circular functions need not be these). */
+#define KDEHIP_MANIFOLD_EUCLIDEAN 0
+#define KDEHIP_MANIFOLD_CIRCULAR 1
+int kdehip_gibbs1_manifold(int Ndens, const kdehip_density *trees, int64_t Np, int Niter, double *pts, int64_t *ind,
+                           const double *randU, int64_t nU, const double *randN, int64_t nN, int addEntropy, int ndims,
+                           const uint8_t *partialDimMask, const uint8_t *manifold /* ndims bytes or NULL */, int device,
+                           int32_t *labels /* optional */);
+
 /* prodAppxMSGibbsS when the caller passes no randU / randN (reference src/MSGibbs01.jl:645-703; its
  * `rand(...)` / `randn(...)` defaults, :661-662, are replaced by the on-device Philox4x32-10 stream keyed by
  * (seed, sample index, draw index): kdehip_philox_fill_* reproduce the numbers).  One-shot: pack, upload, run,

@@ -65,6 +65,8 @@ SIGNATURES = {
                                       f64p, C.c_int64, C.c_int, C.c_int, u8p, C.c_int, i32p]),
     "kdehip_gibbs1_multi": (C.c_int, [C.c_int, C.POINTER(CDensity), C.c_int64, C.c_int, f64p, i64p, f64p, C.c_int64,
                                       f64p, C.c_int64, C.c_int, C.c_int, u8p, C.c_int, C.c_int, i32p]),
+    "kdehip_gibbs1_manifold": (C.c_int, [C.c_int, C.POINTER(CDensity), C.c_int64, C.c_int, f64p, i64p, f64p, C.c_int64,
+                                         f64p, C.c_int64, C.c_int, C.c_int, u8p, u8p, C.c_int, i32p]),
     "kdehip_prod_philox": (C.c_int, [C.c_int, C.POINTER(CDensity), C.c_int64, C.c_int, f64p, i64p, C.c_uint64, C.c_int,
                                      C.c_int, u8p, C.c_int, C.c_int, C.c_int, i32p]),
     "kdehip_product_multi_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(CDensity), C.c_int, u8p,

@@ -396,17 +396,28 @@ struct EvalFast {
   }
 };
 
-// GENERIC: literally the reference's accumulation (:280-303) incl. inactive dimensions.
+// The circular (2 pi) member of the enumerated manifolds (include/kdehip.h "manifolds"; no reference counterpart -- the
+// reference takes its operators as callbacks, src/MSGibbs01.jl:650-653): wrap to [-pi, pi).  Same expression, same
+// constants as oracle/kde_oracle.c circ_wrap (fp64: bit for bit).
+template <typename T>
+__device__ __forceinline__ T circ_wrap(T t) {
+  constexpr double kTwoPi = 6.283185307179586476925286766559, kPi = 3.141592653589793238462643383279;
+  return t - T(kTwoPi) * floor((t + T(kPi)) / T(kTwoPi));
+}
+
+// GENERIC: literally the reference's accumulation (:280-303) incl. inactive dimensions; `circ` bit d = the difference of
+// dimension d is the circular diffop (:290).
 template <typename T, int D, bool OFF = false>
 struct EvalGeneric {
   T center[D], cov[D];
   T xoff;
   uint32_t act;
+  uint32_t circ = 0;
   __device__ __forceinline__ EvalGeneric<T, D, true> with_offset(T o) const {
     EvalGeneric<T, D, true> e;
 #pragma unroll
     for (int d = 0; d < D; ++d) { e.center[d] = center[d]; e.cov[d] = cov[d]; }
-    e.act = act; e.xoff = o;
+    e.act = act; e.circ = circ; e.xoff = o;
     return e;
   }
   struct Row { T m[D], v[D], w; };
@@ -424,7 +435,8 @@ struct EvalGeneric {
     for (int d = 0; d < D; ++d) {
       if ((act >> d) & 1u) {
         const T c = row.v[d] + cov[d];
-        const T dl = row.m[d] - center[d];
+        T dl = row.m[d] - center[d];
+        if ((circ >> d) & 1u) dl = circ_wrap(dl);
         const T distr = (dl * dl) / c;
         if (distr == distr) {
           acc += distr;

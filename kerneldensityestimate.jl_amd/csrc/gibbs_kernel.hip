@@ -127,7 +127,8 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan_
     const T l = on ? (FAST ? fast_rcp(var) : T(1) / var) : T(0);
     if (lane < D) {
       lam[j * D + dl] = l;
-      lmu[j * D + dl] = on ? mu * l : T(0);
+      // (a circular dimension keeps the angle itself: its getMu works on the angles, product_dim below)
+      lmu[j * D + dl] = on ? ((!FAST && ((plan.circ_bits >> dl) & 1u)) ? mu : mu * l) : T(0);
     }
     if (lane == 0) psel[j] = pos;
   };
@@ -142,6 +143,30 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan_
     if (skip >= 0) {
       if (lane < D) { lam[skip * D + dl] = T(0); lmu[skip * D + dl] = T(0); }
       wave_sync();
+    }
+    if constexpr (!FAST) {
+      // The enumerated circular operators (include/kdehip.h "manifolds") at the reference's hooks getLambda / getMu
+      // (:183-184, applied :210-213): getLambda = the same sum; getMu = the information-weighted mean in the tangent space at
+      // the FIRST contributing kernel's angle, mapped back -- the sums in density order, as oracle/kde_oracle.c forms them.
+      if (plan.circ_bits != 0u) {  // (wave-uniform; plans without a circular dimension never come here)
+        const bool circ = (plan.circ_bits >> dl) & 1u;
+        T ls = T(0), ref = T(0);
+        bool have = false;
+        for (int k = 0; k < M; ++k) {
+          const T l = lam[k * D + dl];
+          ls += l;
+          if (!have && l > T(0)) { ref = lmu[k * D + dl]; have = true; }
+        }
+        T acc = T(0);
+        for (int k = 0; k < M; ++k) {
+          const T l = lam[k * D + dl], m = lmu[k * D + dl];
+          acc += circ ? l * circ_wrap(m - ref) : m;  // (Euclidean slots hold mean * lambda already)
+        }
+        const bool on = kAllDimsOn || ((info_bits >> dl) & 1u);
+        cov = on ? T(1) / ls : T(0);
+        mean = on ? (circ ? circ_wrap(ref + cov * acc) : cov * acc) : T(0);
+        return;
+      }
     }
     T ls = T(0), ms = T(0);
     int k = 0;
@@ -200,6 +225,7 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan_
     } else {
       EvalGeneric<T, D> ev;
       ev.act = ds.mask_bits & ds.others_bits;
+      ev.circ = plan.circ_bits;  // (diffop of the circular dimensions, :290)
 #pragma unroll
       for (int d = 0; d < D; ++d) {
         ev.center[d] = lane_read(mean, d);
@@ -390,6 +416,9 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan_
       T mean, cov;
       product_dim(-1, any_bits, mean, cov);
       x = mean + Num<T>::sqrt(cov) * static_cast<T>(normal_for_lane(l - 1));
+      if constexpr (!FAST) {
+        if ((plan.circ_bits >> dl) & 1u) x = circ_wrap(x);  // addop of a circular dimension (:456)
+      }
     }
     const int mode = vlev == 1 ? int(kStageGlobal) : levels[l].stage_mode;
 
@@ -539,7 +568,12 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_product_kernel(PlanDev plan_
     T mean, cov;
     product_dim(-1, any_bits, mean, cov);
     T xf = mean;
-    if (a.addEntropy) xf = mean + Num<T>::sqrt(cov) * static_cast<T>(normal_for_lane(L));
+    if (a.addEntropy) {
+      xf = mean + Num<T>::sqrt(cov) * static_cast<T>(normal_for_lane(L));
+      if constexpr (!FAST) {
+        if ((plan.circ_bits >> dl) & 1u) xf = circ_wrap(xf);
+      }
+    }
     if (live && lane < D) {
       a.points[s * D + lane] = static_cast<double>(xf);
       for (int q = 0; q < a.npeers; ++q) a.peer_points[q][s * D + lane] = static_cast<double>(xf);

@@ -180,7 +180,10 @@ struct PlanDev {
   int64_t tab_rows_total;
   int32_t M, L, D, Lt;       // Lt: levels 1..Lt are tabulated (0 = none)
   int32_t screened;          // 1: the plan carries screen tiles (descriptors behind the level table) and they are built; 2: some chunked
-  int32_t reserved_[3];
+  // bit d: dimension d is CIRCULAR (2 pi) -- the enumerated on-manifold operators of include/kdehip.h "manifolds", applied at
+  // the reference's hook points (src/MSGibbs01.jl:290, 183-184 / 210-213, 456) by the general sampler's generic mode only
+  uint32_t circ_bits;
+  int32_t reserved_[2];
 };
 
 constexpr int kMaxPeers = 7;  // other GPUs of one node

@@ -244,7 +244,7 @@ struct PlanImage {
 };
 
 int build_image(PlanImage &im, int Ndens, const kdehip_density *trees, int ndims, const uint8_t *partialDimMask,
-                int precision) {
+                int precision, bool force_generic = false) {
   if (precision != 64 && precision != 32) return set_error(KDEHIP_ERR_ARG, "precision must be 64 or 32");
   static const bool timing = std::getenv("KDEHIP_TIMING") != nullptr;
   const auto t0 = std::chrono::steady_clock::now();
@@ -254,6 +254,7 @@ int build_image(PlanImage &im, int Ndens, const kdehip_density *trees, int ndims
   // as much as the fill (random accesses into the tree arrays).  The rare density set that does not qualify is laid
   // out again in the generic form and refilled.
   for (PackMode pmode : {kPackOptimistic, kPackGeneric}) {
+    if (force_generic && pmode != kPackGeneric) continue;  // (on-manifold operators run the reference's own accumulation)
     int rc = pack_layout(Ndens, trees, ndims, partialDimMask, precision, im.host, pmode);
     if (rc != KDEHIP_OK) return rc;
     const double us_layout = us();
@@ -567,7 +568,17 @@ struct Shard {
 // randU == nullptr: device Philox stream keyed by (seed, global sample index); otherwise the caller's streams.
 int one_shot(int Ndens, const kdehip_density *trees, int64_t Np, int Niter, double *pts, int64_t *ind,
              const double *randU, int64_t nU, const double *randN, int64_t nN, uint64_t seed, int addEntropy,
-             int ndims, const uint8_t *partialDimMask, int precision, int device, int ngpus, int32_t *labels) {
+             int ndims, const uint8_t *partialDimMask, int precision, int device, int ngpus, int32_t *labels,
+             const uint8_t *manifold = nullptr) {
+  // the enumerated manifolds (kdehip.h "manifolds"): bit d of circ_bits = dimension d is circular
+  uint32_t circ_bits = 0;
+  if (manifold) {
+    if (ndims < 1 || ndims > KDEHIP_MAX_DIMS) return set_error(KDEHIP_ERR_UNSUPPORTED, "ndims outside 1..KDEHIP_MAX_DIMS");
+    for (int d = 0; d < ndims; ++d) {
+      if (manifold[d] > KDEHIP_MANIFOLD_CIRCULAR) return set_error(KDEHIP_ERR_ARG, "manifold: 0 (Euclidean) or 1 (circular) per dimension");
+      if (manifold[d] == KDEHIP_MANIFOLD_CIRCULAR) circ_bits |= 1u << d;
+    }
+  }
   int rc = check_devices(device, ngpus);
   if (rc != KDEHIP_OK) {
     // argument errors of the product itself take precedence over "no device" only when they are detectable
@@ -589,7 +600,7 @@ int one_shot(int Ndens, const kdehip_density *trees, int64_t Np, int Niter, doub
       for (int d : devs) if (g.enter(d) == KDEHIP_OK) (void)hipStreamSynchronize(call_stream());
     }
   };
-  rc = build_image(im, Ndens, trees, ndims, partialDimMask, precision);
+  rc = build_image(im, Ndens, trees, ndims, partialDimMask, precision, /*force_generic=*/circ_bits != 0u);
   if (rc != KDEHIP_OK) return rc;
   const double us_pack = us_since(t_begin);
   if (Np < 0) return set_error(KDEHIP_ERR_ARG, "Np must be >= 0");
@@ -625,6 +636,7 @@ int one_shot(int Ndens, const kdehip_density *trees, int64_t Np, int Niter, doub
     drain.devs.push_back(S.device);
     rc = instantiate(im, S.device, &S.plan, /*wait=*/false);  // the upload overlaps the host side of the launches
     if (rc != KDEHIP_OK) return rc;
+    S.plan->dev.circ_bits = circ_bits;
     rc = guard.enter(S.device);
     if (rc != KDEHIP_OK) return rc;
     const int64_t useU = streams ? ((nU - S.lo * K < n * K) ? nU - S.lo * K : n * K) : 0, useN = streams ? n * R : 0;
@@ -698,6 +710,14 @@ int kdehip_gibbs1_multi(int Ndens, const kdehip_density *trees, int64_t Np, int 
   static const double kNone = 0.0;  // (a null stream pointer must mean "too short", not "use Philox")
   return one_shot(Ndens, trees, Np, Niter, pts, ind, randU ? randU : &kNone, randU ? nU : 0, randN ? randN : &kNone,
                   randN ? nN : 0, 0, addEntropy, ndims, partialDimMask, 64, device, ngpus, labels);
+}
+
+int kdehip_gibbs1_manifold(int Ndens, const kdehip_density *trees, int64_t Np, int Niter, double *pts, int64_t *ind,
+                           const double *randU, int64_t nU, const double *randN, int64_t nN, int addEntropy, int ndims,
+                           const uint8_t *partialDimMask, const uint8_t *manifold, int device, int32_t *labels) {
+  static const double kNone = 0.0;
+  return one_shot(Ndens, trees, Np, Niter, pts, ind, randU ? randU : &kNone, randU ? nU : 0, randN ? randN : &kNone,
+                  randN ? nN : 0, 0, addEntropy, ndims, partialDimMask, 64, device, 1, labels, manifold);
 }
 
 int kdehip_prod_philox(int Ndens, const kdehip_density *trees, int64_t Np, int Niter, double *pts, int64_t *ind,

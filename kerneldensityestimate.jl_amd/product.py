@@ -437,11 +437,25 @@ def makeEmptyGbGlb(recordChoosen=False):
     return GbGlb(recordChoosen)
 
 
+def _manifold_array(manifold, ndims):
+    """per-dimension manifold enum of include/kdehip.h "manifolds": None, or a sequence of 0 / 'euclid' / 1 / 'circular'"""
+    if manifold is None:
+        return None
+    names = {"euclid": 0, "euclidean": 0, "circular": 1, "circ": 1}
+    vals = [names[m.lower()] if isinstance(m, str) else int(m) for m in manifold]
+    if len(vals) != ndims:
+        raise ValueError("manifold needs one entry per dimension")
+    return np.ascontiguousarray(vals, dtype=np.uint8)
+
+
 def gibbs1(Ndens, trees, Np, Niter, pts, ind, randU, randN, *, addEntropy=True, ndims=None,
-           partialDimMask=None, glbs=None, device=0, ngpus=1):
+           partialDimMask=None, glbs=None, device=0, ngpus=1, manifold=None):
     """`gibbs1` (reference src/MSGibbs01.jl:527-537): fills the caller's `pts` (length ndims*Np,
     column-major) and `ind` (Ndens x Np, column-major) in place; returns None.  With
-    `glbs.recordChoosen` the label trace lands in `glbs.labelsChoosen` as in the reference."""
+    `glbs.recordChoosen` the label trace lands in `glbs.labelsChoosen` as in the reference.
+    `manifold`: the reference's operator tuples addop / diffop / getMu / getLambda (:650-653) as a per-dimension ENUM --
+    'euclid' (the defaults) or 'circular' (wrap to [-pi, pi), tangent-space mean; this library's stated semantic,
+    include/kdehip.h "manifolds") -- kdehip_gibbs1_manifold."""
     trees = list(trees)
     if ndims is None:
         ndims = max(Ndim(t) for t in trees)
@@ -458,11 +472,19 @@ def gibbs1(Ndens, trees, Np, Niter, pts, ind, randU, randN, *, addEntropy=True, 
     labels = None
     if glbs is not None and glbs.recordChoosen:
         labels = np.zeros((Np, Ndens, nlevels(max(Npts(t) for t in trees))), dtype=np.int32)
-    _lib.check(_lib.lib.kdehip_gibbs1_multi(int(Ndens), arr, int(Np), int(Niter), ptr(pts.reshape(-1), f64p),
-                                            ptr(tmp_ind, i64p), ptr(randU, f64p), randU.size, ptr(randN, f64p),
-                                            randN.size, int(bool(addEntropy)), int(ndims),
-                                            None if mask is None else ptr(mask, u8p), int(device), int(ngpus),
-                                            None if labels is None else ptr(labels, i32p)))
+    man = _manifold_array(manifold, ndims)
+    if man is not None:
+        _lib.check(_lib.lib.kdehip_gibbs1_manifold(int(Ndens), arr, int(Np), int(Niter), ptr(pts.reshape(-1), f64p),
+                                                   ptr(tmp_ind, i64p), ptr(randU, f64p), randU.size, ptr(randN, f64p),
+                                                   randN.size, int(bool(addEntropy)), int(ndims),
+                                                   None if mask is None else ptr(mask, u8p), ptr(man, u8p), int(device),
+                                                   None if labels is None else ptr(labels, i32p)))
+    else:
+        _lib.check(_lib.lib.kdehip_gibbs1_multi(int(Ndens), arr, int(Np), int(Niter), ptr(pts.reshape(-1), f64p),
+                                                ptr(tmp_ind, i64p), ptr(randU, f64p), randU.size, ptr(randN, f64p),
+                                                randN.size, int(bool(addEntropy)), int(ndims),
+                                                None if mask is None else ptr(mask, u8p), int(device), int(ngpus),
+                                                None if labels is None else ptr(labels, i32p)))
     if labels is not None:
         glbs._fill(labels, Niter)
     if ind.ndim == 2:
@@ -475,14 +497,15 @@ def gibbs1(Ndens, trees, Np, Niter, pts, ind, randU, randN, *, addEntropy=True, 
 def prodAppxMSGibbsS(npd0, trees, anFcns=None, anParams=None, *deprecated_niter, Niter=3, addEntropy=True, ndims=None,
                      Ndens=None, Np=None, maxNp=None, Nlevels=None, randU=None, randN=None, partialDimMask=None,
                      addop=None, diffop=None, getMu=None, getLambda=None, glbs=None,
-                     seed=None, device=0, precision=64, ngpus=1):
+                     seed=None, device=0, precision=64, ngpus=1, manifold=None):
     """`prodAppxMSGibbsS` (reference src/MSGibbs01.jl:645-703).
 
     npd0 only supplies Np = Npts(npd0) (:658); anFcns/anParams are ignored as in the reference
     (:677-678).  With `randU`/`randN` given they are consumed exactly as the reference consumes
     them; otherwise (the reference would call rand/randn) the on-device Philox stream keyed by
     `seed` is used.  Returns (points[ndims, Np], indices[Ndens, Np]).
-    Non-Euclidean addop/diffop/getMu/getLambda cannot cross the C ABI and are rejected.
+    Non-Euclidean addop/diffop/getMu/getLambda FUNCTIONS cannot cross the C ABI and are rejected; `manifold=` gives the
+    four tuples as a per-dimension enum instead ('euclid' / 'circular': see `gibbs1`).
     `maxNp` / `Nlevels` only size the reference's default random arrays (:659-662; `gibbs1` recomputes the level
     count from the trees, :568) and are accepted and ignored; a fifth positional argument is the deprecated
     positional `Niter` (:632-643).
@@ -507,11 +530,18 @@ def prodAppxMSGibbsS(npd0, trees, anFcns=None, anParams=None, *deprecated_niter,
         Np = Npts(npd0)
     if (randU is None) != (randN is None):
         raise ValueError("give both randU and randN, or neither")
+    if manifold is not None and randU is None:
+        # the manifold entry consumes caller streams: the host twin of the device stream gives the run the numbers the
+        # Philox path would have drawn for `seed`
+        if seed is None:
+            seed = int.from_bytes(os.urandom(8), "little")
+        L = nlevels(max(Npts(t) for t in trees[:Ndens]))
+        randU, randN = philox_streams(seed, 0, Np, Ndens * (1 + L * (Niter + 1)), ndims * (L + 1))
     if randU is not None:
         points = np.zeros(ndims * Np)
         indices = np.ones((Ndens, Np), dtype=np.int64)
         gibbs1(Ndens, trees, Np, Niter, points, indices, randU, randN, addEntropy=addEntropy, ndims=ndims,
-               partialDimMask=partialDimMask, glbs=glbs, device=device, ngpus=ngpus)
+               partialDimMask=partialDimMask, glbs=glbs, device=device, ngpus=ngpus, manifold=manifold)
         return points.reshape(Np, ndims).T.copy(), indices
     if seed is None:
         seed = int.from_bytes(os.urandom(8), "little")

@@ -231,6 +231,11 @@ typedef struct {
   int Ndens, Ndim, Nlevels;
   const okde_tree *trees;
   const uint8_t *mask; /* [Ndens*Ndim], 1 = active; NULL = all active */
+  /* per-dimension manifold of the operator tuples addop / diffop / getMu / getLambda (src/MSGibbs01.jl:650-653): NULL or
+   * 0 = Euclidean (the reference's defaults (+,), (-,), getEuclidMu, getEuclidLambda); 1 = CIRCULAR(2 pi).  The reference
+   * repo defines no circular operators (its callers bring them): the semantic below is THIS repo's, stated in
+   * include/kdehip.h "manifolds" -- the hook points are the reference's. */
+  const uint8_t *manifold;
   double *particles, *variance; /* [Ndim x Ndens] column-major as the reference (:3-4) */
   double *p;
   int64_t *ind;
@@ -267,7 +272,17 @@ static void update_particle(okde_glb *g, int j) {
 /* calcIndices! :123-130 */
 static void calc_indices(okde_glb *g) { for (int j = 0; j < g->Ndens; ++j) update_particle(g, j); }
 
-/* gaussianProductMeanCov! :176-216 with getEuclidLambda :141 and getEuclidMu :152-161.
+/* ---- the enumerated CIRCULAR(2 pi) operators (no reference counterpart: see okde_glb.manifold) ----
+ * wrap(t) = t - 2 pi floor((t + pi) / (2 pi)) in [-pi, pi); diffop(a, b) = wrap(a - b); addop(a, b) = wrap(a + b);
+ * getLambda = sum (as Euclidean); getMu(mus, lambdas, scale) = addop(ref, scale * sum_j lambda_j diffop(mu_j, ref)) with
+ * ref = the mu of the FIRST contributing density (lambda_j > 0): the information-weighted mean in the tangent space at
+ * ref, mapped back -- it equals the Euclidean formula whenever no difference wraps. */
+static const double OKDE_TWO_PI = 6.283185307179586476925286766559, OKDE_PI = 3.141592653589793238462643383279;
+static double circ_wrap(double t) { return t - OKDE_TWO_PI * floor((t + OKDE_PI) / OKDE_TWO_PI); }
+static int is_circ(const okde_glb *g, int dim) { return g->manifold && g->manifold[dim] == 1; }
+
+/* gaussianProductMeanCov! :176-216 with getEuclidLambda :141 and getEuclidMu :152-161 (or the circular pair above: the
+ * hooks getLambda / getMu of :183-184, applied at :210-213).
  * skip is a 0-based density index, or -1 for "none". */
 static void gaussian_product(okde_glb *g, int dim, double *destMu, double *destCov, int skip) {
   *destMu = 0.0;
@@ -287,9 +302,18 @@ static void gaussian_product(okde_glb *g, int dim, double *destMu, double *destC
   double lam = 0.0;
   for (int j = 0; j < g->Ndens; ++j) lam += g->calclambdas[j];
   double cov = 1.0 / lam;
+  *destCov = cov;
+  if (is_circ(g, dim)) {
+    int first = -1;
+    for (int j = 0; j < g->Ndens && first < 0; ++j) if (g->calclambdas[j] > 0.0) first = j;
+    const double ref = first >= 0 ? g->calcmu[first] : 0.0;
+    double acc = 0.0;
+    for (int j = 0; j < g->Ndens; ++j) acc += g->calclambdas[j] * circ_wrap(g->calcmu[j] - ref);
+    *destMu = circ_wrap(ref + cov * acc);
+    return;
+  }
   double lambdamu = 0.0;
   for (int j = 0; j < g->Ndens; ++j) lambdamu += g->calcmu[j] * g->calclambdas[j];
-  *destCov = cov;
   *destMu = cov * lambdamu;
 }
 
@@ -322,7 +346,8 @@ static void make_sample_index(okde_glb *g, int j, const double *muValue, const d
       if (!mask_at(g, j, i) || !dimmask[i]) continue;
       double tmpC = t_bw(t, zz, i);
       if (doCalmost) tmpC += covValue[i];
-      double tmpM = t_mean(t, zz, i) - muValue[i];
+      double tmpM = t_mean(t, zz, i) - muValue[i];           /* diffop[i] :290 */
+      if (is_circ(g, i)) tmpM = circ_wrap(tmpM);
       double distr = (tmpM * tmpM) / tmpC;
       if (!isnan(distr)) {
         acc += distr;
@@ -386,7 +411,8 @@ static void sample_point(okde_glb *g, double *X, int addEntropy) {
     g->rnptr += 1;
     if (addEntropy) {
       if (g->rnptr < 1 || g->rnptr > g->nN) { g->err = OKDE_ERR_RANDN; X[d] = mn; continue; }
-      X[d] = mn + sqrt(vn) * g->randN[g->rnptr - 1];
+      X[d] = mn + sqrt(vn) * g->randN[g->rnptr - 1];         /* addop[dim] :456 */
+      if (is_circ(g, d)) X[d] = circ_wrap(X[d]);
     } else {
       X[d] = mn;
     }
@@ -508,6 +534,32 @@ int okde_gibbs1_range(int Ndens, const okde_tree *trees, int64_t s_begin, int64_
   const int64_t K = okde_randu_per_sample(Ndens, g.Nlevels, Niter);
   const int64_t R = okde_randn_per_sample(ndims, g.Nlevels);
   for (int64_t s = s_begin; s < s_end && !g.err; ++s) {
+    g.ruptr = s * K;
+    g.rnptr = s * R;
+    gibbs_one_sample(&g, s, Niter, pts, ind, addEntropy);
+  }
+  rc = g.err;
+  glb_free(&g);
+  return rc;
+}
+
+/* gibbs1 with a per-dimension manifold (okde_glb.manifold: ndims bytes, 0 Euclidean / 1 circular; NULL = all Euclidean) */
+int okde_gibbs1_manifold(int Ndens, const okde_tree *trees, int64_t Np, int Niter, double *pts, int64_t *ind,
+                         const double *randU, int64_t nU, const double *randN, int64_t nN, int addEntropy,
+                         int ndims, const uint8_t *partialDimMask, const uint8_t *manifold, int32_t *labels) {
+  if (Ndens < 1 || ndims < 1 || ndims > 64) return OKDE_ERR_ARG;
+  for (int j = 0; j < Ndens; ++j)
+    if (trees[j].ndim != ndims || trees[j].npts < 1) return OKDE_ERR_ARG;
+  if (manifold)
+    for (int d = 0; d < ndims; ++d) if (manifold[d] > 1) return OKDE_ERR_ARG;
+  okde_glb g;
+  int rc = glb_alloc(&g, Ndens, trees, ndims, partialDimMask);
+  if (rc) { glb_free(&g); return rc; }
+  g.manifold = manifold;
+  g.randU = randU; g.nU = nU; g.randN = randN; g.nN = nN; g.labels = labels;
+  const int64_t K = okde_randu_per_sample(Ndens, g.Nlevels, Niter);
+  const int64_t R = okde_randn_per_sample(ndims, g.Nlevels);
+  for (int64_t s = 0; s < Np && !g.err; ++s) {
     g.ruptr = s * K;
     g.rnptr = s * R;
     gibbs_one_sample(&g, s, Niter, pts, ind, addEntropy);

@@ -50,6 +50,13 @@ int okde_gibbs1(int Ndens, const okde_tree *trees, int64_t Np, int Niter, double
                 const double *randU, int64_t nU, const double *randN, int64_t nN, int addEntropy,
                 int ndims, const uint8_t *partialDimMask, int32_t *labels);
 
+/* gibbs1 with the operator tuples addop / diffop / getMu / getLambda (src/MSGibbs01.jl:650-653) given as a per-dimension
+ * ENUM: manifold[d] = 0 Euclidean (the reference's defaults), 1 = circular (2 pi) -- wrap to [-pi, pi), tangent-space mean at
+ * the first contributing kernel; this repo's stated semantic, applied at the reference's hook points (:290, :183-184 /
+ * :210-213, :456).  manifold == NULL: identical to okde_gibbs1. */
+int okde_gibbs1_manifold(int Ndens, const okde_tree *trees, int64_t Np, int Niter, double *pts, int64_t *ind,
+                         const double *randU, int64_t nU, const double *randN, int64_t nN, int addEntropy,
+                         int ndims, const uint8_t *partialDimMask, const uint8_t *manifold, int32_t *labels);
 int okde_gibbs1_range(int Ndens, const okde_tree *trees, int64_t s_begin, int64_t s_end, int Niter,
                       double *pts, int64_t *ind, const double *randU, int64_t nU, const double *randN,
                       int64_t nN, int addEntropy, int ndims, const uint8_t *partialDimMask,

@@ -59,6 +59,9 @@ def lib():
         L.okde_gibbs1.restype = C.c_int
         L.okde_gibbs1.argtypes = [C.c_int, C.POINTER(_Tree), C.c_int64, C.c_int, _f64p, _i64p, _f64p,
                                   C.c_int64, _f64p, C.c_int64, C.c_int, C.c_int, _u8p, _i32p]
+        L.okde_gibbs1_manifold.restype = C.c_int
+        L.okde_gibbs1_manifold.argtypes = [C.c_int, C.POINTER(_Tree), C.c_int64, C.c_int, _f64p, _i64p, _f64p,
+                                           C.c_int64, _f64p, C.c_int64, C.c_int, C.c_int, _u8p, _u8p, _i32p]
         L.okde_gibbs1_omp.restype = C.c_int
         L.okde_gibbs1_omp.argtypes = [C.c_int, C.POINTER(_Tree), C.c_int64, C.c_int, _f64p, _i64p, _f64p,
                                       C.c_int64, _f64p, C.c_int64, C.c_int, C.c_int, _u8p, C.c_int]
@@ -151,7 +154,7 @@ def rng_sizes(Ndens, ndims, Np, Niter, trees_npts):
 
 
 def gibbs1(trees, Np, Niter, randU, randN, addEntropy=True, partialDimMask=None, want_labels=False,
-           nthreads=0):
+           nthreads=0, manifold=None):
     """prodAppxMSGibbsS body (src/MSGibbs01.jl:680-702): returns (points[D,Np], indices[Ndens,Np][, labels])."""
     M = len(trees)
     D = max(t.dims for t in trees)
@@ -167,7 +170,13 @@ def gibbs1(trees, Np, Niter, randU, randN, addEntropy=True, partialDimMask=None,
     if want_labels:
         L = nlevels(max(t.num_points for t in trees))
         labels = np.zeros((Np, M, L), dtype=np.int32)
-    if nthreads and nthreads > 1:
+    if manifold is not None:   # per-dimension 0 = Euclidean / 1 = circular (kde_oracle.h okde_gibbs1_manifold)
+        man = np.ascontiguousarray(np.asarray(manifold, dtype=np.uint8).reshape(D))
+        rc = lib().okde_gibbs1_manifold(M, arr, Np, Niter, _p(pts, _f64p), _p(ind, _i64p), _p(randU, _f64p),
+                                        randU.size, _p(randN, _f64p), randN.size, int(addEntropy), D,
+                                        None if mask is None else _p(mask, _u8p), _p(man, _u8p),
+                                        None if labels is None else _p(labels, _i32p))
+    elif nthreads and nthreads > 1:
         rc = lib().okde_gibbs1_omp(M, arr, Np, Niter, _p(pts, _f64p), _p(ind, _i64p), _p(randU, _f64p),
                                    randU.size, _p(randN, _f64p), randN.size, int(addEntropy), D,
                                    None if mask is None else _p(mask, _u8p), int(nthreads))

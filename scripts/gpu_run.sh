@@ -10,8 +10,11 @@
 #   bench:<bench.py args>      one bench line                                  -> bench_<n>.json (+ .err)
 #   stats:<bench.py args>      rocprofv3 --kernel-trace --stats of that bench  -> stats_<n>/ + stats_<n>.txt (per-kernel table)
 #   pmc:<bench.py args>        the HBM + SQ counter passes (separate --pmc runs, kernel trace only) -> pmc_<n>/
+#   prof:<ptag>[,bench args]   scripts/profile_gpu.sh (stats + FETCH/WRITE/SQ passes) -> gpurun_out/prof_<ptag>/ ; then HERE:
+#                              python scripts/summarize_profile.py <ptag> <kernel match> <workload>
+#   mix:<ptag>[,bench args]    scripts/valu_mix.sh (instruction-mix passes) -> gpurun_out/mix_<ptag>/ ; then summarize_mix.py
 #   ab:<lib,lib,...;args>      scripts/ab_libs.py on in-tree development libraries (interleaved A/B) -> ab_<n>.txt
-#   py:<script,args>           python <script> <args>                          -> py_<n>.txt
+#   py:[VAR=VALUE,]<script,args>  python <script> <args> (with the environment assignments)  -> py_<n>.txt
 #   soak                       the round's soak list on the final build        -> soak.txt
 # Steps run in order; a failing step does not stop the following ones (its exit code is in steps.txt).
 set -u
@@ -48,6 +51,12 @@ for step in "$@"; do
          > "$O/stats_${n}_bench.json" 2> "$O/stats_$n.err"); rc=$?
       kernel_table "$O/stats_$n" > "$O/stats_$n.txt"
       find "$O/stats_$n" -type f -size +2M -delete ;;
+    prof)   # prof:<ptag>[,bench args] -> gpurun_out/prof_<ptag>/ (scripts/profile_gpu.sh; condensed here by summarize_profile.py)
+      ptag=${arg%% *}; rest=""; [ "$arg" != "$ptag" ] && rest=${arg#* }
+      bash scripts/profile_gpu.sh $ptag $rest > "$O/prof_$ptag.txt" 2>&1; rc=$? ;;
+    mix)    # mix:<ptag>[,bench args]  -> gpurun_out/mix_<ptag>/  (scripts/valu_mix.sh; condensed by summarize_mix.py)
+      ptag=${arg%% *}; rest=""; [ "$arg" != "$ptag" ] && rest=${arg#* }
+      bash scripts/valu_mix.sh $ptag $rest > "$O/mix_$ptag.txt" 2>&1; rc=$? ;;
     pmc)
       rc=0
       for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
@@ -60,7 +69,10 @@ for step in "$@"; do
     ab)
       libs=${arg%%;*}; rest=""; [ "$arg" != "$libs" ] && rest=${arg#*;}
       timeout 1500 python3 scripts/ab_libs.py --libs $libs $rest > "$O/ab_$n.txt" 2>&1; rc=$? ;;
-    py)     timeout 1800 python3 $arg > "$O/py_$n.txt" 2>&1; rc=$? ;;
+    py)     # (leading VAR=VALUE words are environment assignments for this step)
+      envs=""; rest=""
+      for w in $arg; do if [ -z "$rest" ] && [[ "$w" == *=* ]] && [[ "$w" != -* ]]; then envs="$envs $w"; else rest="$rest $w"; fi; done
+      timeout 1800 env $envs python3 $rest > "$O/py_$n.txt" 2>&1; rc=$? ;;
     soak)
       {
         KDEHIP_FUZZ_N=1500 timeout 1500 python3 -m pytest tests/test_gpu_fuzz.py -x -q -m gpu

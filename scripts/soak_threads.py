@@ -42,7 +42,7 @@ def worker(t):
     bad = 0
     for _ in range(ncalls):
         j = jobs[int(r.integers(0, len(jobs)))]
-        kind = int(r.integers(0, 9))
+        kind = int(r.integers(0, 10))
         if kind == 0:
             got = kdehip.prodAppxMSGibbsS(None, j["trees"], None, None, Niter=j["Niter"], Np=j["Np"], seed=j["seed"])
             ok = np.array_equal(got[0], j["a"][0]) and np.array_equal(got[1], j["a"][1])
@@ -91,6 +91,18 @@ def worker(t):
             st.synchronize()
             ok = all(np.array_equal(pr["d_points"].cpu().numpy().reshape(Np, D).T, a[0]) and
                      np.array_equal(pr["d_indices"].cpu().numpy().reshape(Np, M).T, a[1]) for pr, (a, Np, D, M) in zip(prods, want))
+        elif kind == 9:   # several `*` in ONE call (kdehip_mul_device_batch): shared LOOCV launches, pooled trees, shared block
+            picks = [q for q in jobs[:6] if q.get("mul") is not None]
+            if len(picks) < 2:
+                continue
+            picks = [picks[int(r.integers(0, len(picks)))] for _ in range(int(r.integers(2, 5)))]
+            outs = kdehip.mul_device_batch([q["dd"] for q in picks], seeds=[q["seed"] for q in picks])
+            ok = True
+            for q, out in zip(picks, outs):
+                got = out.download()
+                ok = ok and all(np.array_equal(getattr(got, f), getattr(q["mul"], f)) for f in ("means", "bandwidth")) and \
+                    all(np.array_equal(getattr(got.bt, f), getattr(q["mul"].bt, f)) for f in ("weights", "left_child", "permutation"))
+                out.close()
         elif kind == 5:   # kde!(points): the worker pool of the host tree builder is shared by every caller
             got = kdehip.kde_auto(j["x"], overlap=bool(r.integers(0, 2)))
             ok = all(np.array_equal(getattr(got, f), getattr(j["kd"], f)) for f in ("means", "bandwidth")) and \

@@ -216,6 +216,57 @@ def calcIndices(glb):  # :123-130
         updateGlbParticlesVariance(glb, j)
 
 
+# ---- the operator tuples addop / diffop / getMu / getLambda of src/MSGibbs01.jl:650-653, per dimension, as CALLABLES (the
+# reference's own interface: its callers bring on-manifold functions).  Defaults = the reference's Euclidean ones; the
+# circular set is this repo's stated semantic (include/kdehip.h "manifolds"), which the enumerated C / HIP paths must match.
+def getEuclidLambda(lambdas):  # :141
+    lam = 0.0
+    for v in lambdas:
+        lam += v
+    return lam
+
+
+def getEuclidMu(mus, lambdas, scale=1.0):  # :152-161
+    lambdamu = 0.0
+    for z in range(len(mus)):
+        lambdamu += mus[z] * lambdas[z]
+    return scale * lambdamu
+
+
+TWO_PI = 6.283185307179586476925286766559
+
+
+def wrapRad(t):
+    return t - TWO_PI * math.floor((t + math.pi) / TWO_PI)
+
+
+def circ_diff(a, b):
+    return wrapRad(a - b)
+
+
+def circ_add(a, b):
+    return wrapRad(a + b)
+
+
+getCircLambda = getEuclidLambda
+
+
+def getCircMu(mus, lambdas, scale=1.0):
+    ref = 0.0
+    for z in range(len(mus)):
+        if lambdas[z] > 0.0:
+            ref = mus[z]
+            break
+    acc = 0.0
+    for z in range(len(mus)):
+        acc += lambdas[z] * circ_diff(mus[z], ref)
+    return circ_add(ref, scale * acc)
+
+
+EUCLID_OPS = (lambda a, b: a + b, lambda a, b: a - b, getEuclidMu, getEuclidLambda)
+CIRCULAR_OPS = (circ_add, circ_diff, getCircMu, getCircLambda)
+
+
 def gaussianProductMeanCov(glb, dim, skip):  # :176-216, returns (destMu, destCov)
     checkpartials = [None] + [glb.partialDimMask[j][dim] for j in range(1, glb.Ndens + 1)]
     if skip > 0:
@@ -230,14 +281,9 @@ def gaussianProductMeanCov(glb, dim, skip):  # :176-216, returns (destMu, destCo
         else:
             calclambdas[j] = 0.0
             calcmu[j] = 0.0
-    lam = 0.0
-    for j in range(1, glb.Ndens + 1):  # getEuclidLambda :141
-        lam += calclambdas[j]
-    destCov = 1.0 / lam
-    lambdamu = 0.0
-    for zz in range(1, glb.Ndens + 1):  # getEuclidMu :152-161
-        lambdamu += calcmu[zz] * calclambdas[zz]
-    return destCov * lambdamu, destCov
+    destCov = glb.getLambda[dim](calclambdas[1:])  # :210
+    destCov = 1.0 / destCov                         # :211
+    return glb.getMu[dim](calcmu[1:], calclambdas[1:], destCov), destCov  # :213
 
 
 def makeFasterSampleIndex(j, glb, muValue, covValue, offset, doCalmost):  # :250-328
@@ -258,7 +304,7 @@ def makeFasterSampleIndex(j, glb, muValue, covValue, offset, doCalmost):  # :250
             tmpC = bw_(tree, zz, i)
             if doCalmost:
                 tmpC += covValue[i]
-            tmpM = mean_(tree, zz, i) - muValue[i + offset]
+            tmpM = glb.diffop[i](mean_(tree, zz, i), muValue[i + offset])  # :290
             try:
                 distr = (tmpM * tmpM) / tmpC
             except ZeroDivisionError:
@@ -322,7 +368,7 @@ def samplePoint(X, glb, idx, addEntropy=True):  # :440-463
         mn, vn = gaussianProductMeanCov(glb, dim, -1)
         glb.rnptr += 1
         if addEntropy:
-            X[dim + idx] = mn + math.sqrt(vn) * glb.randN[glb.rnptr]
+            X[dim + idx] = glb.addop[dim](mn, math.sqrt(vn) * glb.randN[glb.rnptr])  # :456
         else:
             X[dim + idx] = mn
 
@@ -366,7 +412,7 @@ def levelDown(glb):  # :500-523
     glb.levelList, glb.levelListNew = glb.levelListNew, glb.levelList
 
 
-def prodAppxMSGibbsS(trees0, Np, Niter, randU0, randN0, addEntropy=True, partialDimMask0=None):
+def prodAppxMSGibbsS(trees0, Np, Niter, randU0, randN0, addEntropy=True, partialDimMask0=None, ops=None):
     """gibbs1 :527-629 as called by prodAppxMSGibbsS :645-703.  trees0: list of densities from kde();
     randU0 / randN0: 0-based Python lists.  Returns (points[d][s], indices[j][s]) 0-based nested lists."""
     glb = Glb()
@@ -374,6 +420,12 @@ def prodAppxMSGibbsS(trees0, Np, Niter, randU0, randN0, addEntropy=True, partial
     glb.Ndens = Ndens
     glb.trees = [None] + list(trees0)
     glb.Ndim = max(t.dims for t in trees0)
+    # ops: per dimension an (addop, diffop, getMu, getLambda) tuple -- EUCLID_OPS (default) or CIRCULAR_OPS (:650-653, 672-675)
+    ops = [EUCLID_OPS] * glb.Ndim if ops is None else list(ops)
+    glb.addop = [None] + [o[0] for o in ops]
+    glb.diffop = [None] + [o[1] for o in ops]
+    glb.getMu = [None] + [o[2] for o in ops]
+    glb.getLambda = [None] + [o[3] for o in ops]
     glb.randU = [None] + list(randU0)
     glb.randN = [None] + list(randN0)
     if partialDimMask0 is None:
