@@ -274,6 +274,37 @@ function Base.:*(trees::Vector{DeviceDensity}; addEntropy::Bool=true, seed::Unio
 end
 Base.:*(p::DeviceDensity, q::DeviceDensity) = *([p; q])
 
+struct CMulItem                       # struct kdehip_mul_item, include/kdehip.h
+  Ndens::Int32
+  addEntropy::Int32
+  trees::Ptr{Ptr{Cvoid}}
+  seed::UInt64
+end
+
+"""
+    mul_batch(products::Vector{Vector{DeviceDensity}}; addEntropy=true, seeds=nothing) -> Vector{DeviceDensity}
+
+MANY `*` (src/MSGibbs01.jl:707-726) in ONE library call (`kdehip_mul_device_batch`) -- what a belief-propagation sweep
+issues, on the reference's own sizes (100-300 points, test/runtests.jl:189-201): batched sampler, the LOOCV bandwidth
+searches of all results of one size in the same launches, the trees on the library's host pool under them.  Result `i` is
+bit for bit `*(products[i]; addEntropy, seed=seeds[i])`.
+"""
+function mul_batch(products::Vector{Vector{DeviceDensity}}; addEntropy::Bool=true,
+                   seeds::Union{Nothing,Vector{UInt64}}=nothing)
+  n = length(products)
+  n == 0 && return DeviceDensity[]
+  sds = seeds === nothing ? rand(UInt64, n) : seeds
+  handles = [Ptr{Cvoid}[t.handle for t in p] for p in products]
+  out = fill(Ptr{Cvoid}(C_NULL), n)
+  GC.@preserve products handles begin
+    items = CMulItem[CMulItem(length(handles[i]), addEntropy ? 1 : 0, pointer(handles[i]), sds[i]) for i in 1:n]
+    check(ccall((:kdehip_mul_device_batch, libkdehip), Cint,
+                (Cint, Ptr{CMulItem}, Ptr{Ptr{Cvoid}}, Ptr{Float64}, Ptr{Int32}),
+                n, items, out, C_NULL, C_NULL))
+  end
+  return DeviceDensity[DeviceDensity(h) for h in out]
+end
+
 """
     BallTreeDensity(d::DeviceDensity)
 

@@ -9,8 +9,9 @@
 #     julia oracle/julia_crosscheck.jl --shim /tmp/kat/c1 /tmp/kat/c2 /tmp/kat/d6 /tmp/kat/c3   # on a box with an MI355X:
 #         additionally loads kerneldensityestimate.jl_amd/julia/KernelDensityEstimateHIP.jl and checks (a) that the trees
 #         its `kde!(points, ks)` builds (kdehip_make_density: what enable!() installs in place of the reference's
-#         constructor) are the reference's arrays BIT FOR BIT, `next` included, and (b) that the GPU product on the same
-#         streams returns the reference's labels and points
+#         constructor) are the reference's arrays BIT FOR BIT, `next` included, (b) that the GPU product on the same
+#         streams returns the reference's labels and points, and (c) that `mul_batch` (many `*` in one call) returns the
+#         densities of the single calls
 #
 # Each directory holds meta.txt (D M N Np Niter), points_j.txt (D x N), bw_j.txt (D), randU.txt, randN.txt and the
 # oracle's indices.txt (M x Np) and pGM.txt (D x Np).  The same random streams are handed to the reference through
@@ -60,6 +61,17 @@ function crosscheck(dir::String)
       bw = Float64.(vec(readdlm(joinpath(dir, "bw_$j.txt"))))
       t = same_tree(H.kde!(pts, bw, nothing), trees[j])
       println(dir, ": tree ", j, " built by kdehip_make_density == the reference's: ", t)
+      ok &= t
+    end
+    # many `*` in one call (kdehip_mul_device_batch) against the same `*` one at a time (kdehip_mul_device): every array
+    dd = [H.DeviceDensity(t) for t in trees]
+    prods = [dd[1:min(2, M)], dd, dd[1:1]]
+    sds = UInt64[11, 12, 13]
+    batch = H.mul_batch(prods; seeds=sds)
+    for (k, p) in enumerate(prods)
+      one = *(p; seed=sds[k])
+      t = same_tree(BallTreeDensity(batch[k]), BallTreeDensity(one))
+      println(dir, ": batched `*` ", k, " == the single call: ", t)
       ok &= t
     end
     gp, gi = H.prodAppxMSGibbsS(dummy, trees, nothing, nothing; Niter=Niter, randU=copy(randU), randN=copy(randN))

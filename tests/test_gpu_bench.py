@@ -62,3 +62,22 @@ def test_bench_distributed_path_one_rank():
               "--master-addr", "127.0.0.1", "--master-port", "29534", "bench.py", "--gpus", "1", "--steps", "2",
               "--warmup", "1", "--no-cpu-baseline"])
     assert d["n_gpus"] == 1 and d["value"] > 0
+
+
+def test_bench_frow_lines_and_batched_star():
+    """The callers either side of the product at the measurement bar (`--frow`): each line carries `roofline`
+    with a kernel time measured INSIDE the library (kdehip_profile_phase_read) and `cpu_baseline`; and `--batch B --mul`
+    (many `*` in one call) reports its parity with the single calls."""
+    d = _run([sys.executable, "bench.py", "--frow", "loocv", "--nout", "512", "--steps", "3", "--warmup", "1"])
+    assert REQUIRED <= set(d) and d["cpu_baseline"]["kind"] == "port"
+    r = d["roofline"]
+    assert 0.0 < r["kernel_ms"] < d["ms_per_step"] * 1.05 and 0.0 < r["frac"] < 1.0
+    assert d["parity"]["bandwidths_equal_oracle_1e-9"] and d["parity"]["evaluation_counts_equal"]
+    d = _run([sys.executable, "bench.py", "--frow", "evaluate", "--config", "c2", "--steps", "3", "--warmup", "1"])
+    assert REQUIRED <= set(d) and d["parity"]["max_rel_err_vs_oracle"] < 1e-11
+    assert 0.0 < d["roofline"]["kernel_ms"] < d["ms_per_step"]
+    d = _run([sys.executable, "bench.py", "--frow", "tree", "--nout", "512", "--steps", "3", "--warmup", "1"])
+    assert REQUIRED <= set(d) and d["gpu_builder"]["arrays_identical_to_host_builder"]
+    d = _run([sys.executable, "bench.py", "--config", "c2", "--batch", "6", "--mul", "--steps", "3", "--warmup", "1"])
+    assert d["batched_equals_single_calls_bit_for_bit"] and d["config"]["batch"] == 6
+    assert d["ms_per_step"] < d["back_to_back"]["ms_per_step"]

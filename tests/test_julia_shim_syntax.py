@@ -94,6 +94,7 @@ JULIA_TO_C = {
     "Cstring": {"char*"}, "Cvoid": {"void"},
     "Ptr{Cvoid}": {"kdehip_device_density*"}, "Ref{Ptr{Cvoid}}": {"kdehip_device_density**"},
     "Ptr{Ptr{Cvoid}}": {"kdehip_device_density**"},
+    "Ptr{CMulItem}": {"kdehip_mul_item*"},
 }
 
 
