@@ -105,6 +105,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-spin-up", action="store_true",
                     help="skip the 40 ms of resident-plan launches that bring the device's clock up before the warm-up steps")
+    ap.add_argument("--spin-up-calls", type=int, default=48,
+                    help="untimed calls of the measured path after the resident-plan launches of the spin-up (0 = none)")
+    ap.add_argument("--spin-up-ms", type=float, default=40.0,
+                    help="how long the device is kept busy with launches of one resident plan before the warm-up steps")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--nout", type=int, default=0, help="override chains per GPU (experiments; 0 = the config's)")
     ap.add_argument("--strong", action="store_true",
@@ -243,14 +247,25 @@ def main():
     spin_up = {"launches": 0, "ms": 0.0}
     if not args.no_spin_up and hi > lo:
         ts = time.perf_counter()
-        while time.perf_counter() - ts < 0.040:
+        while time.perf_counter() - ts < args.spin_up_ms * 1e-3:
             for _ in range(4):
                 plan.sample_philox_device(hi - lo, Niter, seed, lo, True, slots[0]["pts"], slots[0]["ind"], None, stream.cuda_stream)
             torch.cuda.synchronize()
             spin_up["launches"] += 4
+        # ... and the first pass of a PROCESS through the measured entry is slower for its first ~40 calls whatever the
+        # clock does (525 -> 490 us per call; a pass of a DIFFERENT, small product beforehand removes it just as well: the HIP
+        # runtime's event / signal / stream pools warming up, not this product's data -- scripts/first_pass_transient.py,
+        # profiles/r06l_first_pass_transient.txt).  Rounds 3-4 measured inside that transient, round 5 behind an extra pass by
+        # accident; now it is run here, untimed and counted: `spin_up.calls`.
+        for i in range(args.spin_up_calls):
+            one_call(16 * (args.warmup + args.steps) + i)
+        drain()
+        spin_up["calls"] = args.spin_up_calls
         spin_up["ms"] = (time.perf_counter() - ts) * 1e3
-    spin_up["what"] = ("untimed launches of one resident plan before the warm-up steps: the device's clock is back at its "
-                       "sustained value when the W warm-up steps start (--no-spin-up: without)")
+    spin_up["what"] = ("untimed, before the W warm-up steps: launches of one resident plan for spin_up_ms (the device's clock is "
+                       "back at its sustained value), then `calls` calls of the measured path (the first ~40 calls of a process "
+                       "through the entry are ~5 % slower: HIP runtime pools); --no-spin-up: without; "
+                       "ms_per_step_no_spin_up = the same W + K steps cold")
 
     elapsed = timed_pass(0)
     gather_wait_s = gather_wait[0]
@@ -357,7 +372,7 @@ def main():
             "spin_up": spin_up,
             "ms_per_step": elapsed / args.steps * 1e3,
             "ms_per_step_no_spin_up": (no_spin_elapsed / args.steps * 1e3) if no_spin_elapsed is not None else None,
-            "passes": "spin-up, W + K (value), K with kernel timestamps, resident plan, 0.5 s idle, W + K without spin-up",
+            "passes": "spin-up (resident launches, then untimed calls), W + K (value), K with kernel timestamps, resident plan, 0.5 s idle, W + K without spin-up",
             "higher_is_better": True,
             "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None,

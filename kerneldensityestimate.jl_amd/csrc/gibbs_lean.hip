@@ -266,11 +266,15 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
 
   // the fp64 REPEAT of a screened step on the plan's fp64 tile in global memory: the canonical lane sums with four rows
   // requested ahead where the registers allow it (up to 7 fields per row: every shared-bandwidth tile, per-node tiles up to
-  // D = 3), then the unchanged selection
+  // D = 3), then the unchanged selection.  ONLY in the chunked-screen builds (the plans whose workgroups wait for a repeating
+  // wavefront: config 4 3.04 -> 2.99 ms): in the plain build the eight rows in flight cost 16 vector registers (209 -> 225,
+  // i.e. 232 allocated), and with 2 x 232 of a SIMD's 512 taken the NEXT call's table-build kernel (64 registers per
+  // wavefront) no longer fits beside the sampler -- config 3's complete call went from 0.481 to 0.494 ms per step with an
+  // unchanged 0.471 ms kernel (profiles/r06_experiments.md section 10).
   auto draw_rows_repeat = [&](const auto &ds, const T *rows, const auto &ev, double u) -> int {
     using Ev = std::decay_t<decltype(ev)>;
 #ifndef KDEHIP_X_NO_DEEP
-    if constexpr (kScreen && sizeof(typename Ev::Row) <= 7 * sizeof(T) && WAVES <= 8) {
+    if constexpr (kScreen && SCHUNK && sizeof(typename Ev::Row) <= 7 * sizeof(T) && WAVES <= 8) {
       LaneAcc<T> acc;
       KDEHIP_PRIO_ROWS();
       lane_rows_all_deep<T, Ev>(rows, ds.B, TileAddr<T>::stride(ds.F), lane, ev, acc);
