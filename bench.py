@@ -745,8 +745,11 @@ def frow_mode(args):
                    "sample": "5 builds of the same density by oracle/kde_oracle.c (okde_build: the reference's sequential quick-select)"}
         # every level's quick-select passes read and swap whole points: ~2 passes x (D + 2) doubles x N per level
         alg_bytes = 2.0 * L * Nout * (D + 2) * 8
-        best_ms = mean_ms
-        out = dict(base, metric="kde_tree_builds_per_sec", value=1e3 / mean_ms, unit="trees/s", ms_per_step=mean_ms, ms_per_step_median=med_ms,
+        best_ms = med_ms
+        # (value from the MEDIAN build: this process hosts torch, whose OpenMP workers spin after its parallel regions -- one
+        # build in ~50 that lands in that window takes ~80 ms, profiles/r06f_host_tree_in_torch.txt; the mean is kept beside it)
+        out = dict(base, metric="kde_tree_builds_per_sec", value=1e3 / med_ms, unit="trees/s", ms_per_step=med_ms, ms_per_step_mean=mean_ms,
+                   ms_per_step_median=med_ms,
                    value_is="one kdehip_make_density call (kde!(points, ks): buildTree! + calcStats, src/BallTree01.jl:223-463, "
                             "src/BallTreeDensity01.jl:141-231) on the library's pooled HOST builder -- the builder every `*` path uses",
                    config={"workload": f"tree: {D} x {Nout} points", "ndims": D, "npts": Nout, "levels": L,
