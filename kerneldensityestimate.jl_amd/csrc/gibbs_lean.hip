@@ -117,11 +117,29 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
   constexpr int kNormOff = 2048;
   constexpr int kUnifOff = kNormOff + WAVES * kLeanMaxNormals * 8;
   constexpr int kPoolOff = kUnifOff + WAVES * 1024;
-  static_assert(kPoolOff + kLdsPoolBytes <= 160 * 1024, "LDS budget of one CU exceeded");
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[kPoolOff + kLdsPoolBytes];
+  // COOPERATIVE fp64 REPEAT (round 6; chunked screen levels of the 8-chain builds).  A wavefront whose fp32 decision is not
+  // certified repeats the draw in fp64 -- 60-130 rows read through the L2, ~11 us -- while its workgroup waits at the next
+  // chunk barrier (config 4: 13 % of the kernel).  With 8 chains per workgroup 22 KB of the CU's LDS are unused: an
+  // exchange area behind the pool lets FOUR wavefronts take the four row classes of the canonical lane sums (LaneAcc: a_k =
+  // the rows r = k mod 4 in increasing order -- each class is one sequential sum, so the split changes no bit), two requests
+  // at a time.  Per request slot: mean and variance of the draw per dimension (what the helpers build the evaluator from)
+  // and the 4 x 64 class sums.  Flags are double-buffered by step parity: a wavefront may be one step ahead of another.
+#ifndef KDEHIP_X_NO_COOP
+  constexpr bool kCoop = kScreen && SCHUNK && WAVES == 8;
+#else
+  constexpr bool kCoop = false;
+#endif
+  constexpr int kXchgOff = kPoolOff + kLdsPoolBytes;
+  constexpr int kXchgSlotDoubles = 32 + 4 * 64;  // [0..7] mean, [8..15] variance, [32 + 64 k + lane] class sums
+  constexpr int kXchgBytes = kCoop ? 64 + WAVES * kXchgSlotDoubles * 8 : 0;
+  static_assert(kPoolOff + kLdsPoolBytes + kXchgBytes <= 160 * 1024, "LDS budget of one CU exceeded");
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[kPoolOff + kLdsPoolBytes + kXchgBytes];
 
   double *sExpTab = reinterpret_cast<double *>(smem);
   if (threadIdx.x < 256) sExpTab[threadIdx.x] = kExp2Tab256[threadIdx.x];
+  if constexpr (kCoop) {
+    if (threadIdx.x < 16) reinterpret_cast<int *>(smem + kXchgOff)[threadIdx.x] = 0;  // request flags [2 parities][WAVES]
+  }
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
@@ -447,6 +465,94 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
     }
     adopt(jc, ds, hdrg, pos);
   };
+  // ---- the cooperative repeat's protocol (kCoop) ----
+  // post: at the end of a chunked step whose decision was not certified -- the draw's operands and a flag (parity of the
+  // step); the wavefront goes on to the next step's first barrier WITHOUT a label.  resolve: right behind that barrier every
+  // wavefront looks at the flags of the step before; if any is set, wavefronts 0-3 take the four row classes of the first
+  // request, 4-7 those of the second (then the third and fourth, ...), one more barrier, and every requester forms the
+  // canonical total from the four class sums, selects (second pass from global memory, as the solo repeat does) and adopts.
+  bool pend = false;
+  T pend_mean = T(0), pend_cov = T(0);
+  double pend_u = 0.0;
+  int cstep = 0;  // chunked steps so far (wave-uniform; its parity picks the flag buffer)
+  auto coop_post = [&](T mean, T cov, double u) {
+    if constexpr (kCoop) {
+      pend = true; pend_mean = mean; pend_cov = cov; pend_u = u;
+      double *xs = reinterpret_cast<double *>(smem + kXchgOff + 64) + wave * kXchgSlotDoubles;
+      if (lane < D) { xs[dl] = static_cast<double>(mean); xs[8 + dl] = static_cast<double>(cov); }
+      if (lane == 0) reinterpret_cast<int *>(smem + kXchgOff)[(cstep & 1) * WAVES + wave] = 1;
+    }
+  };
+  // (`par`: the parity of the step whose requests are looked at; jp / dsp: that step's density and tile)
+  auto coop_resolve = [&](auto jp, const auto &dsp, int par) {
+    if constexpr (kCoop) {
+      int *flags = reinterpret_cast<int *>(smem + kXchgOff) + par * WAVES;
+      const int f = flags[lane & (WAVES - 1)];
+      const unsigned mask = static_cast<unsigned>(__ballot(f != 0 && lane < WAVES));
+      if (mask == 0u) return;  // (wave-uniform, and the same in every wavefront: read behind a barrier, buffered by parity)
+      using TA = TileAddr<T>;
+      const T *hdrg = data + dsp.hdr_off();
+      const T *rows = hdrg + kTileHeader;
+      const int RS = TA::stride(dsp.F), B = dsp.B;
+      const int group = wave >> 2, k = wave & 3;
+      int idx = 0;
+      for (unsigned m = mask; m != 0u; m &= m - 1u, ++idx) {
+        if ((idx & 1) != group) continue;
+        const int r = __builtin_ctz(m);
+        double *xs = reinterpret_cast<double *>(smem + kXchgOff + 64) + r * kXchgSlotDoubles;
+        const T mean_r = static_cast<T>(xs[dl]), cov_r = static_cast<T>(xs[8 + dl]);
+        T acc = T(0);
+        KDEHIP_PRIO_ROWS();
+        draw(dsp, hdrg, mean_r, cov_r, [&](const auto &ev) {
+          // class k: rows k, k + 4, k + 8, ... in increasing order, four of them requested ahead
+          using Ev = std::decay_t<decltype(ev)>;
+          using Row = typename Ev::Row;
+          const T *e = rows + lane * TA::kLane;
+          auto at = [&](int rr) { return e + TA::row(rr < B ? rr : B - 1, RS); };
+          if constexpr (sizeof(Row) <= 4 * sizeof(T)) {  // (shared-bandwidth tiles up to D = 3: eight rows fit the registers)
+            Row a0 = ev.load(at(k)), a1 = ev.load(at(k + 4)), a2 = ev.load(at(k + 8)), a3 = ev.load(at(k + 12));
+            int i = k;
+            for (; i + 12 < B; i += 16) {
+              const Row b0 = ev.load(at(i + 16)), b1 = ev.load(at(i + 20)), b2 = ev.load(at(i + 24)), b3 = ev.load(at(i + 28));
+              __builtin_amdgcn_sched_barrier(0);
+              acc += ev(a0); acc += ev(a1); acc += ev(a2); acc += ev(a3);
+              a0 = b0; a1 = b1; a2 = b2; a3 = b3;
+            }
+            if (i < B) acc += ev(a0);
+            if (i + 4 < B) acc += ev(a1);
+            if (i + 8 < B) acc += ev(a2);
+          } else {
+            Row a0 = ev.load(at(k)), a1 = ev.load(at(k + 4));
+            int i = k;
+            for (; i + 4 < B; i += 8) {
+              const Row b0 = ev.load(at(i + 8)), b1 = ev.load(at(i + 12));
+              __builtin_amdgcn_sched_barrier(0);
+              acc += ev(a0); acc += ev(a1);
+              a0 = b0; a1 = b1;
+            }
+            if (i < B) acc += ev(a0);
+          }
+          return 0;
+        });
+        KDEHIP_PRIO_CHAIN();
+        xs[32 + 64 * k + lane] = static_cast<double>(acc);
+      }
+      __syncthreads();  // the class sums of every request are in place
+      if (pend) {
+        double *xs = reinterpret_cast<double *>(smem + kXchgOff + 64) + wave * kXchgSlotDoubles;
+        const T a0 = static_cast<T>(xs[32 + lane]), a1 = static_cast<T>(xs[32 + 64 + lane]);
+        const T a2 = static_cast<T>(xs[32 + 128 + lane]), a3 = static_cast<T>(xs[32 + 192 + lane]);
+        const T S = (a0 + a1) + (a2 + a3);  // LaneAcc::total
+        const int pos = __builtin_amdgcn_readfirstlane(draw(dsp, hdrg, pend_mean, pend_cov, [&](const auto &ev) {
+          return select_or_raise<T, const T *>(S, rows, dsp, lane, ev, pend_u, fb);
+        }));
+        adopt(jp, dsp, hdrg, pos);
+        pend = false;
+        if (lane == 0) flags[wave] = 0;
+      }
+    }
+  };
+
   auto step_screen = [&](auto jc, const auto &ds, int sc_lds_off, bool first, T x) {
     if constexpr (kScreen) {
       SSTAMP(ts0);
@@ -558,16 +664,23 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
                                                                        (p0 == 0 ? 0 : kScreenHeaderFloats + p0 * RS));
     if (wave < kCopyWaves) stage_tile<kCopyWaves>(src, pool + half * (kLdsPoolBytes / 2), bytes, wave, lane);
   };
-  auto step_screen_chunked = [&](auto jc, const auto &ds, const LevelDesc &sc, const LevelDesc &scn, bool more, bool first, T x) {
+  auto step_screen_chunked = [&](auto jc, const auto &ds, const auto &dsp, const LevelDesc &sc, const LevelDesc &scn, bool more,
+                                 bool first, bool level_start, T x) {
     if constexpr (kScreen && SCHUNK) {
       using TA = TileAddr<float>;
       T mean = x, cov = T(0);
-      if (!first) product(jc, mean, cov);
+      const bool was_pend = kCoop && pend;  // (its label of the step before is still out: the product has to wait)
+      if (!first && !was_pend) product(jc, mean, cov);
       const double u = next_uniform();
       const int RS = TA::stride(sc.F), cp = sc.chunk_rows >> 1, npairs = (sc.B + 1) >> 1;
       staging_barrier();  // chunk 0 has landed for every wavefront; the other half is free again
       if (cp < npairs) stage_schunk(sc, cp, (gchunk + 1) & 1);
       else if (more) stage_schunk(scn, 0, (gchunk + 1) & 1);
+      if constexpr (kCoop) {
+        constexpr int j = decltype(jc)::value;
+        if (!level_start) coop_resolve(IC<(j + M - 1) % M>{}, dsp, (cstep + 1) & 1);  // the requests of the step before
+        if (was_pend && !first) product(jc, mean, cov);
+      }
       const LdsPtr<float> h32 = (LdsPtr<float>)(pool + (gchunk & 1) * (kLdsPoolBytes / 2));
       const LdsPtr<double> h64 = (LdsPtr<double>)(pool + (gchunk & 1) * (kLdsPoolBytes / 2));
       const double mu0 = h64[dl], cmin = h64[8 + dl];
@@ -590,7 +703,18 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
         if (!ok) return -1;
         return screen_decide<D, Ev::kUni, true>(grows, ds.n, ds.B, RS, lane, ev, u, q.values(), q.errors() SSTAMP_ARGS);
       }));
-      screen_finish(jc, ds, pos, mean, cov, u);
+      if constexpr (kCoop) {
+        ++n_screened;
+        if (pos < 0) {
+          ++n_repeated;
+          coop_post(mean, cov, u);
+        } else {
+          adopt(jc, ds, data + ds.hdr_off(), pos);
+        }
+        ++cstep;
+      } else {
+        screen_finish(jc, ds, pos, mean, cov, u);
+      }
     }
   };
 
@@ -682,6 +806,9 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
           staging_barrier();  // tile t has landed for everyone; the other half was last read in step t - 1
           constexpr bool kLateCopy = kCopyWaves < WAVES;
           if (!kLateCopy && t + 1 < nsteps) stage_screen(scn, (t + 1) & 1, IC<WAVES>{});
+          // (the cooperative repeat of the chunked levels was tried here too -- posting instead of repeating, resolving behind
+          // this barrier: config 4 2.876 -> 2.909 ms: these tiles are 16-32 rows per lane, a solo repeat is short, and the
+          // extra copies of the protocol cost registers -- 13 spilled against 2; profiles/r06_experiments.md section 12)
           step_screen(jc, ds, (t & 1) * (kLdsPoolBytes / 2), p == 0, x);
           if (kLateCopy && t + 1 < nsteps) stage_screen(scn, (t + 1) & 1, IC<kCopyWaves>{});
           ++t;
@@ -696,10 +823,15 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_lean_kernel(PlanDev plan_, R
         static_for<M>([&](auto jc) {
           constexpr int j = decltype(jc)::value;
           constexpr int jn = (j + 1 == M) ? 0 : j + 1;
+          constexpr int jp = (j + M - 1) % M;
           const LeanTile<D> ds = tile(j);
-          step_screen_chunked(jc, ds, screen(j), screen(jn), t + 1 < nsteps, p == 0, x);
+          step_screen_chunked(jc, ds, tile(jp), screen(j), screen(jn), t + 1 < nsteps, p == 0, t == 0, x);
           ++t;
         });
+      if constexpr (kCoop) {  // the requests of the level's last step
+        __syncthreads();
+        coop_resolve(IC<M - 1>{}, tile(M - 1), (cstep + 1) & 1);
+      }
     } else if (mode == kStageResident) {
       staging_barrier();  // every wavefront is done reading the previous level's images
       static_for<M>([&](auto jc) {
