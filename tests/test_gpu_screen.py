@@ -130,6 +130,35 @@ def test_screen_range_rules(shift, scale, why):
     assert np.array_equal(res[0][1], oi) and np.array_equal(res[0][2], ol)
 
 
+@pytest.mark.parametrize("scale,why", [
+    (1.0, "ordinary data: ~1 % of the draws post a request, mostly one per workgroup-step"),
+    (3.0e4, "tiles outside the bound's range: EVERY wavefront posts at EVERY step -- four rounds of two requests, all 8 slots"),
+])
+def test_cooperative_repeat_on_chunked_levels(scale, why):
+    """The fp64 repeat of a chunked screen level in the 8-chain builds is cooperative (gibbs_lean.hip kCoop: four wavefronts
+    take the four LaneAcc row classes of a request through an LDS exchange area, two requests at a time).  Each class is one
+    sequential sum, so labels and points must be the unscreened run's (variant 5), bit for bit, and the oracle's."""
+    D, Ns, Np, Niter = 6, [4096, 5000, 4096, 4500], 72, 2   # 9 workgroups of 8 chains; level 12-13 chunked, up to 79 rows per lane
+    g, o = _trees(808, D, Ns, scale=scale)
+    with kdehip.ProductPlan(g) as plan:
+        plan.set_variant(8)   # eight chains per workgroup whatever the chain count: the builds that have the exchange area
+        assert plan.kernel_name(Np) == "gibbs_lean_kernel" and plan.launch_geometry(Np)["waves"] == 8
+        res = _run_variants(plan, Np, Niter, 31, variants=(8, 5))
+        res[0] = res[8]
+        plan.set_variant(8)
+        plan.sample(Np, Niter=Niter, seed=31)
+        st = plan.screen_stats()
+        K, R = plan.randu_per_sample(Niter), plan.randn_per_sample()
+    for a, b in zip(res[0], res[5]):
+        assert np.array_equal(a, b), why
+    assert st["steps"] > 0 and st["repeats"] > 0, st
+    if scale != 1.0:
+        assert st["repeats"] == st["steps"], (st, why)
+    u, n = kdehip.philox_streams(31, 0, Np, K, R)
+    op, oi, ol = oracle.gibbs1(o, Np, Niter, u, n, want_labels=True)
+    assert np.array_equal(res[0][1], oi) and np.array_equal(res[0][2], ol), why
+
+
 def test_screen_linearisation_guard():
     """Clusters thousands of bandwidths apart (coordinates ~ +-4000, sigma 0.2): the tiles pass the range checks (|m'| <=
     2^16, variances >= 2^-7) but the centring term na = sqrt(c0) u |g / sigma| is ~4e-3, where the bound's linearised
