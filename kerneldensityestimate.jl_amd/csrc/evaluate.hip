@@ -962,7 +962,7 @@ class kdehip::LoocvSearch {
 int kdehip::LoocvSearch::begin(int nb, int D, int64_t N, const double *points, const double *d_points, hipStream_t st) {
   st_ = st; nb_ = nb; D_ = D;
   const int nm = nm_ = nb * D;
-  if (nb < 1 || nm > 21000) return set_error(KDEHIP_ERR_UNSUPPORTED, "bandwidth search: too many marginals for one launch");
+  if (nb < 1 || nm > kLoocvMaxMarginals) return set_error(KDEHIP_ERR_UNSUPPORTED, "bandwidth search: too many marginals for one launch");
   if (!points && !(d_points && N <= kPrepMaxN)) return set_error(KDEHIP_ERR_ARG, "auto_bandwidth_run: no host copy of the points");
   if (nb > 1 && !(d_points && N <= kPrepMaxN)) return set_error(KDEHIP_ERR_ARG, "bandwidth search: a batch needs device matrices of at most 2048 points");
 

@@ -8,6 +8,8 @@ namespace kdehip {
 // marginals in the same launches; non-blocking pieces: begin enqueues the preparation and the first batch of rounds on
 // `stream`, the caller synchronises the stream and polls (done, or the next batch enqueued), finish hands out nb * D
 // bandwidths and nb evaluation counts.  kdehip_mul_device_batch keeps one search per distinct N in flight.
+// (a launch indexes marginals in blockIdx.z, three probes each in the speculative rounds: at most this many per search)
+constexpr int kLoocvMaxMarginals = 21000;
 class LoocvSearch;
 LoocvSearch *loocv_new();
 void loocv_delete(LoocvSearch *s);  // (waits for the stream when the search was abandoned half-way)

@@ -618,7 +618,9 @@ extern "C" int kdehip_mul_device_batch(int nprod, const kdehip_mul_item *items, 
     m.loose = xs == nullptr || m.N < 2 || m.N > kLoocvPrepMaxN;
     if (m.loose) continue;
     int g = -1;
-    for (size_t k = 0; k < groups.size(); ++k) if (groups[k].D == m.D && groups[k].N == m.N) g = static_cast<int>(k);
+    const size_t cap = static_cast<size_t>(kLoocvMaxMarginals / m.D);  // (products per search: its launches index marginals)
+    for (size_t k = 0; k < groups.size(); ++k)
+      if (groups[k].D == m.D && groups[k].N == m.N && groups[k].members.size() < cap) g = static_cast<int>(k);
     if (g < 0) { groups.push_back(MulGroup{m.D, m.N, {}}); g = static_cast<int>(groups.size()) - 1; }
     m.group = g; m.slot = static_cast<int>(groups[g].members.size());
     groups[g].members.push_back(i);

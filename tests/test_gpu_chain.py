@@ -186,3 +186,24 @@ def test_mul_device_batch_argument_errors():
     with pytest.raises(kdehip.KdeHipError):
         kdehip.mul_device_batch([[a, a], []], seeds=[1, 2])
     a.close(); b.close()
+
+
+def test_mul_device_batch_beyond_one_search():
+    """More marginals than one bandwidth search indexes (21,000: 3,600 products x 6 dimensions): the batch splits the results of
+    one size over several searches; spot-checked against single calls at both ends and across the split."""
+    D, B = 6, 3600
+    pool = [kdehip.DeviceDensity(t) for t in _trees(77, D, [5, 5, 5, 5])]
+    rng = np.random.default_rng(3)
+    products = [[pool[j] for j in rng.choice(4, size=2, replace=False)] for _ in range(B)]
+    seeds = [40000 + k for k in range(B)]
+    outs = kdehip.mul_device_batch(products, seeds=seeds)
+    assert len(outs) == B and all(o.num_points == 5 for o in outs)
+    for k in (0, 1, 3498, 3499, 3500, 3501, B - 2, B - 1):
+        with kdehip.mul_device(products[k], seed=seeds[k]) as ref:
+            assert np.array_equal(outs[k].bw, ref.bw) and outs[k].nevals == ref.nevals, k
+            assert_same_density(outs[k].download(), ref.download(), f"product {k}")
+    for o in outs:
+        o.close()
+    for d in pool:
+        d.close()
+    kdehip._clib.kdehip_clear_cache()
