@@ -1161,7 +1161,11 @@ extern "C" int kdehip_auto_bandwidth(int64_t D64, int64_t N, const double *point
   DeviceGuard guard;
   const int rc = guard.enter(device);
   if (rc != KDEHIP_OK) return rc;
-  return auto_bandwidth_run(static_cast<int>(D64), N, points, nullptr, hipStreamPerThread, bw_out, nevals_out);
+  try {  // (host-prepared marginals use std::vector / std::thread: nothing may throw out of an extern "C" entry point)
+    return auto_bandwidth_run(static_cast<int>(D64), N, points, nullptr, hipStreamPerThread, bw_out, nevals_out);
+  } catch (const std::exception &e) {
+    return set_error(KDEHIP_ERR_ALLOC, std::string("kdehip_auto_bandwidth: ") + e.what());
+  }
 }
 
 // kde!(points) (src/KDE01.jl:3-27) with the tree built under the bandwidth search: the builder is a task of the host

@@ -566,7 +566,7 @@ struct MulPlan {   // what one item of the batch becomes
   int D = 0, M = 0;
   int64_t N = 0;          // points of the result (Np of the product, or the density's own count for the shortcut)
   bool shortcut = false, loose = false;  // loose: outside the batched path (fewer than 2 or more than 2048 points): a call of its own
-  int group = -1, slot = 0;              // its (D, N) group and position in it
+  int group = -1;                        // its (D, N) group
   size_t pts_off = 0, ind_off = 0;       // in the scratch block (bytes)
   size_t a_off = 0, b_off = 0, x_off = 0;  // in the shared block: region A (means, weights, permutation, ids), B (variances); mirror extras
   size_t front_cap = 0;
@@ -579,8 +579,21 @@ struct MulGroup { int D; int64_t N; std::vector<int> members; size_t pts_off = 0
 
 }  // namespace
 
+static int mul_device_batch_impl(int nprod, const kdehip_mul_item *items, kdehip_device_density **out, double *bw_out,
+                                 int32_t *nevals);
 extern "C" int kdehip_mul_device_batch(int nprod, const kdehip_mul_item *items, kdehip_device_density **out, double *bw_out,
                                        int32_t *nevals) {
+  // (the bookkeeping below lives in std::vectors: nothing may throw out of an extern "C" entry point -- the unwinding runs the
+  // clean-up that takes every block and handle back first)
+  try {
+    return mul_device_batch_impl(nprod, items, out, bw_out, nevals);
+  } catch (const std::exception &e) {
+    if (out) for (int i = 0; i < nprod; ++i) out[i] = nullptr;
+    return set_error(KDEHIP_ERR_ALLOC, std::string("kdehip_mul_device_batch: ") + e.what());
+  }
+}
+static int mul_device_batch_impl(int nprod, const kdehip_mul_item *items, kdehip_device_density **out, double *bw_out,
+                                 int32_t *nevals) {
   if (nprod < 0 || (nprod > 0 && (!items || !out))) return set_error(KDEHIP_ERR_ARG, "kdehip_mul_device_batch: bad item list");
   for (int i = 0; i < nprod; ++i) out[i] = nullptr;
   if (nprod == 0) return KDEHIP_OK;
@@ -622,7 +635,7 @@ extern "C" int kdehip_mul_device_batch(int nprod, const kdehip_mul_item *items, 
     for (size_t k = 0; k < groups.size(); ++k)
       if (groups[k].D == m.D && groups[k].N == m.N && groups[k].members.size() < cap) g = static_cast<int>(k);
     if (g < 0) { groups.push_back(MulGroup{m.D, m.N, {}}); g = static_cast<int>(groups.size()) - 1; }
-    m.group = g; m.slot = static_cast<int>(groups[g].members.size());
+    m.group = g;
     groups[g].members.push_back(i);
   }
   size_t pts_bytes = 0, ind_bytes = 0, a_bytes = 0, b_bytes = 0, x_bytes = 0;
