@@ -245,9 +245,9 @@ def main():
     # a SHORT run (--steps 20 --warmup 5 = 15 ms) would sit on that ramp.  So the device is first kept busy for 40 ms with
     # launches of ONE resident plan -- not warm-up steps of the measured call path, and reported as `spin_up`.
     spin_up = {"launches": 0, "ms": 0.0}
-    if not args.no_spin_up and hi > lo:
+    if not args.no_spin_up:
         ts = time.perf_counter()
-        while time.perf_counter() - ts < args.spin_up_ms * 1e-3:
+        while hi > lo and time.perf_counter() - ts < args.spin_up_ms * 1e-3:
             for _ in range(4):
                 plan.sample_philox_device(hi - lo, Niter, seed, lo, True, slots[0]["pts"], slots[0]["ind"], None, stream.cuda_stream)
             torch.cuda.synchronize()
@@ -257,6 +257,7 @@ def main():
         # runtime's event / signal / stream pools warming up, not this product's data -- scripts/first_pass_transient.py,
         # profiles/r06l_first_pass_transient.txt).  Rounds 3-4 measured inside that transient, round 5 behind an extra pass by
         # accident; now it is run here, untimed and counted: `spin_up.calls`.
+        # (every rank runs them, also one without chains of its own: with N > 1 a call ends in the collective)
         for i in range(args.spin_up_calls):
             one_call(16 * (args.warmup + args.steps) + i)
         drain()
